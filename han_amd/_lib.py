@@ -1,0 +1,109 @@
+"""ctypes binding of ``libhan_hip.so`` (the C ABI declared in ``include/han_hip.h``).
+
+The library is built in-tree by :func:`build` (``hipcc --offload-arch=gfx950``).
+There is NO fallback: if the shared object is missing or a symbol is absent the
+import of anything that computes raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhan_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ("node_attn.hip", "project.hip", "sem_attn.hip", "loss_opt.hip")
+
+P = c_void_p
+I64 = c_int64
+
+# name -> (restype, argtypes); mirrors include/han_hip.h one to one
+SIGNATURES = {
+    "han_abi_version": (c_int, []),
+    "han_error_string": (c_char_p, [c_int]),
+    "han_project_fwd": (c_int, [P, I64, P, P, P, P, P, P, P, P, P, I64, c_int, c_int, c_int,
+                                c_float, c_float, c_uint64, I64, P]),
+    "han_project_bwd_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
+    "han_project_bwd": (c_int, [P, I64, P, P, P, c_size_t, I64, c_int, c_int, c_int, c_float,
+                                c_uint64, I64, P]),
+    "han_node_attn_fwd": (c_int, [P, P, P, P, P, P, P, I64, P, P, P, P, I64, I64, c_int, c_int,
+                                  c_float, c_float, c_uint64, I64, c_int, P]),
+    "han_node_attn_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
+    "han_node_attn_bwd_rows": (c_int, [P, I64, P, P, P, P, P, P, P, P, P, P, P, c_size_t, I64,
+                                       c_int, c_int, c_int, P]),
+    "han_node_attn_bwd_cols": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, c_int,
+                                       c_float, c_float, c_float, c_uint64, I64, I64, P]),
+    "han_score_param_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
+    "han_score_param_bwd": (c_int, [P, P, P, P, P, P, P, P, c_size_t, I64, c_int, c_int, P]),
+    "han_sem_attn_fwd": (c_int, [P, P, P, P, P, P, I64, c_int, c_int, c_int, P]),
+    "han_sem_attn_bwd_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
+    "han_sem_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_size_t, I64, c_int, c_int,
+                                 c_int, P]),
+    "han_classifier_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
+    "han_classifier_loss": (c_int, [P, P, P, P, P, c_float, P, P, P, P, P, P, c_size_t, I64,
+                                    c_int, c_int, c_int, P]),
+    "han_adam_step": (c_int, [P, P, P, P, I64, c_float, c_float, c_float, c_float, c_float, P]),
+    "han_l2_half_sumsq": (c_int, [P, I64, P, P, c_size_t, P]),
+    "han_bias_row_counts": (c_int, [P, I64, I64, P, P]),
+    "han_bias_fill_csr": (c_int, [P, I64, I64, P, P, P]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class HanLibraryError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``han_amd/libhan_hip.so``."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "han_common.h"),
+                   os.path.join(_HERE, "..", "include", "han_hip.h")]
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(d) for d in deps)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise HanLibraryError("hipcc failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+def load():
+    """Load the library and bind every symbol of include/han_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HanLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "han_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HanLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.han_abi_version()
+    if v != ABI_VERSION:
+        raise HanLibraryError(f"libhan_hip.so ABI {v} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        msg = load().han_error_string(code)
+        raise HanLibraryError(f"{what or 'libhan_hip'} failed ({code}): "
+                              f"{msg.decode() if msg else '?'}")

@@ -1,0 +1,66 @@
+// Internal helpers shared by the gfx950 kernels of libhan_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/han_hip.h"
+
+#define HAN_D 64            // K*FP of this build: one projected row = 256 B
+#define HAN_NEG_BIG (-1.0e30f)
+
+#define HAN_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t _e = hipGetLastError();                   \
+        if (_e != hipSuccess) return (int)_e;                \
+    } while (0)
+
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// Counter-based dropout RNG.  One 32-bit hash per Bernoulli draw, keyed by
+// (seed, stream, a, b) so that forward and backward -- and any node partition --
+// regenerate the same mask from global ids.  tests/rng_ref.py restates it in
+// NumPy so that the oracle can be fed the identical masks.
+//   stream 0: input-feature dropout  a = global row,  b = f*K + k   (layers.py:19)
+//   stream 1: attention dropout      a = global dst i, b = j*K + k  (layers.py:30)
+//   stream 2: projected-row dropout  a = global row j, b = d        (layers.py:32)
+// ---------------------------------------------------------------------------
+#define HAN_STREAM_SEQ 0u
+#define HAN_STREAM_COEF 1u
+#define HAN_STREAM_FTS 2u
+
+__host__ __device__ __forceinline__ uint32_t han_hash(uint32_t seed_lo, uint32_t seed_hi,
+                                                      uint32_t stream, uint32_t a, uint32_t b) {
+    uint32_t h = (a * 0x9E3779B1u) ^ (seed_lo + stream * 0x7F4A7C15u);
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13;
+    h ^= b * 0xC2B2AE35u + seed_hi;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+// keep iff the top 24 bits are below keep_prob * 2^24
+__host__ __device__ __forceinline__ uint32_t han_keep_threshold(float keep_prob) {
+    return (uint32_t)(keep_prob * 16777216.0f);
+}
+__host__ __device__ __forceinline__ bool han_keep(uint32_t h, uint32_t thr) {
+    return (h >> 8) < thr;
+}
+
+__device__ __forceinline__ float han_lrelu(float x, float slope) { return fmaxf(x, slope * x); }
+
+__device__ __forceinline__ float han_elu(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }
+
+template <typename T>
+__device__ __forceinline__ T han_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
+
+__device__ __forceinline__ float han_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int han_grid_for(int64_t items, int per_block, int cap) {
+    int64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}

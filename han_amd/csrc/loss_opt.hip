@@ -1,0 +1,315 @@
+// Classifier + masked loss, optimiser, and the bias-matrix -> CSR input step (gfx950).
+//
+// Reference arithmetic:
+//   models/gat.py:65-72        logits = (1/HC) sum_h (Z Wc[h] + bc[h])
+//   models/base_gattn.py:41-48 masked softmax cross-entropy
+//   models/base_gattn.py:61-69 masked accuracy
+//   models/base_gattn.py:12-24 L2 on every trainable + tf.train.AdamOptimizer
+//   utils/process.py:14-25     additive bias matrix (edge <=> entry > -1e8)
+// All of it is row-local streaming work (HBM-bound, tiny next to K2).
+#include "han_common.h"
+
+namespace {
+
+constexpr int MAXC = 16;
+constexpr int kClsBlocks = 512;
+
+// slab row: [64*C] dWm | [C] dbm | loss | acc
+struct ClsArgs {
+    const float *Z, *Wc, *bc;
+    const int32_t *labels;
+    const uint8_t *mask;
+    float row_weight;
+    float *logits, *dZ, *slab;
+    int64_t N;
+    int C, HC;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
+    __shared__ float Wm[64 * MAXC];
+    __shared__ float bm[MAXC];
+    const int C = a.C;
+    const float invh = 1.f / (float)a.HC;
+    for (int i = threadIdx.x; i < 64 * C; i += 256) {
+        float s = 0.f;
+        for (int h = 0; h < a.HC; ++h) s += a.Wc[(int64_t)h * 64 * C + i];
+        Wm[i] = s * invh;
+    }
+    if (threadIdx.x < C) {
+        float s = 0.f;
+        for (int h = 0; h < a.HC; ++h) s += a.bc[h * C + threadIdx.x];
+        bm[threadIdx.x] = s * invh;
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 15;
+    const int64_t grp0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t ngrp = (int64_t)gridDim.x * 16;
+    float dW[4][MAXC];
+    float dbacc[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        dbacc[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dW[t][c] = 0.f;
+    }
+    float loss_acc = 0.f, acc_acc = 0.f;
+    for (int64_t row = grp0; row < a.N; row += ngrp) {
+        const float4_t z4 = *reinterpret_cast<const float4_t *>(a.Z + row * 64 + 4 * q);
+        float lg[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            float s = 0.f;
+            if (c < C) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) s += z4[t] * Wm[(4 * q + t) * C + c];
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+            lg[c] = c < C ? s + bm[c] : HAN_NEG_BIG;
+        }
+        if (q < C) {
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) v = (q == c) ? lg[c] : v;
+            a.logits[row * C + q] = v;
+        }
+        float mx = lg[0];
+        int am = 0;
+#pragma unroll
+        for (int c = 1; c < MAXC; ++c)
+            if (lg[c] > mx) { mx = lg[c]; am = c; }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) se += c < C ? __expf(lg[c] - mx) : 0.f;
+        const int lab = a.labels[row];
+        const float w = a.mask[row] ? a.row_weight : 0.f;
+        float llab = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) llab = (c == lab) ? lg[c] : llab;
+        if (q == 0) {
+            loss_acc += w * (mx + __logf(se) - llab);
+            acc_acc += w * (am == lab ? 1.f : 0.f);
+        }
+        if (BWD) {
+            const float inv = 1.f / se;
+            float dl[MAXC];
+            float4_t dz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                dl[c] = c < C ? w * (__expf(lg[c] - mx) * inv - (c == lab ? 1.f : 0.f)) : 0.f;
+                if (c < C) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        dz[t] += dl[c] * Wm[(4 * q + t) * C + c];
+                        dW[t][c] += z4[t] * dl[c];
+                    }
+                    if (q == 0) dbacc[c] += dl[c];
+                }
+            }
+            *reinterpret_cast<float4_t *>(a.dZ + row * 64 + 4 * q) = dz;
+        }
+    }
+    // block reduction: 16 groups -> one slab row.  Serialise the groups through
+    // Wm-sized scratch (one group adds at a time; 16 barriers, once per block).
+    __syncthreads();
+    float *scr = Wm;                  // [64*C]
+    __shared__ float sc2[MAXC + 2];   // db | loss | acc
+    const int grp = threadIdx.x >> 4;
+    for (int r = 0; r < 16; ++r) {
+        if (grp == r) {
+            if (BWD) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    if (c < C) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int idx = (4 * q + t) * C + c;
+                            scr[idx] = (r == 0 ? 0.f : scr[idx]) + dW[t][c];
+                        }
+                        if (q == 0) sc2[c] = (r == 0 ? 0.f : sc2[c]) + dbacc[c];
+                    }
+                }
+            }
+            if (q == 0) {
+                sc2[MAXC] = (r == 0 ? 0.f : sc2[MAXC]) + loss_acc;
+                sc2[MAXC + 1] = (r == 0 ? 0.f : sc2[MAXC + 1]) + acc_acc;
+            }
+        }
+        __syncthreads();
+    }
+    const int width = 64 * C + C + 2;
+    float *out = a.slab + (int64_t)blockIdx.x * width;
+    for (int i = threadIdx.x; i < width; i += 256) {
+        float v;
+        if (i < 64 * C) v = BWD ? scr[i] : 0.f;
+        else if (i < 64 * C + C) v = BWD ? sc2[i - 64 * C] : 0.f;
+        else v = sc2[MAXC + (i - 64 * C - C)];
+        out[i] = v;
+    }
+}
+
+__global__ void classifier_finish_kernel(const float *slab, int nblocks, int C, int HC, float *loss_acc,
+                                         float *dWc, float *dbc) {
+    const int width = 64 * C + C + 2;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= width) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += slab[(int64_t)b * width + n];
+    const float invh = 1.f / (float)HC;
+    if (n < 64 * C) {
+        if (dWc)
+            for (int h = 0; h < HC; ++h) dWc[(int64_t)h * 64 * C + n] = s * invh;
+    } else if (n < 64 * C + C) {
+        if (dbc)
+            for (int h = 0; h < HC; ++h) dbc[h * C + (n - 64 * C)] = s * invh;
+    } else {
+        loss_acc[n - 64 * C - C] = s;
+    }
+}
+
+__global__ void adam_kernel(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1,
+                            float b2, float eps, float l2) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float pi = p[i];
+        const float gi = g[i] + l2 * pi;             // d/dp of l2_coef * p^2/2
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float *p, int64_t n, float *partial) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += p[i] * p[i];
+    s = han_wave_sum(s);
+    __shared__ float w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+
+__global__ void sumsq_finish_kernel(const float *partial, int nblocks, float *out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 64) s += partial[i];
+    s = han_wave_sum(s);
+    if (threadIdx.x == 0) out[0] = 0.5f * s;
+}
+
+// one wave per row of the dense bias matrix
+__global__ __launch_bounds__(256) void bias_count_kernel(const float *bias, int64_t N, int64_t ld,
+                                                         int64_t *counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    int cnt = 0;
+    for (int64_t c0 = 0; c0 < N; c0 += 64) {
+        const int64_t c = c0 + lane;
+        const bool edge = c < N && bias[row * ld + c] > -1e8f;
+        cnt += __popcll(__ballot(edge));
+    }
+    if (lane == 0) counts[row] = cnt;
+}
+
+__global__ __launch_bounds__(256) void bias_fill_kernel(const float *bias, int64_t N, int64_t ld,
+                                                        const int64_t *rowptr, int32_t *colidx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    int64_t pos = rowptr[row];
+    for (int64_t c0 = 0; c0 < N; c0 += 64) {
+        const int64_t c = c0 + lane;
+        const bool edge = c < N && bias[row * ld + c] > -1e8f;
+        const unsigned long long b = __ballot(edge);
+        if (edge) colidx[pos + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)c;
+        pos += __popcll(b);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t han_classifier_workspace(int64_t N, int D, int C, int HC) {
+    (void)N; (void)D; (void)HC;
+    return (size_t)kClsBlocks * (size_t)(64 * C + C + 2) * sizeof(float);
+}
+
+extern "C" int han_classifier_loss(const float *Z, const float *Wc, const float *bc, const int32_t *labels,
+                                   const uint8_t *mask, float row_weight, float *logits, float *loss_acc,
+                                   float *dZ, float *dWc, float *dbc, void *workspace, size_t workspace_bytes,
+                                   int64_t N, int D, int C, int HC, void *stream) {
+    if (!Z || !Wc || !bc || !labels || !mask || !logits || !loss_acc || !workspace || N < 0 || HC <= 0)
+        return HAN_E_BADARG;
+    if (D != HAN_D || C < 1 || C > MAXC) return HAN_E_UNSUPPORTED;
+    const bool bwd = dZ != nullptr;
+    if (bwd && (!dWc || !dbc)) return HAN_E_BADARG;
+    if (workspace_bytes < han_classifier_workspace(N, D, C, HC)) return HAN_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    ClsArgs a;
+    a.Z = Z; a.Wc = Wc; a.bc = bc; a.labels = labels; a.mask = mask; a.row_weight = row_weight;
+    a.logits = logits; a.dZ = dZ; a.slab = (float *)workspace; a.N = N; a.C = C; a.HC = HC;
+    const int grid = han_grid_for(N > 0 ? N : 1, 16, kClsBlocks);
+    if (bwd) classifier_kernel<true><<<grid, 256, 0, st>>>(a);
+    else classifier_kernel<false><<<grid, 256, 0, st>>>(a);
+    HAN_CHECK_LAUNCH();
+    const int width = 64 * C + C + 2;
+    classifier_finish_kernel<<<(width + 255) / 256, 256, 0, st>>>((const float *)workspace, grid, C, HC,
+                                                                  loss_acc, bwd ? dWc : nullptr,
+                                                                  bwd ? dbc : nullptr);
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int han_adam_step(float *param, const float *grad, float *m, float *v, int64_t n, float lr_t,
+                             float beta1, float beta2, float eps, float l2_coef, void *stream) {
+    if (!param || !grad || !m || !v || n < 0) return HAN_E_BADARG;
+    if (n == 0) return 0;
+    adam_kernel<<<han_grid_for(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(param, grad, m, v, n, lr_t, beta1,
+                                                                            beta2, eps, l2_coef);
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int han_l2_half_sumsq(const float *param, int64_t n, float *out, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+    if (!param || !out || !workspace || n < 0) return HAN_E_BADARG;
+    if (workspace_bytes < 4096 * sizeof(float)) return HAN_E_WORKSPACE;
+    const int grid = han_grid_for(n > 0 ? n : 1, 256, 1024);
+    sumsq_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(param, n, (float *)workspace);
+    HAN_CHECK_LAUNCH();
+    sumsq_finish_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float *)workspace, grid, out);
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int han_bias_row_counts(const float *bias, int64_t N, int64_t ld, int64_t *counts, void *stream) {
+    if (!bias || !counts || N < 0 || ld < N) return HAN_E_BADARG;
+    if (N == 0) return 0;
+    bias_count_kernel<<<(unsigned)((N + 3) / 4), 256, 0, (hipStream_t)stream>>>(bias, N, ld, counts);
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int han_bias_fill_csr(const float *bias, int64_t N, int64_t ld, const int64_t *rowptr,
+                                 int32_t *colidx, void *stream) {
+    if (!bias || !rowptr || !colidx || N < 0 || ld < N) return HAN_E_BADARG;
+    if (N == 0) return 0;
+    bias_fill_kernel<<<(unsigned)((N + 3) / 4), 256, 0, (hipStream_t)stream>>>(bias, N, ld, rowptr, colidx);
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int han_abi_version(void) { return HAN_ABI_VERSION; }
+
+extern "C" const char *han_error_string(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case HAN_E_BADARG: return "han: bad argument (null pointer, negative size or inconsistent shape)";
+        case HAN_E_UNSUPPORTED: return "han: shape not supported by this build (needs K*FP == 64, FP in {4,8,16,32,64}, A in {64,128}, C <= 16)";
+        case HAN_E_WORKSPACE: return "han: workspace too small";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "han: unknown error";
+    }
+}

@@ -1,0 +1,640 @@
+// K2 -- node-level attention over CSR neighbours, forward and backward (gfx950).
+//
+// Reference arithmetic: utils/layers.py:26-35,46 (attn_head, dense additive
+// mask) == utils/layers.py:95-118,127 (sp_attn_head) restricted to stored
+// neighbours.  The N x N logits / coefficient tensors of the reference are never
+// materialised.
+//
+// Data layout (HBM): a projected row H_j is D = 64 fp32 = 256 B = two 128-B
+// lines; the per-head scores f2_j are K fp32 in a separate small table (hot in
+// L2 / Infinity Cache).  Lane mapping: a wave is 4 groups of 16 lanes; lane q of
+// a group owns features 4q..4q+3 (one dwordx4 = 16 B per lane, 256 B per group
+// per load instruction), i.e. head (4q)/FP.  The 4 groups take 4 different
+// neighbours of the same destination row per step, U steps are kept in flight,
+// so one wave has 4*U gathered rows (4 KiB at U=4) outstanding.  Softmax is an
+// online (running max / running sum) softmax per lane; the 4 groups' partial
+// (m, l, acc) are merged with two xor-shuffles (16, 32) at the end of the row.
+//
+// Roofline: HBM / Infinity-Cache gather bandwidth.  Algorithmic bytes per edge:
+// 4 (colidx) + 256 (H_j) + 4K (f2_j) = 292 B at K = 8.
+#include "han_common.h"
+
+namespace {
+
+struct FwdArgs {
+    const int64_t *rowptr;
+    const int32_t *colidx;
+    const float *H;
+    const float *f1;
+    const float *f2;
+    const float *c;
+    float *out;
+    int64_t out_stride;
+    float *pre, *lse, *aggp, *tsum;
+    int64_t N;
+    float slope;
+    uint32_t seed_lo, seed_hi, thr_coef;
+    float inv_keep_coef;
+    int64_t row_offset;
+    int activation;
+};
+
+// merge the online-softmax state of lane `lane ^ off` into this lane
+#define HAN_MERGE_STATE(off)                                                   \
+    {                                                                          \
+        const float m_o = __shfl_xor(m, off, 64);                              \
+        const float l_o = __shfl_xor(l, off, 64);                              \
+        const float M = fmaxf(m, m_o);                                         \
+        const float sa = __expf(m - M), sb = __expf(m_o - M);                  \
+        l = l * sa + l_o * sb;                                                 \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                          \
+            acc[t] = acc[t] * sa + __shfl_xor(acc[t], off, 64) * sb;           \
+        if (TRAIN) {                                                           \
+            tl = tl * sa + __shfl_xor(tl, off, 64) * sb;                       \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                      \
+                accp[t] = accp[t] * sa + __shfl_xor(accp[t], off, 64) * sb;    \
+        }                                                                      \
+        m = M;                                                                 \
+    }
+
+// One wave per destination row (RPW = 1) or one 16-lane group per row (RPW = 4,
+// for low-degree graphs).  TRAIN also produces pre / lse / aggp / tsum and
+// applies attention dropout when thr_coef < 2^24.
+template <int FP, bool TRAIN, int RPW, int U>
+__global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
+    constexpr int K = HAN_D / FP;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, q = lane & 15;
+    const int head = (4 * q) / FP;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const float4_t c4 = *reinterpret_cast<const float4_t *>(a.c + 4 * q);
+    const bool drop = TRAIN && a.thr_coef < 16777216u;
+    const int64_t nunits = (a.N + RPW - 1) / RPW;   // wave-sized work units
+
+    for (int64_t unit = wave0; unit < nunits; unit += nwaves) {
+        const int64_t row_raw = (RPW == 1) ? unit : unit * 4 + g;
+        const bool row_ok = row_raw < a.N;
+        const int64_t row = row_ok ? row_raw : a.N - 1;
+        const int64_t s = a.rowptr[row];
+        const int64_t e = row_ok ? a.rowptr[row + 1] : s;
+        const float f1h = a.f1[row * K + head];
+        const uint32_t gi = (uint32_t)(row + a.row_offset);
+
+        float m = HAN_NEG_BIG, l = 0.f, tl = 0.f;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float accp[4] = {0.f, 0.f, 0.f, 0.f};
+
+        if (RPW == 1) {
+            for (int64_t base = s; base < e; base += 64) {
+                const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
+                const int mycol = a.colidx[base + (lane < cnt ? lane : cnt - 1)];
+                for (int it = 0; it * 4 < cnt; it += U) {
+                    int j[U];
+                    bool valid[U];
+                    float4_t hv[U];
+                    float s2[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int idx = (it + u) * 4 + g;
+                        valid[u] = idx < cnt;
+                        j[u] = __shfl(mycol, idx & 63, 64);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        hv[u] = *reinterpret_cast<const float4_t *>(a.H + (int64_t)j[u] * HAN_D + 4 * q);
+                        s2[u] = a.f2[(int64_t)j[u] * K + head];
+                    }
+                    float ev[U], sg[U];
+                    float mc = m;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float x = f1h + s2[u];
+                        sg[u] = x > 0.f ? 1.f : a.slope;
+                        ev[u] = valid[u] ? han_lrelu(x, a.slope) : HAN_NEG_BIG;
+                        mc = fmaxf(mc, ev[u]);
+                    }
+                    const float sc = __expf(m - mc);
+                    l *= sc;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] *= sc;
+                    if (TRAIN) {
+                        tl *= sc;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) accp[t] *= sc;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float p = valid[u] ? __expf(ev[u] - mc) : 0.f;
+                        l += p;
+                        float pd = p;
+                        if (drop) {
+                            const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
+                                                        (uint32_t)j[u] * (uint32_t)K + (uint32_t)head);
+                            pd = han_keep(h, a.thr_coef) ? p * a.inv_keep_coef : 0.f;
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[t] += pd * hv[u][t];
+                        if (TRAIN) {
+                            tl += p * sg[u];
+                            const float pds = pd * sg[u];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) accp[t] += pds * hv[u][t];
+                        }
+                    }
+                    m = mc;
+                }
+            }
+            HAN_MERGE_STATE(16)
+            HAN_MERGE_STATE(32)
+        } else {
+            // each 16-lane group walks its own row; the wave loops to the longest
+            int64_t len = e - s;
+            int64_t maxlen = len;
+            {
+                int64_t o = __shfl_xor(maxlen, 16, 64);
+                maxlen = o > maxlen ? o : maxlen;
+                o = __shfl_xor(maxlen, 32, 64);
+                maxlen = o > maxlen ? o : maxlen;
+            }
+            for (int64_t it = 0; it < maxlen; it += U) {
+                int j[U];
+                bool valid[U];
+                float4_t hv[U];
+                float s2[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    valid[u] = it + u < len;
+                    const int64_t pos = valid[u] ? s + it + u : (len > 0 ? s : 0);
+                    j[u] = (len > 0) ? a.colidx[pos] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    hv[u] = *reinterpret_cast<const float4_t *>(a.H + (int64_t)j[u] * HAN_D + 4 * q);
+                    s2[u] = a.f2[(int64_t)j[u] * K + head];
+                }
+                float ev[U], sg[U];
+                float mc = m;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float x = f1h + s2[u];
+                    sg[u] = x > 0.f ? 1.f : a.slope;
+                    ev[u] = valid[u] ? han_lrelu(x, a.slope) : HAN_NEG_BIG;
+                    mc = fmaxf(mc, ev[u]);
+                }
+                const float sc = __expf(m - mc);
+                l *= sc;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] *= sc;
+                if (TRAIN) {
+                    tl *= sc;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) accp[t] *= sc;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float p = valid[u] ? __expf(ev[u] - mc) : 0.f;
+                    l += p;
+                    float pd = p;
+                    if (drop) {
+                        const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
+                                                    (uint32_t)j[u] * (uint32_t)K + (uint32_t)head);
+                        pd = han_keep(h, a.thr_coef) ? p * a.inv_keep_coef : 0.f;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] += pd * hv[u][t];
+                    if (TRAIN) {
+                        tl += p * sg[u];
+                        const float pds = pd * sg[u];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) accp[t] += pds * hv[u][t];
+                    }
+                }
+                m = mc;
+            }
+        }
+
+        // epilogue: normalise, bias, activation (layers.py:35,46)
+        const bool writer = row_ok && (RPW == 4 || g == 0);
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        float4_t pv, ov;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            pv[t] = acc[t] * inv + c4[t];
+            ov[t] = a.activation == HAN_ACT_ELU ? han_elu(pv[t]) : pv[t];
+        }
+        if (writer) {
+            *reinterpret_cast<float4_t *>(a.out + row * a.out_stride + 4 * q) = ov;
+            if (TRAIN) {
+                float4_t ap;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) ap[t] = accp[t] * inv;
+                *reinterpret_cast<float4_t *>(a.pre + row * HAN_D + 4 * q) = pv;
+                *reinterpret_cast<float4_t *>(a.aggp + row * HAN_D + 4 * q) = ap;
+                if ((4 * q) % FP == 0) {
+                    a.lse[row * K + head] = l > 0.f ? m + __logf(l) : HAN_NEG_BIG;
+                    a.tsum[row * K + head] = tl * inv;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward step 1: row-local pass
+// ---------------------------------------------------------------------------
+struct BwdRowsArgs {
+    const float *dOut;
+    int64_t dout_stride;
+    const float *pre, *aggp, *tsum, *f1, *lse, *c;
+    float *g, *stats, *df1;
+    float *slab;   // [gridDim.x][64] partial sums of g (for dc)
+    int64_t N;
+    int activation;
+};
+
+template <int FP>
+__device__ __forceinline__ float head_sum(float v) {
+    // sum over the FP/4 lanes that share a head (contiguous, aligned lanes)
+#pragma unroll
+    for (int o = 1; o < FP / 4; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int FP>
+__global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsArgs a) {
+    constexpr int K = HAN_D / FP;
+    const int q = threadIdx.x & 15;
+    const int head = (4 * q) / FP;
+    const int64_t grp0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t ngrp = (int64_t)gridDim.x * 16;
+    const float4_t c4 = *reinterpret_cast<const float4_t *>(a.c + 4 * q);
+    float dc[4] = {0.f, 0.f, 0.f, 0.f};
+    // all 16 lanes of a group run the same trip count -> shuffles are safe
+    for (int64_t row = grp0; row < a.N; row += ngrp) {
+        const float4_t d4 = *reinterpret_cast<const float4_t *>(a.dOut + row * a.dout_stride + 4 * q);
+        const float4_t p4 = *reinterpret_cast<const float4_t *>(a.pre + row * HAN_D + 4 * q);
+        const float4_t ap4 = *reinterpret_cast<const float4_t *>(a.aggp + row * HAN_D + 4 * q);
+        float4_t g4;
+        float sp = 0.f, dp = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float da = (a.activation == HAN_ACT_ELU && p4[t] <= 0.f) ? __expf(p4[t]) : 1.f;
+            g4[t] = d4[t] * da;
+            sp += g4[t] * (p4[t] - c4[t]);
+            dp += g4[t] * ap4[t];
+            dc[t] += g4[t];
+        }
+        sp = head_sum<FP>(sp);
+        dp = head_sum<FP>(dp);
+        *reinterpret_cast<float4_t *>(a.g + row * HAN_D + 4 * q) = g4;
+        if ((4 * q) % FP == 0) {
+            const float ts = a.tsum[row * K + head];
+            a.df1[row * K + head] = dp - sp * ts;
+            float4_t st;
+            st[0] = a.f1[row * K + head];
+            st[1] = a.lse[row * K + head];
+            st[2] = sp;
+            st[3] = 0.f;
+            *reinterpret_cast<float4_t *>(a.stats + (row * K + head) * 4) = st;
+        }
+    }
+    // block reduction of dc over the 16 groups
+    __shared__ float red[16][64];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) red[threadIdx.x >> 4][4 * q + t] = dc[t];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += red[r][threadIdx.x];
+        a.slab[(int64_t)blockIdx.x * 64 + threadIdx.x] = sacc;
+    }
+}
+
+// out[n] = sum_b slab[b][n]   (deterministic second stage of every reduction)
+__global__ void reduce_slabs_kernel(const float *slab, int nblocks, int width, float *out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= width) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += slab[(int64_t)b * width + n];
+    out[n] = s;
+}
+
+// ---------------------------------------------------------------------------
+// backward step 2: gather over the transposed graph (one wave per source row)
+// ---------------------------------------------------------------------------
+struct BwdColsArgs {
+    const int64_t *colptr;
+    const int32_t *rowidx;
+    const float *g, *stats, *H, *f2, *df1, *a1, *a2;
+    float *dH, *df2;
+    int64_t NS;
+    float slope;
+    uint32_t seed_lo, seed_hi, thr_coef, thr_fts;
+    float inv_keep_coef, inv_keep_fts;
+    int64_t src_offset, dst_offset;
+};
+
+template <int FP, int RPW, int U>
+__global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsArgs a) {
+    constexpr int K = HAN_D / FP;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, q = lane & 15;
+    const int head = (4 * q) / FP;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const bool drop_c = a.thr_coef < 16777216u;
+    const bool drop_f = a.thr_fts < 16777216u;
+    const float4_t a14 = *reinterpret_cast<const float4_t *>(a.a1 + 4 * q);
+    const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
+    const int64_t nunits = (a.NS + RPW - 1) / RPW;
+
+    for (int64_t unit = wave0; unit < nunits; unit += nwaves) {
+        const int64_t src_raw = (RPW == 1) ? unit : unit * 4 + g;
+        const bool src_ok = src_raw < a.NS;
+        const int64_t src = src_ok ? src_raw : a.NS - 1;
+        const int64_t s = a.colptr[src];
+        const int64_t e = src_ok ? a.colptr[src + 1] : s;
+        const uint32_t gj = (uint32_t)(src + a.src_offset);
+        const float f2h = a.f2[src * K + head];
+        // the dropped projected row H~_j = H_j * mask / keep (layers.py:32)
+        float4_t hd = *reinterpret_cast<const float4_t *>(a.H + src * HAN_D + 4 * q);
+        float mk[4] = {1.f, 1.f, 1.f, 1.f};
+        if (drop_f) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_FTS, gj, (uint32_t)(4 * q + t));
+                mk[t] = han_keep(h, a.thr_fts) ? a.inv_keep_fts : 0.f;
+                hd[t] *= mk[t];
+            }
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float dfacc = 0.f;
+        const int64_t len = e - s;
+        int64_t trips;
+        if (RPW == 1) {
+            trips = (len + 3) >> 2;
+        } else {
+            trips = len;
+            int64_t o = __shfl_xor(trips, 16, 64);
+            trips = o > trips ? o : trips;
+            o = __shfl_xor(trips, 32, 64);
+            trips = o > trips ? o : trips;
+        }
+        for (int64_t it = 0; it < trips; it += U) {
+            int i[U];
+            bool valid[U];
+            float4_t gv[U], st[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = (RPW == 1) ? (it + u) * 4 + g : it + u;
+                valid[u] = k < len;
+                i[u] = len > 0 ? a.rowidx[valid[u] ? s + k : s] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                gv[u] = *reinterpret_cast<const float4_t *>(a.g + (int64_t)i[u] * HAN_D + 4 * q);
+                st[u] = *reinterpret_cast<const float4_t *>(a.stats + ((int64_t)i[u] * K + head) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float x = st[u][0] + f2h;
+                const float sg = x > 0.f ? 1.f : a.slope;
+                float alpha = __expf(han_lrelu(x, a.slope) - st[u][1]);
+                alpha = valid[u] ? alpha : 0.f;
+                float am = 1.f;
+                if (drop_c) {
+                    const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_COEF,
+                                                (uint32_t)((int64_t)i[u] + a.dst_offset),
+                                                gj * (uint32_t)K + (uint32_t)head);
+                    am = han_keep(h, a.thr_coef) ? a.inv_keep_coef : 0.f;
+                }
+                float dot = gv[u][0] * hd[0] + gv[u][1] * hd[1] + gv[u][2] * hd[2] + gv[u][3] * hd[3];
+                dot = head_sum<FP>(dot);
+                dfacc += alpha * sg * (am * dot - st[u][2]);
+                const float w = alpha * am;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] += w * gv[u][t];
+            }
+        }
+        if (RPW == 1) {
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                dfacc += __shfl_xor(dfacc, off, 64);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] += __shfl_xor(acc[t], off, 64);
+            }
+        }
+        const bool writer = src_ok && (RPW == 4 || g == 0);
+        if (writer) {
+            const float d1 = a.df1[src * K + head];
+            float4_t o;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = acc[t] * mk[t] + d1 * a14[t] + dfacc * a24[t];
+            *reinterpret_cast<float4_t *>(a.dH + src * HAN_D + 4 * q) = o;
+            if ((4 * q) % FP == 0) a.df2[src * K + head] = dfacc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward step 3: score-parameter gradients (da1, da2, db1, db2)
+// slab row layout: [0,64) da1, [64,128) da2, [128,128+K) db1, [128+K,128+2K) db2
+// ---------------------------------------------------------------------------
+#define HAN_SP_WIDTH 160   // 128 + 2*16 (K <= 16)
+
+template <int FP>
+__global__ __launch_bounds__(256) void score_param_bwd_kernel(const float *H, const float *df1,
+                                                              const float *df2, float *slab, int64_t N) {
+    constexpr int K = HAN_D / FP;
+    const int q = threadIdx.x & 15;
+    const int head = (4 * q) / FP;
+    const int64_t grp0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t ngrp = (int64_t)gridDim.x * 16;
+    float d1[4] = {0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t row = grp0; row < N; row += ngrp) {
+        const float4_t h4 = *reinterpret_cast<const float4_t *>(H + row * HAN_D + 4 * q);
+        const float x1 = df1[row * K + head], x2 = df2[row * K + head];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            d1[t] += x1 * h4[t];
+            d2[t] += x2 * h4[t];
+        }
+        s1 += x1;
+        s2 += x2;
+    }
+    __shared__ float red[16][HAN_SP_WIDTH];
+    const int r = threadIdx.x >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        red[r][4 * q + t] = d1[t];
+        red[r][64 + 4 * q + t] = d2[t];
+    }
+    if ((4 * q) % FP == 0) {
+        red[r][128 + head] = s1;
+        red[r][128 + K + head] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128 + 2 * K) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) sacc += red[rr][threadIdx.x];
+        slab[(int64_t)blockIdx.x * HAN_SP_WIDTH + threadIdx.x] = sacc;
+    }
+}
+
+__global__ void score_param_finish_kernel(const float *slab, int nblocks, int K, float *da1, float *da2,
+                                          float *db1, float *db2) {
+    const int n = threadIdx.x;
+    if (n >= 128 + 2 * K) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += slab[(int64_t)b * HAN_SP_WIDTH + n];
+    if (n < 64) da1[n] = s;
+    else if (n < 128) da2[n - 64] = s;
+    else if (n < 128 + K) db1[n - 128] = s;
+    else db2[n - 128 - K] = s;
+}
+
+constexpr int kReduceBlocks = 1024;
+
+bool fp_supported(int K, int FP) {
+    return K * FP == HAN_D && (FP == 4 || FP == 8 || FP == 16 || FP == 32 || FP == 64);
+}
+
+// Launch geometry: 256-thread blocks, 4 waves each; cap the grid and grid-stride.
+int attn_grid(int64_t units) { return han_grid_for(units, 4, 256 * 8 * 4); }
+
+}  // namespace
+
+#define HAN_DISPATCH_FP(FPV, ...)                     \
+    switch (FPV) {                                    \
+        case 4: { constexpr int FPC = 4; __VA_ARGS__; } break;   \
+        case 8: { constexpr int FPC = 8; __VA_ARGS__; } break;   \
+        case 16: { constexpr int FPC = 16; __VA_ARGS__; } break; \
+        case 32: { constexpr int FPC = 32; __VA_ARGS__; } break; \
+        default: { constexpr int FPC = 64; __VA_ARGS__; } break; \
+    }
+
+// mean degree (E / N) below which a 16-lane group per row beats a wave per row
+static constexpr double kLowDegree = 12.0;
+
+extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float *H,
+                                 const float *f1, const float *f2, const float *c, float *out,
+                                 int64_t out_stride, float *pre, float *lse, float *aggp, float *tsum,
+                                 int64_t N, int64_t E, int K, int FP, float slope, float coef_drop,
+                                 uint64_t seed, int64_t row_offset, int activation, void *stream) {
+    if (!rowptr || !colidx || !H || !f1 || !f2 || !c || !out || N < 0 || E < 0 || out_stride < HAN_D)
+        return HAN_E_BADARG;
+    if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
+    const bool train = pre || lse || aggp || tsum;
+    if (train && !(pre && lse && aggp && tsum)) return HAN_E_BADARG;
+    if (coef_drop < 0.f || coef_drop >= 1.f) return HAN_E_BADARG;
+    if (coef_drop > 0.f && !train) return HAN_E_BADARG;
+    if (N == 0) return 0;
+    FwdArgs a;
+    a.rowptr = rowptr; a.colidx = colidx; a.H = H; a.f1 = f1; a.f2 = f2; a.c = c;
+    a.out = out; a.out_stride = out_stride; a.pre = pre; a.lse = lse; a.aggp = aggp; a.tsum = tsum;
+    a.N = N; a.slope = slope;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    const float keep = 1.f - coef_drop;
+    a.thr_coef = coef_drop > 0.f ? han_keep_threshold(keep) : 16777216u;
+    a.inv_keep_coef = 1.f / keep;
+    a.row_offset = row_offset; a.activation = activation;
+    hipStream_t st = (hipStream_t)stream;
+    const bool low = (double)E < kLowDegree * (double)N;
+    HAN_DISPATCH_FP(FP, {
+        if (low) {
+            const int grid = attn_grid((N + 3) / 4);
+            if (train) node_attn_fwd_kernel<FPC, true, 4, 2><<<grid, 256, 0, st>>>(a);
+            else node_attn_fwd_kernel<FPC, false, 4, 2><<<grid, 256, 0, st>>>(a);
+        } else {
+            const int grid = attn_grid(N);
+            if (train) node_attn_fwd_kernel<FPC, true, 1, 4><<<grid, 256, 0, st>>>(a);
+            else node_attn_fwd_kernel<FPC, false, 1, 4><<<grid, 256, 0, st>>>(a);
+        }
+    })
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t han_node_attn_bwd_workspace(int64_t N, int K, int FP) {
+    (void)N; (void)K; (void)FP;
+    return (size_t)kReduceBlocks * 64 * sizeof(float);
+}
+
+extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *pre,
+                                      const float *aggp, const float *tsum, const float *f1,
+                                      const float *lse, const float *c, float *g, float *stats,
+                                      float *df1, float *dc, void *workspace, size_t workspace_bytes,
+                                      int64_t N, int K, int FP, int activation, void *stream) {
+    if (!dOut || !pre || !aggp || !tsum || !f1 || !lse || !c || !g || !stats || !df1 || !dc || !workspace ||
+        N < 0 || dout_stride < HAN_D)
+        return HAN_E_BADARG;
+    if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
+    if (workspace_bytes < han_node_attn_bwd_workspace(N, K, FP)) return HAN_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    BwdRowsArgs a;
+    a.dOut = dOut; a.dout_stride = dout_stride; a.pre = pre; a.aggp = aggp; a.tsum = tsum;
+    a.f1 = f1; a.lse = lse; a.c = c; a.g = g; a.stats = stats; a.df1 = df1;
+    a.slab = (float *)workspace; a.N = N; a.activation = activation;
+    const int grid = han_grid_for(N, 16, kReduceBlocks);
+    HAN_DISPATCH_FP(FP, { node_attn_bwd_rows_kernel<FPC><<<grid, 256, 0, st>>>(a); })
+    HAN_CHECK_LAUNCH();
+    reduce_slabs_kernel<<<1, 64, 0, st>>>((const float *)workspace, grid, 64, dc);
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const float *g,
+                                      const float *stats, const float *H, const float *f2,
+                                      const float *df1, const float *a1, const float *a2, float *dH,
+                                      float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
+                                      float coef_drop, float fts_drop, uint64_t seed, int64_t src_offset,
+                                      int64_t dst_offset, void *stream) {
+    if (!colptr || !rowidx || !g || !stats || !H || !f2 || !df1 || !a1 || !a2 || !dH || !df2 || NS < 0 || E < 0)
+        return HAN_E_BADARG;
+    if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
+    if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
+    if (NS == 0) return 0;
+    BwdColsArgs a;
+    a.colptr = colptr; a.rowidx = rowidx; a.g = g; a.stats = stats; a.H = H; a.f2 = f2; a.df1 = df1;
+    a.a1 = a1; a.a2 = a2; a.dH = dH; a.df2 = df2; a.NS = NS; a.slope = slope;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : 16777216u;
+    a.thr_fts = fts_drop > 0.f ? han_keep_threshold(1.f - fts_drop) : 16777216u;
+    a.inv_keep_coef = 1.f / (1.f - coef_drop);
+    a.inv_keep_fts = 1.f / (1.f - fts_drop);
+    a.src_offset = src_offset; a.dst_offset = dst_offset;
+    hipStream_t st = (hipStream_t)stream;
+    const bool low = (double)E < kLowDegree * (double)NS;
+    HAN_DISPATCH_FP(FP, {
+        if (low) node_attn_bwd_cols_kernel<FPC, 4, 2><<<attn_grid((NS + 3) / 4), 256, 0, st>>>(a);
+        else node_attn_bwd_cols_kernel<FPC, 1, 4><<<attn_grid(NS), 256, 0, st>>>(a);
+    })
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t han_score_param_bwd_workspace(int64_t N, int K, int FP) {
+    (void)N; (void)K; (void)FP;
+    return (size_t)kReduceBlocks * HAN_SP_WIDTH * sizeof(float);
+}
+
+extern "C" int han_score_param_bwd(const float *H, const float *df1, const float *df2, float *da1,
+                                   float *da2, float *db1, float *db2, void *workspace,
+                                   size_t workspace_bytes, int64_t N, int K, int FP, void *stream) {
+    if (!H || !df1 || !df2 || !da1 || !da2 || !db1 || !db2 || !workspace || N < 0) return HAN_E_BADARG;
+    if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
+    if (workspace_bytes < han_score_param_bwd_workspace(N, K, FP)) return HAN_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = han_grid_for(N, 16, kReduceBlocks);
+    HAN_DISPATCH_FP(FP, {
+        score_param_bwd_kernel<FPC><<<grid, 256, 0, st>>>(H, df1, df2, (float *)workspace, N);
+    })
+    HAN_CHECK_LAUNCH();
+    score_param_finish_kernel<<<1, 256, 0, st>>>((const float *)workspace, grid, K, da1, da2, db1, db2);
+    HAN_CHECK_LAUNCH();
+    return 0;
+}

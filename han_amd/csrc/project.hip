@@ -1,0 +1,368 @@
+// K1 -- dense feature projection for all K heads of one meta-path (gfx950).
+//
+// Reference arithmetic: utils/layers.py:18-24 (per head: input dropout, 1x1
+// conv1d == X @ W_k, two 1x1 conv1d == H_k . a + b) and :31-32 (dropout of the
+// projected rows, applied after the scores were taken from the undropped rows).
+//
+// The only GEMM-shaped work on the path, so the only MFMA user: exact-fp32
+// v_mfma_f32_16x16x4_f32 (no xf32/TF32 on gfx950).  M = N rows, N = D = 64
+// columns, K = F.  A block of 4 waves owns 64 rows x all 64 columns, so X is
+// read from HBM exactly once; W (F x 64) is re-read per block from L2.
+// Roofline at F = 256: 2*N*F*64 flop vs N*(F+64)*4 B -> ~24 flop/B, i.e. at the
+// fp32-MFMA ridge: HBM-bound in eval, MFMA-bound in training where the per-head
+// input dropout (layers.py:18-19 sits inside the per-head call) forces one
+// masked MFMA per head per 16-column tile.
+#include "han_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64;      // rows per block (forward)
+constexpr int BK = 32;      // K-step
+constexpr int XS_LD = 34;   // LDS leading dims chosen conflict-free for the MFMA fragment reads
+constexpr int WS_LD = 80;
+
+struct ProjFwdArgs {
+    const float *X;
+    int64_t ldx;
+    const float *W;
+    float *H;
+    int64_t N;
+    int F;
+    uint32_t seed_lo, seed_hi, thr_in;
+    float inv_keep_in;
+    int64_t row_offset;
+};
+
+// heads covered by one 16-column MFMA tile
+template <int FP>
+struct HeadsPerTile { static constexpr int value = FP >= 16 ? 1 : 16 / FP; };
+
+template <int FP, bool DROP>
+__global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
+    constexpr int K = HAN_D / FP;
+    constexpr int HPT = HeadsPerTile<FP>::value;
+    __shared__ float Xs[BM * XS_LD];
+    __shared__ float Ws[BK * WS_LD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float xr[8], wr[8];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx >> 5, cc = idx & 31;
+            const int64_t row = row0 + r;
+            const int k = k0 + cc;
+            xr[i] = (row < a.N && k < a.F) ? a.X[row * a.ldx + k] : 0.f;
+            const int wr_r = idx >> 6, wr_c = idx & 63;
+            const int kw = k0 + wr_r;
+            wr[i] = kw < a.F ? a.W[(int64_t)kw * HAN_D + wr_c] : 0.f;
+        }
+    };
+    load_tile(0);
+    const uint32_t nglob = (uint32_t)(row0 + 16 * w + l15 + a.row_offset);
+    for (int k0 = 0; k0 < a.F; k0 += BK) {
+        __syncthreads();   // previous tile's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i;
+            Xs[(idx >> 5) * XS_LD + (idx & 31)] = xr[i];
+            Ws[(idx >> 6) * WS_LD + (idx & 63)] = wr[i];
+        }
+        __syncthreads();
+        if (k0 + BK < a.F) load_tile(k0 + BK);   // in flight under the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            const float av = Xs[(16 * w + l15) * XS_LD + kk + l4];
+            uint32_t kglob = (uint32_t)(k0 + kk + l4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float bv = Ws[(kk + l4) * WS_LD + 16 * t + l15];
+                if (!DROP) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int hh = 0; hh < HPT; ++hh) {
+                        const int head = (16 * t) / FP + hh;
+                        const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob,
+                                                    kglob * (uint32_t)K + (uint32_t)head);
+                        const float am = han_keep(h, a.thr_in) ? av : 0.f;
+                        const float bm = (HPT == 1 || (l15 / FP) == hh) ? bv : 0.f;
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 16 * w + l4 * 4 + r;
+            if (row < a.N) a.H[row * HAN_D + 16 * t + l15] = DROP ? acc[t][r] * a.inv_keep_in : acc[t][r];
+        }
+    }
+}
+
+// Row-local epilogue: f1 = H_k.a1 + b1, f2 = H_k.a2 + b2 (layers.py:23-24) and the
+// dropped copy Hd = dropout(H) that the aggregation gathers (layers.py:31-32).
+struct ScoreArgs {
+    const float *H, *a1, *a2, *b1, *b2;
+    float *f1, *f2, *Hd;
+    int64_t N;
+    uint32_t seed_lo, seed_hi, thr_fts;
+    float inv_keep_fts;
+    int64_t row_offset;
+};
+
+template <int FP>
+__global__ __launch_bounds__(256) void project_scores_kernel(const ScoreArgs a) {
+    constexpr int K = HAN_D / FP;
+    const int q = threadIdx.x & 15;
+    const int head = (4 * q) / FP;
+    const int64_t grp0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t ngrp = (int64_t)gridDim.x * 16;
+    const float4_t a14 = *reinterpret_cast<const float4_t *>(a.a1 + 4 * q);
+    const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
+    const float b1 = a.b1[head], b2 = a.b2[head];
+    for (int64_t row = grp0; row < a.N; row += ngrp) {
+        const float4_t h4 = *reinterpret_cast<const float4_t *>(a.H + row * HAN_D + 4 * q);
+        float s1 = h4[0] * a14[0] + h4[1] * a14[1] + h4[2] * a14[2] + h4[3] * a14[3];
+        float s2 = h4[0] * a24[0] + h4[1] * a24[1] + h4[2] * a24[2] + h4[3] * a24[3];
+#pragma unroll
+        for (int o = 1; o < FP / 4; o <<= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+        }
+        if ((4 * q) % FP == 0) {
+            a.f1[row * K + head] = s1 + b1;
+            a.f2[row * K + head] = s2 + b2;
+        }
+        if (a.Hd) {
+            float4_t d4;
+            const uint32_t gr = (uint32_t)(row + a.row_offset);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_FTS, gr, (uint32_t)(4 * q + t));
+                d4[t] = han_keep(h, a.thr_fts) ? h4[t] * a.inv_keep_fts : 0.f;
+            }
+            *reinterpret_cast<float4_t *>(a.Hd + row * HAN_D + 4 * q) = d4;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward: dW = X~^T dH.  Output tile 64 (f) x 64 (d) per block, reduction over
+// a chunk of rows; partial tiles go to a slab, a second kernel sums the chunks
+// (deterministic, no float atomics).
+// ---------------------------------------------------------------------------
+constexpr int BF = 64;       // f rows of dW per block
+constexpr int BN = 32;       // reduction step (rows of X / dH)
+constexpr int TS_LD = 80;
+
+struct ProjBwdArgs {
+    const float *X;
+    int64_t ldx;
+    const float *dH;
+    float *slab;   // [nchunks][F][64]
+    int64_t N;
+    int F;
+    int64_t rows_per_chunk;
+    uint32_t seed_lo, seed_hi, thr_in;
+    float inv_keep_in;
+    int64_t row_offset;
+};
+
+template <int FP, bool DROP>
+__global__ __launch_bounds__(256) void project_bwd_kernel(const ProjBwdArgs a) {
+    constexpr int K = HAN_D / FP;
+    constexpr int HPT = HeadsPerTile<FP>::value;
+    __shared__ float Xs[BN * TS_LD];
+    __shared__ float Gs[BN * TS_LD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int f0 = blockIdx.x * BF;
+    const int64_t chunk = blockIdx.y;
+    const int64_t n_begin = chunk * a.rows_per_chunk;
+    const int64_t n_end = (n_begin + a.rows_per_chunk < a.N) ? n_begin + a.rows_per_chunk : a.N;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float xr[8], gr[8];
+    auto load_tile = [&](int64_t n0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx >> 6, cc = idx & 63;
+            const int64_t row = n0 + r;
+            const int f = f0 + cc;
+            xr[i] = (row < n_end && f < a.F) ? a.X[row * a.ldx + f] : 0.f;
+            gr[i] = row < n_end ? a.dH[row * HAN_D + cc] : 0.f;
+        }
+    };
+    load_tile(n_begin);
+    const uint32_t fglob = (uint32_t)(f0 + 16 * w + l15);
+    for (int64_t n0 = n_begin; n0 < n_end; n0 += BN) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i;
+            Xs[(idx >> 6) * TS_LD + (idx & 63)] = xr[i];
+            Gs[(idx >> 6) * TS_LD + (idx & 63)] = gr[i];
+        }
+        __syncthreads();
+        if (n0 + BN < n_end) load_tile(n0 + BN);
+#pragma unroll
+        for (int kk = 0; kk < BN; kk += 4) {
+            // A[i = f][k = n] = X[n][f]
+            const float av = Xs[(kk + l4) * TS_LD + 16 * w + l15];
+            const uint32_t nglob = (uint32_t)(n0 + kk + l4 + a.row_offset);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float bv = Gs[(kk + l4) * TS_LD + 16 * t + l15];
+                if (!DROP) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int hh = 0; hh < HPT; ++hh) {
+                        const int head = (16 * t) / FP + hh;
+                        const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob,
+                                                    fglob * (uint32_t)K + (uint32_t)head);
+                        const float am = han_keep(h, a.thr_in) ? av : 0.f;
+                        const float bm = (HPT == 1 || (l15 / FP) == hh) ? bv : 0.f;
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    float *out = a.slab + chunk * (int64_t)a.F * HAN_D;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = f0 + 16 * w + l4 * 4 + r;
+            if (f < a.F) out[(int64_t)f * HAN_D + 16 * t + l15] = DROP ? acc[t][r] * a.inv_keep_in : acc[t][r];
+        }
+    }
+}
+
+__global__ void project_bwd_reduce_kernel(const float *slab, int64_t nchunks, int64_t width, float *dW) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= width) return;
+    float s = 0.f;
+    for (int64_t ch = 0; ch < nchunks; ++ch) s += slab[ch * width + n];
+    dW[n] = s;
+}
+
+bool fp_ok(int K, int FP) {
+    return K * FP == HAN_D && (FP == 4 || FP == 8 || FP == 16 || FP == 32 || FP == 64);
+}
+
+void bwd_geometry(int64_t N, int F, int *ftiles, int64_t *rows_per_chunk, int64_t *nchunks) {
+    *ftiles = (F + BF - 1) / BF;
+    int64_t target = 2048 / *ftiles;
+    if (target < 1) target = 1;
+    int64_t rpc = (N + target - 1) / target;
+    rpc = ((rpc + BN - 1) / BN) * BN;
+    if (rpc < BN) rpc = BN;
+    *rows_per_chunk = rpc;
+    *nchunks = N > 0 ? (N + rpc - 1) / rpc : 1;
+}
+
+}  // namespace
+
+#define HAN_DISPATCH_FP(FPV, ...)                                 \
+    switch (FPV) {                                                \
+        case 4: { constexpr int FPC = 4; __VA_ARGS__; } break;    \
+        case 8: { constexpr int FPC = 8; __VA_ARGS__; } break;    \
+        case 16: { constexpr int FPC = 16; __VA_ARGS__; } break;  \
+        case 32: { constexpr int FPC = 32; __VA_ARGS__; } break;  \
+        default: { constexpr int FPC = 64; __VA_ARGS__; } break;  \
+    }
+
+extern "C" int han_project_fwd(const float *X, int64_t ldx, const float *W, const float *a1,
+                               const float *a2, const float *b1, const float *b2, float *H, float *Hd,
+                               float *f1, float *f2, int64_t N, int F, int K, int FP, float in_drop,
+                               float fts_drop, uint64_t seed, int64_t row_offset, void *stream) {
+    if (!X || !W || !a1 || !a2 || !b1 || !b2 || !H || !f1 || !f2 || N < 0 || F <= 0 || ldx < F)
+        return HAN_E_BADARG;
+    if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
+    if (in_drop < 0.f || in_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
+    if (fts_drop > 0.f && !Hd) return HAN_E_BADARG;
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    ProjFwdArgs a;
+    a.X = X; a.ldx = ldx; a.W = W; a.H = H; a.N = N; a.F = F;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : 16777216u;
+    a.inv_keep_in = 1.f / (1.f - in_drop);
+    a.row_offset = row_offset;
+    const int grid = (int)((N + BM - 1) / BM);
+    HAN_DISPATCH_FP(FP, {
+        if (in_drop > 0.f) project_fwd_kernel<FPC, true><<<grid, 256, 0, st>>>(a);
+        else project_fwd_kernel<FPC, false><<<grid, 256, 0, st>>>(a);
+    })
+    HAN_CHECK_LAUNCH();
+    ScoreArgs s;
+    s.H = H; s.a1 = a1; s.a2 = a2; s.b1 = b1; s.b2 = b2; s.f1 = f1; s.f2 = f2;
+    s.Hd = fts_drop > 0.f ? Hd : nullptr;
+    s.N = N; s.seed_lo = a.seed_lo; s.seed_hi = a.seed_hi;
+    s.thr_fts = fts_drop > 0.f ? han_keep_threshold(1.f - fts_drop) : 16777216u;
+    s.inv_keep_fts = 1.f / (1.f - fts_drop);
+    s.row_offset = row_offset;
+    const int sgrid = han_grid_for(N, 16, 256 * 8);
+    HAN_DISPATCH_FP(FP, { project_scores_kernel<FPC><<<sgrid, 256, 0, st>>>(s); })
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t han_project_bwd_workspace(int64_t N, int F, int K, int FP) {
+    (void)K; (void)FP;
+    int ftiles; int64_t rpc, nch;
+    bwd_geometry(N, F, &ftiles, &rpc, &nch);
+    return (size_t)nch * (size_t)F * HAN_D * sizeof(float);
+}
+
+extern "C" int han_project_bwd(const float *X, int64_t ldx, const float *dH, float *dW, void *workspace,
+                               size_t workspace_bytes, int64_t N, int F, int K, int FP, float in_drop,
+                               uint64_t seed, int64_t row_offset, void *stream) {
+    if (!X || !dH || !dW || !workspace || N < 0 || F <= 0 || ldx < F) return HAN_E_BADARG;
+    if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
+    if (in_drop < 0.f || in_drop >= 1.f) return HAN_E_BADARG;
+    if (workspace_bytes < han_project_bwd_workspace(N, F, K, FP)) return HAN_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int ftiles; int64_t rpc, nch;
+    bwd_geometry(N, F, &ftiles, &rpc, &nch);
+    ProjBwdArgs a;
+    a.X = X; a.ldx = ldx; a.dH = dH; a.slab = (float *)workspace; a.N = N; a.F = F;
+    a.rows_per_chunk = rpc;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : 16777216u;
+    a.inv_keep_in = 1.f / (1.f - in_drop);
+    a.row_offset = row_offset;
+    dim3 grid(ftiles, (unsigned)nch);
+    HAN_DISPATCH_FP(FP, {
+        if (in_drop > 0.f) project_bwd_kernel<FPC, true><<<grid, 256, 0, st>>>(a);
+        else project_bwd_kernel<FPC, false><<<grid, 256, 0, st>>>(a);
+    })
+    HAN_CHECK_LAUNCH();
+    const int64_t width = (int64_t)F * HAN_D;
+    project_bwd_reduce_kernel<<<(unsigned)((width + 255) / 256), 256, 0, st>>>((const float *)workspace, nch,
+                                                                               width, dW);
+    HAN_CHECK_LAUNCH();
+    return 0;
+}

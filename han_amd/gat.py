@@ -1,0 +1,204 @@
+"""``models/gat.py`` surface: :class:`HeteGAT_multi`.
+
+The reference builds a TF graph by calling ``HeteGAT_multi.inference(...)`` on
+the CLASS (it is defined without ``self``, ``models/gat.py:35``; called as
+``model.inference(...)`` with ``model = HeteGAT_multi``, ``ex_acm3025.py:31,139``);
+variables are created implicitly on that first call.  Here the same call works
+on the class (a process-wide default instance plays the role of TF's default
+graph) or on an instance; parameters are created on the first call from the
+shapes of the arguments, with the reference's initialisers, and live in ONE
+flat fp32 buffer (so that Adam and the gradient all-reduce are one launch /
+one collective).
+"""
+from __future__ import annotations
+
+import functools
+import math
+
+import torch
+import torch.nn.functional as F_torch
+
+from . import layers, ops, rng
+from .base_gattn import BaseGAttN
+from .dist import NodePartition
+from .graph import CSRGraph, as_graph
+
+D = ops.D
+
+
+class _ClassOrInstance:
+    """Lets ``Cls.method(...)`` run on a lazily created default instance."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        functools.update_wrapper(self, fn)
+
+    def __get__(self, obj, objtype=None):
+        if obj is None:
+            obj = objtype.default_instance()
+        return functools.partial(self.fn, obj)
+
+
+# name -> shape builder; order == flat layout == gradient all-reduce layout
+def _param_shapes(P, F, K, FP, A, C, HC):
+    return [("W", (P, F, D)), ("a1", (P, K, FP)), ("b1", (P, K)), ("a2", (P, K, FP)),
+            ("b2", (P, K)), ("c", (P, D)), ("w_omega", (D, A)), ("b_omega", (A,)),
+            ("u_omega", (A,)), ("Wc", (HC, D, C)), ("bc", (HC, C))]
+
+
+class HeteGAT_multi(BaseGAttN, torch.nn.Module):
+    """models/gat.py:34-77."""
+
+    _default = None
+
+    def __init__(self, device=None):
+        torch.nn.Module.__init__(self)
+        self._built = False
+        self._device = torch.device(device) if device is not None else None
+        self.partition: NodePartition | None = None
+        self._graph_cache: dict = {}
+
+    @classmethod
+    def default_instance(cls):
+        if cls._default is None:
+            cls._default = cls()
+        return cls._default
+
+    @classmethod
+    def reset_default(cls):
+        """tf.reset_default_graph() analogue."""
+        cls._default = None
+
+    # ------------------------------------------------------------------ params
+    def build(self, n_metapaths, ft_size, nb_classes, hid_units=(8,), n_heads=(8, 1),
+              mp_att_size=128, device=None, generator: torch.Generator | None = None):
+        """Create the variables the reference's first inference() call creates
+        (SURVEY.md 8a): glorot-uniform conv1d/dense kernels, zero biases,
+        N(0, 0.1^2) semantic-attention variables."""
+        if len(hid_units) != 1:
+            raise NotImplementedError("multi-layer node attention (len(hid_units) > 1, "
+                                      "models/gat.py:48-57) is not built yet")
+        K, FP, HC = int(n_heads[0]), int(hid_units[0]), int(n_heads[-1])
+        ops._check_heads(K, FP)
+        if mp_att_size not in (64, 128):
+            raise NotImplementedError("mp_att_size must be 64 or 128 in this build")
+        if not (1 <= nb_classes <= 16):
+            raise NotImplementedError("nb_classes must be in [1,16] in this build")
+        dev = torch.device(device) if device is not None else (self._device or torch.device("cuda:0"))
+        self.P, self.F, self.K, self.FP = int(n_metapaths), int(ft_size), K, FP
+        self.A, self.C, self.HC = int(mp_att_size), int(nb_classes), HC
+        shapes = _param_shapes(self.P, self.F, K, FP, self.A, self.C, HC)
+        total = sum(math.prod(s) for _, s in shapes)
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.register_buffer("flat", flat, persistent=False)        # storage owner
+        self.register_buffer("flat_grad", torch.zeros_like(flat), persistent=False)
+        self._views = {}
+        off = 0
+        for name, shp in shapes:
+            n = math.prod(shp)
+            v = torch.nn.Parameter(self.flat[off:off + n].view(shp), requires_grad=True)
+            v.grad = self.flat_grad[off:off + n].view(shp)
+            self._views[name] = v
+            self.register_parameter(name, v)
+            off += n
+        g = generator
+
+        def uni(t, limit):
+            t.data.copy_((torch.rand(t.shape, generator=g, dtype=torch.float32) * 2 - 1) * limit)
+
+        def nrm(t, std):
+            t.data.copy_(torch.randn(t.shape, generator=g, dtype=torch.float32) * std)
+
+        uni(self.W, math.sqrt(6.0 / (self.F + FP)))          # conv1d kernel (1,F,F')
+        uni(self.a1, math.sqrt(6.0 / (FP + 1)))              # conv1d kernel (1,F',1)
+        uni(self.a2, math.sqrt(6.0 / (FP + 1)))
+        nrm(self.w_omega, 0.1)                               # utils/layers.py:145-147
+        nrm(self.b_omega, 0.1)
+        nrm(self.u_omega, 0.1)
+        uni(self.Wc, math.sqrt(6.0 / (D + self.C)))          # tf.layers.dense kernel
+        self._built = True
+        return self
+
+    def trainable(self):
+        return [self._views[n] for n, _ in _param_shapes(self.P, self.F, self.K, self.FP,
+                                                         self.A, self.C, self.HC)]
+
+    def zero_grad_flat(self):
+        """Zero the flat gradient buffer and (re)bind every .grad to its slice."""
+        self.flat_grad.zero_()
+        self._rebind_grads()
+
+    def _rebind_grads(self):
+        off = 0
+        for name, shp in _param_shapes(self.P, self.F, self.K, self.FP, self.A, self.C, self.HC):
+            n = math.prod(shp)
+            self._views[name].grad = self.flat_grad[off:off + n].view(shp)
+            off += n
+
+    # ---------------------------------------------------------------- forward
+    def _graphs(self, bias_mat_list, device):
+        out = []
+        for b in bias_mat_list:
+            if isinstance(b, CSRGraph):
+                out.append(b if b.device == device else b.to(device))
+                continue
+            key = id(b)
+            hit = self._graph_cache.get(key)
+            if hit is None or hit[0] is not b:
+                hit = (b, as_graph(b, device))     # dense mask -> CSR once per tensor identity
+                self._graph_cache[key] = hit
+            out.append(hit[1])
+        return out
+
+    def node_level(self, xs, graphs, attn_drop, ffd_drop, train, act_code, graphs_t=None):
+        cfg = {"train": train, "in_drop": float(ffd_drop), "coef_drop": float(attn_drop),
+               "seeds": tuple(rng.next_seed() for _ in graphs) if train else (0,) * len(graphs),
+               "act": act_code, "part": self.partition, "graphs_t": graphs_t}
+        return layers.NodeLevelAttention.apply(self.W, self.a1, self.b1, self.a2, self.b2, self.c,
+                                               tuple(xs), tuple(graphs), cfg)
+
+    @_ClassOrInstance
+    def inference(self, inputs_list, nb_classes, nb_nodes, training, attn_drop, ffd_drop,
+                  bias_mat_list, hid_units, n_heads, activation=F_torch.elu, residual=False,
+                  mp_att_size=128):
+        """Same positional arguments as models/gat.py:35-37.  `inputs_list[p]`:
+        (1,N,F) or (N,F) fp32 GPU tensor; `bias_mat_list[p]`: (1,N,N) additive
+        mask, CSRGraph or (rowptr, colidx).  Lists are zipped, shorter wins
+        (gat.py:39).  `training` and `nb_nodes` are accepted and ignored, as in
+        the reference; dropout is driven by attn_drop / ffd_drop alone.
+        Returns (logits (1,N,C), final_embed (N,K*F'), att_val (N,P))."""
+        if residual:
+            raise NotImplementedError("residual=True is not built (it is False in every "
+                                      "reference config; utils/layers.py:38-42)")
+        n = min(len(inputs_list), len(bias_mat_list))
+        xs = [layers._squeeze_batch(x, f"inputs_list[{i}]") for i, x in enumerate(inputs_list[:n])]
+        for x in xs:
+            if not x.is_cuda:
+                raise ValueError("inputs must be GPU tensors: han_amd has no CPU path")
+        dev = xs[0].device
+        if not self._built:
+            self.build(n, xs[0].shape[1], nb_classes, hid_units, n_heads, mp_att_size, device=dev)
+        if n != self.P or xs[0].shape[1] != self.F or nb_classes != self.C:
+            raise ValueError("arguments do not match the variables created by the first call")
+        graphs = self._graphs(bias_mat_list[:n], dev)
+        for x, g in zip(xs, graphs):
+            if g.n_rows != x.shape[0]:
+                raise ValueError(f"graph has {g.n_rows} rows, features have {x.shape[0]}")
+        code, post = layers._act_code(activation)
+        if post is not None:
+            raise NotImplementedError("only ELU / identity activations run inside the kernels")
+        train = torch.is_grad_enabled() and self.W.requires_grad
+        attn_drop, ffd_drop = float(attn_drop), float(ffd_drop)
+        if not train and (attn_drop > 0 or ffd_drop > 0):
+            raise ValueError("dropout > 0 needs gradients enabled (training step)")
+        M = self.node_level(xs, graphs, attn_drop, ffd_drop, train, code)          # gat.py:39-60
+        final_embed, att_val = layers.SemanticAttention.apply(M, self.w_omega,     # gat.py:61-63
+                                                              self.b_omega, self.u_omega)
+        logits = layers.classifier(final_embed, self.Wc, self.bc)                  # gat.py:65-72
+        return logits[None], final_embed, att_val                                  # gat.py:76-77
+
+    def forward(self, inputs_list, bias_mat_list, attn_drop=0.0, ffd_drop=0.0):
+        if not self._built:
+            raise RuntimeError("call build(...) or inference(...) first")
+        return self.inference(inputs_list, self.C, None, None, attn_drop, ffd_drop, bias_mat_list,
+                              [self.FP], [self.K, self.HC], mp_att_size=self.A)

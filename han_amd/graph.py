@@ -1,0 +1,197 @@
+"""Meta-path graphs in the layout the HIP kernels read: CSR with int64 row
+pointers and int32 neighbour ids, plus the transposed (CSC) form the backward
+gathers over.
+
+The reference never builds a sparse structure: it feeds a dense additive mask
+``bias_mat`` (0 / -1e9, ``utils/process.py:14-25``) or, in the unused
+``sp_attn_head`` (``utils/layers.py:85``), a ``tf.SparseTensor``.  Both are
+accepted here and converted once.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+EDGE_THRESHOLD = -1e8   # an entry of bias_mat is an edge iff it is > -1e8
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class CSRGraph:
+    """rows = destination nodes i, columns = source nodes j (alpha_ij weights H_j).
+
+    rowptr (n_rows+1,) int64, colidx (nnz,) int32, both on `device`.
+    `n_cols` is the number of rows of the tables that colidx indexes.
+    """
+
+    def __init__(self, rowptr: torch.Tensor, colidx: torch.Tensor, n_cols: int | None = None,
+                 validate: bool = True):
+        if rowptr.dtype != torch.int64 or colidx.dtype != torch.int32:
+            raise ValueError("rowptr must be int64 and colidx int32")
+        if rowptr.dim() != 1 or colidx.dim() != 1 or rowptr.numel() < 1:
+            raise ValueError("rowptr/colidx must be 1-D")
+        if rowptr.device != colidx.device:
+            raise ValueError("rowptr and colidx must live on the same device")
+        self.rowptr = rowptr.contiguous()
+        self.colidx = colidx.contiguous()
+        self.n_rows = rowptr.numel() - 1
+        self.n_cols = int(n_cols) if n_cols is not None else self.n_rows
+        self.nnz = colidx.numel()
+        self._t = None
+        if validate:
+            self.validate()
+
+    # ---- checks -----------------------------------------------------------
+    def validate(self):
+        rp = self.rowptr
+        if int(rp[0]) != 0 or int(rp[-1]) != self.nnz:
+            raise ValueError("rowptr[0] must be 0 and rowptr[-1] == nnz")
+        if self.n_rows > 0 and bool((rp[1:] < rp[:-1]).any()):
+            raise ValueError("rowptr must be non-decreasing")
+        if self.nnz:
+            lo, hi = int(self.colidx.min()), int(self.colidx.max())
+            if lo < 0 or hi >= self.n_cols:
+                raise ValueError(f"colidx out of range [0,{self.n_cols}): [{lo},{hi}]")
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+    def degrees(self) -> torch.Tensor:
+        return self.rowptr[1:] - self.rowptr[:-1]
+
+    def has_empty_rows(self) -> bool:
+        return self.n_rows > 0 and bool((self.degrees() == 0).any())
+
+    def to(self, device) -> "CSRGraph":
+        g = CSRGraph(self.rowptr.to(device), self.colidx.to(device), self.n_cols, validate=False)
+        return g
+
+    # ---- transposition (CSC) ------------------------------------------------
+    def transpose(self) -> "CSRGraph":
+        """The transposed graph: for every source j the destinations i, in
+        ascending i (stable), as a CSRGraph with n_rows = n_cols of self."""
+        if self._t is None:
+            rows = torch.repeat_interleave(
+                torch.arange(self.n_rows, device=self.device, dtype=torch.int32), self.degrees())
+            cols = self.colidx.long()
+            order = torch.sort(cols, stable=True).indices
+            rowidx = rows[order].contiguous()
+            counts = torch.bincount(cols, minlength=self.n_cols)
+            colptr = torch.zeros(self.n_cols + 1, dtype=torch.int64, device=self.device)
+            torch.cumsum(counts, 0, out=colptr[1:])
+            t = CSRGraph(colptr, rowidx, n_cols=self.n_rows, validate=False)
+            t._t = self
+            self._t = t
+        return self._t
+
+    # ---- constructors ---------------------------------------------------------
+    @staticmethod
+    def from_bias(bias_mat: torch.Tensor) -> "CSRGraph":
+        """Dense additive mask (N,N) or (1,N,N) -> CSR on the tensor's device.
+        On a GPU tensor this runs the HIP count/fill kernels (the replacement
+        for the O(N^2) Python loop of utils/process.py:21-24 + the dense feed)."""
+        b = bias_mat
+        if b.dim() == 3:
+            if b.shape[0] != 1:
+                raise ValueError("batch size must be 1 (as the reference, ex_acm3025.py:21)")
+            b = b[0]
+        if b.dim() != 2 or b.shape[0] != b.shape[1]:
+            raise ValueError("bias_mat must be (N,N) or (1,N,N)")
+        n = b.shape[0]
+        if b.is_cuda:
+            lib = _lib.load()
+            b = b.to(torch.float32)
+            if b.stride(1) != 1:
+                b = b.contiguous()
+            counts = torch.empty(n, dtype=torch.int64, device=b.device)
+            _lib.check(lib.han_bias_row_counts(b.data_ptr(), n, b.stride(0), counts.data_ptr(),
+                                               _stream()), "han_bias_row_counts")
+            rowptr = torch.zeros(n + 1, dtype=torch.int64, device=b.device)
+            torch.cumsum(counts, 0, out=rowptr[1:])
+            nnz = int(rowptr[-1])
+            colidx = torch.empty(nnz, dtype=torch.int32, device=b.device)
+            _lib.check(lib.han_bias_fill_csr(b.data_ptr(), n, b.stride(0), rowptr.data_ptr(),
+                                             colidx.data_ptr(), _stream()), "han_bias_fill_csr")
+            return CSRGraph(rowptr, colidx, n, validate=False)
+        keep = b > EDGE_THRESHOLD
+        rowptr = torch.zeros(n + 1, dtype=torch.int64)
+        torch.cumsum(keep.sum(1), 0, out=rowptr[1:])
+        colidx = keep.nonzero()[:, 1].to(torch.int32)
+        return CSRGraph(rowptr, colidx, n, validate=False)
+
+    @staticmethod
+    def from_adjacency(adj, add_self_loops: bool = True, device=None) -> "CSRGraph":
+        """Dense/scipy adjacency (N,N): edge iff (adj + I)_ij > 0 -- the nhood=1
+        case of utils/process.py:14-25 without materialising the mask."""
+        import scipy.sparse as sp
+        a = sp.csr_matrix(adj)
+        a = (a != 0).astype(np.int8)
+        if add_self_loops:
+            a = ((a + sp.identity(a.shape[0], dtype=np.int8, format="csr")) != 0).astype(np.int8)
+        a.sort_indices()
+        return CSRGraph.from_arrays(a.indptr, a.indices, a.shape[1], device=device)
+
+    @staticmethod
+    def from_arrays(rowptr, colidx, n_cols=None, device=None) -> "CSRGraph":
+        rp = torch.as_tensor(np.asarray(rowptr, dtype=np.int64))
+        ci = torch.as_tensor(np.asarray(colidx, dtype=np.int32))
+        if device is not None:
+            rp, ci = rp.to(device), ci.to(device)
+        return CSRGraph(rp, ci, n_cols)
+
+    @staticmethod
+    def from_torch_sparse(t: torch.Tensor) -> "CSRGraph":
+        """Binary pattern of a torch sparse COO/CSR tensor of shape (N,N) or
+        (1,N,N) (the rank-3 SparseTensor of utils/layers.py:85-115)."""
+        if t.layout == torch.sparse_csr:
+            return CSRGraph(t.crow_indices().to(torch.int64), t.col_indices().to(torch.int32),
+                            t.shape[-1])
+        t = t.coalesce()
+        idx = t.indices()
+        if idx.shape[0] == 3:
+            if t.shape[0] != 1:
+                raise ValueError("batch size must be 1 (utils/layers.py:110-113)")
+            idx = idx[1:]
+        n = t.shape[-2]
+        order = torch.argsort(idx[0] * t.shape[-1] + idx[1])
+        rows, cols = idx[0][order], idx[1][order]
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=t.device)
+        torch.cumsum(torch.bincount(rows, minlength=n), 0, out=rowptr[1:])
+        return CSRGraph(rowptr, cols.to(torch.int32), t.shape[-1])
+
+    def to_bias(self, dtype=torch.float32) -> torch.Tensor:
+        """Back to the reference's dense additive mask (1,N,N) -- tests only."""
+        b = torch.full((self.n_rows, self.n_cols), -1e9, dtype=dtype, device=self.device)
+        rows = torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), self.degrees())
+        b[rows, self.colidx.long()] = 0.0
+        return b[None]
+
+
+def as_graph(g, device=None) -> CSRGraph:
+    """Accept a CSRGraph, a dense bias matrix, a torch sparse tensor or a
+    (rowptr, colidx[, n_cols]) tuple -- the `bias_mat_list[p]` / `adj_mat`
+    arguments of the reference surface."""
+    if isinstance(g, CSRGraph):
+        out = g
+    elif isinstance(g, torch.Tensor) and g.layout != torch.strided:
+        out = CSRGraph.from_torch_sparse(g)
+    elif isinstance(g, torch.Tensor):
+        if device is not None and g.device != torch.device(device):
+            g = g.to(device)
+        out = CSRGraph.from_bias(g)
+    elif isinstance(g, np.ndarray):
+        t = torch.as_tensor(g, dtype=torch.float32)
+        out = CSRGraph.from_bias(t.to(device) if device is not None else t)
+    elif isinstance(g, (tuple, list)) and len(g) in (2, 3):
+        out = CSRGraph.from_arrays(*g, device=device) if not isinstance(g[0], torch.Tensor) \
+            else CSRGraph(g[0], g[1], g[2] if len(g) == 3 else None)
+    else:
+        raise TypeError(f"cannot interpret {type(g)} as a meta-path graph")
+    if device is not None and out.device != torch.device(device):
+        out = out.to(device)
+    return out

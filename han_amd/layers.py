@@ -1,0 +1,297 @@
+"""Layer library: the reference's ``utils/layers.py`` surface on the HIP kernels.
+
+Same names, argument meaning and return values as the reference:
+
+* :func:`attn_head`       -- utils/layers.py:7-46  (dense additive-mask form)
+* :func:`sp_attn_head`    -- utils/layers.py:85-127 (SparseTensor form)
+* :func:`SimpleAttLayer`  -- utils/layers.py:132-164
+
+TensorFlow creates the variables inside each call; here they are passed in
+``params`` (functional form) or owned by ``han_amd.gat.HeteGAT_multi`` (module
+form).  The fast path used by the model is :class:`NodeLevelAttention`, which
+runs all K heads of all P meta-paths through the K1/K2 kernels and writes the
+heads straight into ``M[:, p, :]`` (models/gat.py:46,58-60).
+
+There is no CPU implementation: every function raises on non-GPU tensors.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F_torch
+
+from . import ops, rng
+from .dist import NodePartition
+from .graph import CSRGraph, as_graph
+
+D = ops.D
+
+
+def _act_code(activation):
+    """Map the reference's `activation` argument to (kernel code, torch post-op)."""
+    if activation is None:
+        return ops.ACT_IDENTITY, None
+    if activation in (F_torch.elu, torch.nn.functional.elu, "elu") or \
+            isinstance(activation, torch.nn.ELU):
+        return ops.ACT_ELU, None
+    if activation == "identity":
+        return ops.ACT_IDENTITY, None
+    if callable(activation):
+        return ops.ACT_IDENTITY, activation   # kernel emits the pre-activation; torch applies it
+    raise ValueError(f"unsupported activation {activation!r}")
+
+
+class NodeLevelAttention(torch.autograd.Function):
+    """K1 + K2 for every meta-path: (X_p, graph_p) -> M (N, P, D).
+
+    forward(W (P,F,D), a1 (P,K,F'), b1 (P,K), a2, b2, c (P,D), xs, graphs, cfg)
+      xs      tuple of P feature tensors (N,F) (no gradient: they are inputs)
+      graphs  tuple of P CSRGraph (rows = local destinations)
+      cfg     dict: train (bool), in_drop, coef_drop, seeds (tuple of P ints),
+              act (kernel activation code), part (NodePartition or None),
+              graphs_t (tuple of P transposed graphs for the backward, or None)
+    """
+
+    @staticmethod
+    def forward(ctx, W, a1, b1, a2, b2, c, xs, graphs, cfg):
+        P = len(graphs)
+        K, FP = a1.shape[1], a1.shape[2]
+        part: NodePartition | None = cfg.get("part")
+        train = bool(cfg["train"])
+        in_drop = float(cfg.get("in_drop", 0.0)) if train else 0.0
+        coef_drop = float(cfg.get("coef_drop", 0.0)) if train else 0.0
+        N = xs[0].shape[0]
+        M = torch.empty((N, P, D), dtype=torch.float32, device=W.device)
+        row_offset = part.row_start if part is not None else 0
+        saved = []
+        for p in range(P):
+            seed = int(cfg["seeds"][p])
+            H, Hd, f1, f2 = ops.project_fwd(xs[p], W[p], a1[p], a2[p], b1[p], b2[p],
+                                            in_drop=in_drop, fts_drop=in_drop, seed=seed,
+                                            row_offset=row_offset)
+            src = Hd if Hd is not None else H
+            if part is not None and part.world > 1:
+                H_tab = part.all_gather_rows(src)
+                f2_tab = part.all_gather_rows(f2)
+            else:
+                H_tab, f2_tab = src, f2
+            _, sv = ops.node_attn_fwd(graphs[p], H_tab, f1, f2_tab, c[p], out=M[:, p, :],
+                                      train=train, coef_drop=coef_drop, seed=seed,
+                                      row_offset=row_offset, activation=cfg["act"], K=K, FP=FP)
+            if train:
+                saved.append((H, f1, f2) + sv)
+        ctx.cfg, ctx.xs, ctx.graphs = cfg, xs, graphs
+        ctx.saved_per_p = saved
+        ctx.in_drop, ctx.coef_drop = in_drop, coef_drop
+        ctx.save_for_backward(W, a1, b1, a2, b2, c)
+        return M
+
+    @staticmethod
+    def backward(ctx, dM):
+        W, a1, b1, a2, b2, c = ctx.saved_tensors
+        cfg, xs, graphs = ctx.cfg, ctx.xs, ctx.graphs
+        if not cfg["train"]:
+            raise RuntimeError("NodeLevelAttention was run with train=False; no backward state")
+        part: NodePartition | None = cfg.get("part")
+        P = len(graphs)
+        K, FP = a1.shape[1], a1.shape[2]
+        dM = dM.contiguous()
+        graphs_t = cfg.get("graphs_t") or tuple(g.transpose() for g in graphs)
+        row_offset = part.row_start if part is not None else 0
+        dW = torch.empty_like(W)
+        da1, da2 = torch.empty_like(a1), torch.empty_like(a2)
+        db1, db2 = torch.empty_like(b1), torch.empty_like(b2)
+        dc = torch.empty_like(c)
+        for p in range(P):
+            H, f1, f2, pre, lse, aggp, tsum = ctx.saved_per_p[p]
+            seed = int(cfg["seeds"][p])
+            g, stats, df1, dcp = ops.node_attn_bwd_rows(dM[:, p, :], pre, aggp, tsum, f1, lse, c[p],
+                                                        activation=cfg["act"], K=K, FP=FP)
+            if part is not None and part.world > 1:
+                g_tab = part.all_gather_rows(g)
+                stats_tab = part.all_gather_rows(stats)
+            else:
+                g_tab, stats_tab = g, stats
+            dH, df2 = ops.node_attn_bwd_cols(graphs_t[p], g_tab, stats_tab, H, f2, df1, a1[p], a2[p],
+                                             coef_drop=ctx.coef_drop, fts_drop=ctx.in_drop, seed=seed,
+                                             src_offset=row_offset, dst_offset=0)
+            d1, d2, e1, e2 = ops.score_param_bwd(H, df1, df2, K=K, FP=FP)
+            da1[p], da2[p], db1[p], db2[p], dc[p] = d1, d2, e1, e2, dcp
+            dW[p] = ops.project_bwd(xs[p], dH, K, FP, in_drop=ctx.in_drop, seed=seed,
+                                    row_offset=row_offset)
+        ctx.saved_per_p = None
+        return dW, da1, db1, da2, db2, dc, None, None, None
+
+
+class SemanticAttention(torch.autograd.Function):
+    """K3: M (N,P,D) -> (Z (N,D), beta (N,P)); utils/layers.py:152-159."""
+
+    @staticmethod
+    def forward(ctx, M, w_omega, b_omega, u_omega):
+        M = M.contiguous()
+        Z, beta = ops.sem_attn_fwd(M, w_omega, b_omega, u_omega)
+        ctx.save_for_backward(M, w_omega, b_omega, u_omega, beta)
+        ctx.mark_non_differentiable(beta)
+        return Z, beta
+
+    @staticmethod
+    def backward(ctx, dZ, _dbeta):
+        M, w, b, u, beta = ctx.saved_tensors
+        dM, dw, db, du = ops.sem_attn_bwd(M, w, b, u, beta, dZ.contiguous())
+        return dM, dw, db, du
+
+
+class ClassifierLoss(torch.autograd.Function):
+    """Fused classifier + masked softmax-CE (+ accuracy).
+    models/gat.py:65-72, models/base_gattn.py:41-48,61-69.
+    Returns (loss, accuracy, logits (N,C)); only `loss` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, Z, Wc, bc, labels, mask, row_weight):
+        need = Z.requires_grad or Wc.requires_grad or bc.requires_grad
+        logits, loss_acc, grads = ops.classifier_loss(Z.contiguous(), Wc, bc, labels, mask,
+                                                      row_weight, backward=need)
+        ctx.grads = grads
+        loss, acc = loss_acc[0], loss_acc[1]
+        ctx.mark_non_differentiable(acc, logits)
+        return loss.clone(), acc.clone(), logits
+
+    @staticmethod
+    def backward(ctx, dloss, _dacc, _dlogits):
+        dZ, dWc, dbc = ctx.grads
+        ctx.grads = None
+        return dZ * dloss, dWc * dloss, dbc * dloss, None, None, None
+
+
+class _ClassifierForward(torch.autograd.Function):
+    """logits = (1/HC) sum_h (Z Wc[h] + bc[h]) (models/gat.py:65-72) by the HIP
+    kernel; the (tiny, N x C) backward uses torch matmuls."""
+
+    @staticmethod
+    def forward(ctx, Z, Wc, bc):
+        N = Z.shape[0]
+        labels = torch.zeros(N, dtype=torch.int32, device=Z.device)
+        mask = torch.zeros(N, dtype=torch.uint8, device=Z.device)
+        logits, _, _ = ops.classifier_loss(Z.contiguous(), Wc, bc, labels, mask, 0.0, backward=False)
+        ctx.save_for_backward(Z, Wc)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        Z, Wc = ctx.saved_tensors
+        HC = Wc.shape[0]
+        Wm = Wc.mean(0)
+        dZ = dlogits @ Wm.t()
+        dWc = (Z.t() @ dlogits / HC).unsqueeze(0).expand(HC, -1, -1).contiguous()
+        dbc = (dlogits.sum(0) / HC).unsqueeze(0).expand(HC, -1).contiguous()
+        return dZ, dWc, dbc
+
+
+def classifier(Z, Wc, bc):
+    return _ClassifierForward.apply(Z, Wc, bc)
+
+
+# ---------------------------------------------------------------------------
+# reference-named functional API
+# ---------------------------------------------------------------------------
+def _squeeze_batch(seq: torch.Tensor, name="seq") -> torch.Tensor:
+    if seq.dim() == 3:
+        if seq.shape[0] != 1:
+            raise ValueError(f"{name}: batch size must be 1 (ex_acm3025.py:21; "
+                             "utils/layers.py:110-113)")
+        return seq[0]
+    if seq.dim() != 2:
+        raise ValueError(f"{name}: expected (1,N,F) or (N,F), got {tuple(seq.shape)}")
+    return seq
+
+
+def _single_head(seq, out_sz, graph, activation, in_drop, coef_drop, residual, params, training,
+                 seed):
+    """One head of width out_sz through the D=64 kernels: the head occupies
+    slot 0 of K = 64/out_sz head slots, the other slots have zero weights."""
+    x = _squeeze_batch(seq)
+    if out_sz not in (4, 8, 16, 32, 64):
+        raise NotImplementedError("out_sz must be one of 4, 8, 16, 32, 64 in this build")
+    K = D // out_sz
+    dev = x.device
+    Fin = x.shape[1]
+
+    def pad_last(t, width):
+        out = t.new_zeros(t.shape[:-1] + (width,))
+        out[..., :t.shape[-1]] = t
+        return out
+
+    W = pad_last(params["W"], D)[None]                                   # (1,F,D)
+    a1 = torch.cat([params["a1"][None], x.new_zeros(K - 1, out_sz)])[None]   # (1,K,F')
+    a2 = torch.cat([params["a2"][None], x.new_zeros(K - 1, out_sz)])[None]
+    b1 = pad_last(params["b1"].reshape(1), K)[None]
+    b2 = pad_last(params["b2"].reshape(1), K)[None]
+    c = pad_last(params["c"], D)[None]
+    if W.shape[1] != Fin:
+        raise ValueError(f"W has {W.shape[1]} input features, seq has {Fin}")
+    code, post = _act_code(activation)
+    train = bool(training) or in_drop > 0 or coef_drop > 0 or W.requires_grad
+    cfg = {"train": train, "in_drop": in_drop, "coef_drop": coef_drop,
+           "seeds": (rng.next_seed() if seed is None else seed,), "act": code, "part": None}
+    M = NodeLevelAttention.apply(W, a1, b1, a2, b2, c, (x,), (graph,), cfg)
+    ret = M[:, 0, :out_sz]
+    if residual:
+        # utils/layers.py:38-42: only the dims-differ branch has an effect
+        if Fin != out_sz:
+            ret = ret + x @ params["res_W"] + params["res_b"]
+    if post is not None:
+        ret = post(ret)
+    return ret[None]     # (1,N,out_sz)
+
+
+def attn_head(seq, out_sz, bias_mat, activation, in_drop=0.0, coef_drop=0.0, residual=False,
+              return_coef=False, *, params, training=False, seed=None):
+    """utils/layers.py:7-46.  seq (1,N,F); bias_mat (1,N,N) additive mask, or a
+    CSRGraph / (rowptr, colidx) pair.  params: dict W (F,out_sz), a1 (out_sz,),
+    b1 (), a2 (out_sz,), b2 (), c (out_sz,) [+ res_W, res_b].
+    NOTE residual with a non-ELU activation is applied after the kernel."""
+    if return_coef:
+        raise NotImplementedError("return_coef would materialise the N x N coefficients; "
+                                  "not provided by the CSR kernels")
+    if residual and _act_code(activation)[0] != ops.ACT_IDENTITY:
+        # the residual must be added before the activation (layers.py:40,46)
+        inner = _single_head(seq, out_sz, as_graph(bias_mat, seq.device), None, in_drop, coef_drop,
+                             residual, params, training, seed)
+        return F_torch.elu(inner)
+    return _single_head(seq, out_sz, as_graph(bias_mat, seq.device), activation, in_drop,
+                        coef_drop, residual, params, training, seed)
+
+
+def sp_attn_head(seq, out_sz, adj_mat, activation, nb_nodes, in_drop=0.0, coef_drop=0.0,
+                 residual=False, *, params, training=False, seed=None):
+    """utils/layers.py:85-127.  adj_mat: torch sparse (1,N,N)/(N,N) tensor with a
+    BINARY pattern, a CSRGraph or (rowptr, colidx).  Non-binary values (which
+    scale the logits in the reference, :95-96) are not supported."""
+    if isinstance(adj_mat, torch.Tensor) and adj_mat.layout != torch.strided:
+        vals = adj_mat.coalesce().values() if adj_mat.layout == torch.sparse_coo else adj_mat.values()
+        if vals.numel() and not bool(torch.all(vals == 1)):
+            raise NotImplementedError("sp_attn_head: only binary adjacency values are supported")
+    g = as_graph(adj_mat, seq.device)
+    if g.n_rows != nb_nodes:
+        raise ValueError(f"nb_nodes={nb_nodes} but adj_mat has {g.n_rows} rows")
+    if residual and _act_code(activation)[0] != ops.ACT_IDENTITY:
+        inner = _single_head(seq, out_sz, g, None, in_drop, coef_drop, residual, params, training, seed)
+        return F_torch.elu(inner)
+    return _single_head(seq, out_sz, g, activation, in_drop, coef_drop, residual, params, training,
+                        seed)
+
+
+def SimpleAttLayer(inputs, attention_size, time_major=False, return_alphas=False, *, params):
+    """utils/layers.py:132-164.  inputs (N,P,D) [or (P,N,D) if time_major, or a
+    tuple to be concatenated on the last axis]; params: w_omega (D,A),
+    b_omega (A,), u_omega (A,)."""
+    if isinstance(inputs, tuple):
+        inputs = torch.cat(inputs, 2)                    # :134-136
+    if time_major:
+        inputs = inputs.transpose(0, 1)                  # :138-140
+    if params["w_omega"].shape != (inputs.shape[2], attention_size):
+        raise ValueError("w_omega must be (hidden_size, attention_size)")
+    out, alphas = SemanticAttention.apply(inputs.contiguous(), params["w_omega"],
+                                          params["b_omega"], params["u_omega"])
+    if not return_alphas:
+        return out
+    return out, alphas

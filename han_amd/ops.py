@@ -1,0 +1,330 @@
+"""Thin, validating Python wrappers over the C ABI (one per entry point).
+
+Tensors are plumbing: device memory + the current HIP stream.  Every wrapper
+checks device / dtype / contiguity / shape and raises ``ValueError`` before the
+kernel sees the pointers (the kernels assume validated input).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .graph import CSRGraph
+
+ACT_IDENTITY = 0
+ACT_ELU = 1
+LEAKY_SLOPE = 0.2          # tf.nn.leaky_relu default (utils/layers.py:27)
+D = 64                     # K * F' of this build
+
+_workspaces: dict = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(nbytes: int, device, tag: str = "") -> torch.Tensor:
+    """Grow-only scratch buffer per (device, tag)."""
+    key = (str(device), tag)
+    t = _workspaces.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = t
+    return t
+
+
+def _chk(t: torch.Tensor, name: str, shape=None, dtype=torch.float32, device=None, contiguous=True):
+    if not isinstance(t, torch.Tensor):
+        raise ValueError(f"{name}: expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: must be a GPU tensor (han_amd has no CPU path); got {t.device}")
+    if device is not None and t.device != device:
+        raise ValueError(f"{name}: on {t.device}, expected {device}")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if shape is not None:
+        if t.dim() != len(shape) or any(s is not None and int(a) != int(s)
+                                        for a, s in zip(t.shape, shape)):
+            raise ValueError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+def _check_heads(K: int, FP: int):
+    if K * FP != D or FP not in (4, 8, 16, 32, 64):
+        raise NotImplementedError(
+            f"this build supports n_heads*hid_units == 64 with hid_units in "
+            f"{{4,8,16,32,64}}; got n_heads={K}, hid_units={FP}")
+
+
+def _check_drop(p: float, name: str):
+    p = float(p)
+    if not (0.0 <= p < 1.0):
+        raise ValueError(f"{name} must be in [0, 1), got {p}")
+    return p
+
+
+# --------------------------------------------------------------------------- K1
+def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_offset=0):
+    """utils/layers.py:18-24,31-32 for the K heads of one meta-path.
+    X (N,F) [row stride >= F]; W (F,D); a1,a2 (K,F'); b1,b2 (K,).
+    Returns H (N,D), Hd (N,D) or None, f1 (N,K), f2 (N,K)."""
+    lib = _lib.load()
+    if X.dim() != 2:
+        raise ValueError(f"X: expected (N,F), got {tuple(X.shape)}")
+    _chk(X, "X", contiguous=False)
+    if X.stride(1) != 1:
+        raise ValueError("X: rows must be contiguous")
+    N, F = X.shape
+    dev = X.device
+    K, FP = a1.shape
+    _check_heads(K, FP)
+    _chk(W, "W", (F, D), device=dev)
+    _chk(a1, "a1", (K, FP), device=dev)
+    _chk(a2, "a2", (K, FP), device=dev)
+    _chk(b1, "b1", (K,), device=dev)
+    _chk(b2, "b2", (K,), device=dev)
+    in_drop = _check_drop(in_drop, "in_drop")
+    fts_drop = _check_drop(fts_drop, "fts_drop")
+    H = torch.empty((N, D), dtype=torch.float32, device=dev)
+    Hd = torch.empty((N, D), dtype=torch.float32, device=dev) if fts_drop > 0 else None
+    f1 = torch.empty((N, K), dtype=torch.float32, device=dev)
+    f2 = torch.empty((N, K), dtype=torch.float32, device=dev)
+    _lib.check(lib.han_project_fwd(
+        X.data_ptr(), X.stride(0) if N > 1 else max(F, X.stride(0)), W.data_ptr(), a1.data_ptr(),
+        a2.data_ptr(), b1.data_ptr(), b2.data_ptr(), H.data_ptr(),
+        Hd.data_ptr() if Hd is not None else None, f1.data_ptr(), f2.data_ptr(), N, F, K, FP,
+        in_drop, fts_drop, int(seed), int(row_offset), _stream()), "han_project_fwd")
+    return H, Hd, f1, f2
+
+
+def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0):
+    """dW (F,D) = dropout_k(X)^T dH."""
+    lib = _lib.load()
+    _chk(X, "X", contiguous=False)
+    N, F = X.shape
+    _chk(dH, "dH", (N, D), device=X.device)
+    _check_heads(K, FP)
+    dW = torch.empty((F, D), dtype=torch.float32, device=X.device)
+    nbytes = lib.han_project_bwd_workspace(N, F, K, FP)
+    ws = _ws(nbytes, X.device, "proj")
+    _lib.check(lib.han_project_bwd(
+        X.data_ptr(), X.stride(0) if N > 1 else max(F, X.stride(0)), dH.data_ptr(), dW.data_ptr(),
+        ws.data_ptr(), ws.numel(), N, F, K, FP, _check_drop(in_drop, "in_drop"), int(seed),
+        int(row_offset), _stream()), "han_project_bwd")
+    return dW
+
+
+# --------------------------------------------------------------------------- K2
+def node_attn_fwd(graph: CSRGraph, H_tab, f1, f2_tab, c, out=None, train=False, coef_drop=0.0,
+                  seed=0, row_offset=0, activation=ACT_ELU, K=8, FP=8):
+    """utils/layers.py:26-35,46.  H_tab (NT,D), f2_tab (NT,K): gather tables
+    indexed by graph.colidx; f1 (N,K) local rows; c (D,).  `out`: optional
+    (N,D) view with unit inner stride (e.g. M[:,p,:]).  Returns
+    out, saved where saved = (pre, lse, aggp, tsum) if train else None."""
+    lib = _lib.load()
+    _check_heads(K, FP)
+    N = graph.n_rows
+    dev = H_tab.device
+    _chk(H_tab, "H", (graph.n_cols, D))
+    _chk(f2_tab, "f2", (graph.n_cols, K), device=dev)
+    _chk(f1, "f1", (N, K), device=dev)
+    _chk(c, "c", (D,), device=dev)
+    if graph.device != dev:
+        raise ValueError("graph and tables must be on the same device")
+    if out is None:
+        out = torch.empty((N, D), dtype=torch.float32, device=dev)
+    else:
+        _chk(out, "out", (N, D), device=dev, contiguous=False)
+        if out.stride(1) != 1 or (N > 1 and out.stride(0) < D):
+            raise ValueError("out: rows must be contiguous with row stride >= 64")
+    coef_drop = _check_drop(coef_drop, "coef_drop")
+    if coef_drop > 0 and not train:
+        raise ValueError("coef_drop > 0 requires train=True")
+    saved = None
+    ptrs = [None, None, None, None]
+    if train:
+        pre = torch.empty((N, D), dtype=torch.float32, device=dev)
+        aggp = torch.empty((N, D), dtype=torch.float32, device=dev)
+        lse = torch.empty((N, K), dtype=torch.float32, device=dev)
+        tsum = torch.empty((N, K), dtype=torch.float32, device=dev)
+        saved = (pre, lse, aggp, tsum)
+        ptrs = [pre.data_ptr(), lse.data_ptr(), aggp.data_ptr(), tsum.data_ptr()]
+    _lib.check(lib.han_node_attn_fwd(
+        graph.rowptr.data_ptr(), graph.colidx.data_ptr(), H_tab.data_ptr(), f1.data_ptr(),
+        f2_tab.data_ptr(), c.data_ptr(), out.data_ptr(), out.stride(0) if N > 1 else D,
+        ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop,
+        int(seed), int(row_offset), int(activation), _stream()), "han_node_attn_fwd")
+    return out, saved
+
+
+def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=8, FP=8):
+    """Row-local half of the K2 backward.  dOut (N,D) view (unit inner stride).
+    Returns g (N,D), stats (N,K,4), df1 (N,K), dc (D,)."""
+    lib = _lib.load()
+    _check_heads(K, FP)
+    N = pre.shape[0]
+    dev = pre.device
+    _chk(dOut, "dOut", (N, D), device=dev, contiguous=False)
+    if dOut.stride(1) != 1:
+        raise ValueError("dOut: rows must be contiguous")
+    for t, n, s in ((pre, "pre", (N, D)), (aggp, "aggp", (N, D)), (tsum, "tsum", (N, K)),
+                    (f1, "f1", (N, K)), (lse, "lse", (N, K)), (c, "c", (D,))):
+        _chk(t, n, s, device=dev)
+    g = torch.empty((N, D), dtype=torch.float32, device=dev)
+    stats = torch.empty((N, K, 4), dtype=torch.float32, device=dev)
+    df1 = torch.empty((N, K), dtype=torch.float32, device=dev)
+    dc = torch.empty((D,), dtype=torch.float32, device=dev)
+    ws = _ws(lib.han_node_attn_bwd_workspace(N, K, FP), dev, "rows")
+    _lib.check(lib.han_node_attn_bwd_rows(
+        dOut.data_ptr(), dOut.stride(0) if N > 1 else D, pre.data_ptr(), aggp.data_ptr(),
+        tsum.data_ptr(), f1.data_ptr(), lse.data_ptr(), c.data_ptr(), g.data_ptr(),
+        stats.data_ptr(), df1.data_ptr(), dc.data_ptr(), ws.data_ptr(), ws.numel(), N, K, FP,
+        int(activation), _stream()), "han_node_attn_bwd_rows")
+    return g, stats, df1, dc
+
+
+def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=0.0,
+                       fts_drop=0.0, seed=0, src_offset=0, dst_offset=0):
+    """Transposed-graph half of the K2 backward.  graph_t rows = local sources j,
+    its colidx = destinations i indexing g_tab (NT,D) / stats_tab (NT,K,4).
+    H (NS,D) undropped local rows, f2/df1 (NS,K).  Returns dH (NS,D), df2 (NS,K)."""
+    lib = _lib.load()
+    K, FP = a1.shape
+    _check_heads(K, FP)
+    NS = graph_t.n_rows
+    dev = H.device
+    _chk(g_tab, "g", (graph_t.n_cols, D), device=dev)
+    _chk(stats_tab, "stats", (graph_t.n_cols, K, 4), device=dev)
+    _chk(H, "H", (NS, D))
+    _chk(f2, "f2", (NS, K), device=dev)
+    _chk(df1, "df1", (NS, K), device=dev)
+    _chk(a1, "a1", (K, FP), device=dev)
+    _chk(a2, "a2", (K, FP), device=dev)
+    dH = torch.empty((NS, D), dtype=torch.float32, device=dev)
+    df2 = torch.empty((NS, K), dtype=torch.float32, device=dev)
+    _lib.check(lib.han_node_attn_bwd_cols(
+        graph_t.rowptr.data_ptr(), graph_t.colidx.data_ptr(), g_tab.data_ptr(),
+        stats_tab.data_ptr(), H.data_ptr(), f2.data_ptr(), df1.data_ptr(), a1.data_ptr(),
+        a2.data_ptr(), dH.data_ptr(), df2.data_ptr(), NS, graph_t.nnz, K, FP, LEAKY_SLOPE,
+        _check_drop(coef_drop, "coef_drop"), _check_drop(fts_drop, "fts_drop"), int(seed),
+        int(src_offset), int(dst_offset), _stream()), "han_node_attn_bwd_cols")
+    return dH, df2
+
+
+def score_param_bwd(H, df1, df2, K=8, FP=8):
+    """da1, da2 (K,F'), db1, db2 (K,)."""
+    lib = _lib.load()
+    _check_heads(K, FP)
+    N = H.shape[0]
+    dev = H.device
+    _chk(H, "H", (N, D))
+    _chk(df1, "df1", (N, K), device=dev)
+    _chk(df2, "df2", (N, K), device=dev)
+    da1 = torch.empty((K, FP), dtype=torch.float32, device=dev)
+    da2 = torch.empty((K, FP), dtype=torch.float32, device=dev)
+    db1 = torch.empty((K,), dtype=torch.float32, device=dev)
+    db2 = torch.empty((K,), dtype=torch.float32, device=dev)
+    ws = _ws(lib.han_score_param_bwd_workspace(N, K, FP), dev, "score")
+    _lib.check(lib.han_score_param_bwd(
+        H.data_ptr(), df1.data_ptr(), df2.data_ptr(), da1.data_ptr(), da2.data_ptr(),
+        db1.data_ptr(), db2.data_ptr(), ws.data_ptr(), ws.numel(), N, K, FP, _stream()),
+        "han_score_param_bwd")
+    return da1, da2, db1, db2
+
+
+# --------------------------------------------------------------------------- K3
+def sem_attn_fwd(M, w_omega, b_omega, u_omega):
+    """utils/layers.py:152-159.  M (N,P,D) -> Z (N,D), beta (N,P)."""
+    lib = _lib.load()
+    _chk(M, "M")
+    if M.dim() != 3 or M.shape[2] != D:
+        raise ValueError(f"M: expected (N,P,{D}), got {tuple(M.shape)}")
+    N, P, _ = M.shape
+    A = w_omega.shape[1]
+    dev = M.device
+    _chk(w_omega, "w_omega", (D, A), device=dev)
+    _chk(b_omega, "b_omega", (A,), device=dev)
+    _chk(u_omega, "u_omega", (A,), device=dev)
+    Z = torch.empty((N, D), dtype=torch.float32, device=dev)
+    beta = torch.empty((N, P), dtype=torch.float32, device=dev)
+    _lib.check(lib.han_sem_attn_fwd(M.data_ptr(), w_omega.data_ptr(), b_omega.data_ptr(),
+                                    u_omega.data_ptr(), Z.data_ptr(), beta.data_ptr(), N, P, D, A,
+                                    _stream()), "han_sem_attn_fwd")
+    return Z, beta
+
+
+def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ):
+    lib = _lib.load()
+    N, P, _ = M.shape
+    A = w_omega.shape[1]
+    dev = M.device
+    _chk(M, "M", (N, P, D))
+    _chk(beta, "beta", (N, P), device=dev)
+    _chk(dZ, "dZ", (N, D), device=dev)
+    dM = torch.empty_like(M)
+    dw = torch.empty_like(w_omega)
+    db = torch.empty_like(b_omega)
+    du = torch.empty_like(u_omega)
+    ws = _ws(lib.han_sem_attn_bwd_workspace(N, P, D, A), dev, "sem")
+    _lib.check(lib.han_sem_attn_bwd(
+        M.data_ptr(), w_omega.data_ptr(), b_omega.data_ptr(), u_omega.data_ptr(), beta.data_ptr(),
+        dZ.data_ptr(), dM.data_ptr(), dw.data_ptr(), db.data_ptr(), du.data_ptr(), ws.data_ptr(),
+        ws.numel(), N, P, D, A, _stream()), "han_sem_attn_bwd")
+    return dM, dw, db, du
+
+
+# ------------------------------------------------------------- classifier + loss
+def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False):
+    """models/gat.py:65-72 + models/base_gattn.py:41-48,61-69.
+    Z (N,D); Wc (HC,D,C); bc (HC,C); labels int32 (N,); mask uint8 (N,).
+    Returns logits (N,C), loss_acc (2,) [masked CE, masked accuracy] and, if
+    backward, (dZ, dWc, dbc)."""
+    lib = _lib.load()
+    _chk(Z, "Z")
+    N = Z.shape[0]
+    dev = Z.device
+    HC, _, C = Wc.shape
+    _chk(Z, "Z", (N, D))
+    _chk(Wc, "Wc", (HC, D, C), device=dev)
+    _chk(bc, "bc", (HC, C), device=dev)
+    _chk(labels, "labels", (N,), dtype=torch.int32, device=dev)
+    _chk(mask, "mask", (N,), dtype=torch.uint8, device=dev)
+    logits = torch.empty((N, C), dtype=torch.float32, device=dev)
+    loss_acc = torch.empty((2,), dtype=torch.float32, device=dev)
+    grads = None
+    ptrs = (None, None, None)
+    if backward:
+        dZ = torch.empty((N, D), dtype=torch.float32, device=dev)
+        dWc = torch.empty_like(Wc)
+        dbc = torch.empty_like(bc)
+        grads = (dZ, dWc, dbc)
+        ptrs = (dZ.data_ptr(), dWc.data_ptr(), dbc.data_ptr())
+    ws = _ws(lib.han_classifier_workspace(N, D, C, HC), dev, "cls")
+    _lib.check(lib.han_classifier_loss(
+        Z.data_ptr(), Wc.data_ptr(), bc.data_ptr(), labels.data_ptr(), mask.data_ptr(),
+        float(row_weight), logits.data_ptr(), loss_acc.data_ptr(), ptrs[0], ptrs[1], ptrs[2],
+        ws.data_ptr(), ws.numel(), N, D, C, HC, _stream()), "han_classifier_loss")
+    return logits, loss_acc, grads
+
+
+# ------------------------------------------------------------------- optimiser
+def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, l2_coef=0.0):
+    lib = _lib.load()
+    n = param.numel()
+    for t, nme in ((param, "param"), (grad, "grad"), (m, "m"), (v, "v")):
+        _chk(t, nme, (n,), device=param.device)
+    _lib.check(lib.han_adam_step(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n,
+                                 float(lr_t), float(beta1), float(beta2), float(eps),
+                                 float(l2_coef), _stream()), "han_adam_step")
+
+
+def l2_half_sumsq(param):
+    lib = _lib.load()
+    _chk(param, "param", (param.numel(),))
+    out = torch.empty((1,), dtype=torch.float32, device=param.device)
+    ws = _ws(4096 * 4, param.device, "l2")
+    _lib.check(lib.han_l2_half_sumsq(param.data_ptr(), param.numel(), out.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), _stream()), "han_l2_half_sumsq")
+    return out

@@ -1,0 +1,103 @@
+"""Synthetic HAN workloads of BASELINE.json's shapes.
+
+There are no datasets in the container or on the GPU box (ACM3025.mat etc. are
+external downloads), so every configuration is generated: random graphs with the
+degree statistics of the named dataset, Gaussian features, uniform labels.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .graph import CSRGraph
+
+
+def random_regular_graph(n: int, deg: int, seed: int, device="cpu", symmetric=False) -> CSRGraph:
+    """Each row: the self-loop + (deg-1) uniformly random neighbours (duplicates
+    of the self-loop or of each other are possible at rate ~deg^2/n and are kept:
+    the kernels treat a repeated neighbour as a repeated term, as a multigraph).
+    Generated on `device` with torch so that 5e7-edge graphs take seconds."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    nb = torch.randint(0, n, (n, deg - 1), generator=g, device=device, dtype=torch.int32)
+    self_ids = torch.arange(n, device=device, dtype=torch.int32)[:, None]
+    cols = torch.cat([self_ids, nb], dim=1)
+    cols, _ = torch.sort(cols, dim=1)
+    rowptr = torch.arange(0, n * deg + 1, deg, device=device, dtype=torch.int64)
+    graph = CSRGraph(rowptr, cols.reshape(-1).contiguous(), n, validate=False)
+    if symmetric:
+        raise NotImplementedError
+    return graph
+
+
+def powerlaw_graph(n: int, nnz: int, alpha: float, seed: int, device="cpu") -> CSRGraph:
+    """Skewed variant: row degrees ~ Zipf-like with exponent alpha, scaled to
+    about `nnz` edges, every row keeps its self-loop; neighbours uniform."""
+    rng = np.random.default_rng(seed)
+    w = rng.pareto(alpha - 1.0, size=n) + 1.0
+    deg = np.maximum(1, np.floor(w / w.sum() * nnz)).astype(np.int64)
+    deg = np.minimum(deg, n)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    e = int(rowptr[-1])
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    cols = torch.randint(0, n, (e,), generator=g, device=device, dtype=torch.int32)
+    rp = torch.as_tensor(rowptr, device=device)
+    cols[rp[:-1]] = torch.arange(n, device=device, dtype=torch.int32)   # self-loop first
+    return CSRGraph(rp, cols, n, validate=False)
+
+
+def bernoulli_graph(n: int, density: float, seed: int, device="cpu") -> CSRGraph:
+    """ACM/DBLP-like: symmetric Bernoulli(density) edges + I (dense generation,
+    n <= ~10k)."""
+    rng = np.random.default_rng(seed)
+    a = rng.random((n, n)) < density / 2
+    a = a | a.T
+    np.fill_diagonal(a, True)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(a.sum(1), out=rowptr[1:])
+    colidx = np.nonzero(a)[1].astype(np.int32)
+    return CSRGraph.from_arrays(rowptr, colidx, n, device=device)
+
+
+CONFIGS = {
+    # name: (N, P, F, C, per-meta-path graph spec)
+    "acm-like": dict(n=3025, f=1870, c=3, graphs=[("bernoulli", 29281 / 3025 ** 2),
+                                                  ("bernoulli", 2210761 / 3025 ** 2)]),
+    "dblp-like": dict(n=4057, f=334, c=4, graphs=[("bernoulli", 11113 / 4057 ** 2),
+                                                  ("bernoulli", 5000495 / 4057 ** 2),
+                                                  ("bernoulli", 12924399 / 4057 ** 2)]),
+    "syn-1m": dict(n=1_000_000, f=256, c=4, graphs=[("regular", 50)] * 4),
+    "syn-1m-skew": dict(n=1_000_000, f=256, c=4, graphs=[("powerlaw", 50_000_000, 2.1)] * 4),
+    "syn-100k": dict(n=100_000, f=256, c=4, graphs=[("regular", 50)] * 4),
+    "tiny": dict(n=512, f=48, c=3, graphs=[("bernoulli", 0.02), ("bernoulli", 0.2)]),
+}
+
+
+def make_graph(spec, n, seed, device):
+    kind = spec[0]
+    if kind == "regular":
+        return random_regular_graph(n, spec[1], seed, device)
+    if kind == "powerlaw":
+        return powerlaw_graph(n, spec[1], spec[2], seed, device)
+    if kind == "bernoulli":
+        return bernoulli_graph(n, spec[1], seed, device)
+    raise ValueError(kind)
+
+
+def make_workload(name: str, device="cpu", seed: int = 1234, n_override: int | None = None):
+    """Returns dict(x (N,F) fp32, graphs [P CSRGraph], labels int32 (N,),
+    train_mask / val_mask uint8 (N,), n, f, c, p)."""
+    cfg = CONFIGS[name]
+    n = int(n_override) if n_override else cfg["n"]
+    graphs = [make_graph(s, n, seed + p, device) for p, s in enumerate(cfg["graphs"])]
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    x = torch.randn((n, cfg["f"]), generator=g, device=device, dtype=torch.float32)
+    labels = torch.randint(0, cfg["c"], (n,), generator=g, device=device, dtype=torch.int32)
+    u = torch.rand((n,), generator=g, device=device)
+    train_mask = (u < 0.10).to(torch.uint8)
+    val_mask = ((u >= 0.10) & (u < 0.20)).to(torch.uint8)
+    return dict(x=x, graphs=graphs, labels=labels, train_mask=train_mask, val_mask=val_mask,
+                n=n, f=cfg["f"], c=cfg["c"], p=len(graphs), name=name)

@@ -1,0 +1,123 @@
+"""Full-graph training loop of the reference (``ex_acm3025.py:171-245``) on the
+HIP kernels: one epoch = ONE fwd+bwd+Adam step on the whole graph with dropout
+0.6/0.6 on the train mask, then ONE eval forward on the val mask (both `while`
+loops of the script run exactly once because batch_size = 1 = number of graphs).
+
+`sess.run([train_op, loss, accuracy], feed_dict)` becomes :meth:`train_step`,
+`sess.run([loss, accuracy], feed_dict)` becomes :meth:`eval_step`.  Under a
+:class:`~han_amd.dist.NodePartition` every rank owns a block of rows; the only
+collectives are the table all-gathers inside the node-attention op and one
+all-reduce of the flat gradient buffer.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import layers, ops
+from .base_gattn import TFAdam
+from .dist import NodePartition
+from .gat import HeteGAT_multi
+from .graph import CSRGraph
+
+
+class HANTrainer:
+    def __init__(self, model: HeteGAT_multi, xs, graphs, labels, train_mask, val_mask=None,
+                 lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
+                 part: NodePartition | None = None, patience=100):
+        """xs: list of P (N_local,F) feature tensors (this rank's rows);
+        graphs: list of P CSRGraph -- the GLOBAL graphs when `part` is given
+        (they are sharded here), else the local==global graphs;
+        labels int32 (N_local,) class ids; masks uint8/bool (N_local,)."""
+        if not model._built:
+            raise RuntimeError("build the model first (model.build(...))")
+        self.model = model
+        self.part = part if (part is not None and part.world > 1) else None
+        model.partition = self.part
+        dev = model.flat.device
+        self.xs = [x.contiguous() for x in xs]
+        if self.part is not None:
+            sharded = [self.part.shard_graph(g) for g in graphs]
+            self.graphs = [s[0] for s in sharded]
+            self.graphs_t = [s[1] for s in sharded]
+        else:
+            self.graphs = list(graphs)
+            self.graphs_t = [g.transpose() for g in graphs]
+        self.labels = labels.to(device=dev, dtype=torch.int32).contiguous()
+        self.train_mask = train_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        self.val_mask = (val_mask if val_mask is not None else train_mask).to(
+            device=dev, dtype=torch.uint8).contiguous()
+        # mean(loss * mask / mean(mask)) == sum(mask * loss) / count(mask): the
+        # normaliser is a setup-time constant, summed over ranks once.
+        self.w_train = 1.0 / max(self._global_count(self.train_mask), 1)
+        self.w_val = 1.0 / max(self._global_count(self.val_mask), 1)
+        self.opt = TFAdam(model.flat, model.flat_grad, lr=lr, l2_coef=l2_coef)
+        self.attn_drop, self.ffd_drop = attn_drop, ffd_drop
+        self.patience = patience
+        self.vlss_mn, self.vacc_mx, self.curr_step = float("inf"), 0.0, 0
+        self.best_state = None
+
+    def _global_count(self, mask):
+        c = mask.sum().to(torch.float32).reshape(1)
+        if self.part is not None:
+            self.part.all_reduce_sum_(c)
+        return int(c.item())
+
+    def _forward(self, train: bool, mask, weight):
+        m = self.model
+        with torch.set_grad_enabled(train):
+            M = m.node_level(self.xs, self.graphs, self.attn_drop if train else 0.0,
+                             self.ffd_drop if train else 0.0, train, ops.ACT_ELU,
+                             graphs_t=self.graphs_t)
+            Z, _ = layers.SemanticAttention.apply(M, m.w_omega, m.b_omega, m.u_omega)
+            loss, acc, _ = layers.ClassifierLoss.apply(Z, m.Wc, m.bc, self.labels, mask, weight)
+        return loss, acc
+
+    def train_step(self):
+        """sess.run([train_op, loss, accuracy]) with drop = 0.6 (ex_acm3025.py:178-193).
+        Returns device scalars (this rank's share of) loss and accuracy."""
+        self.model.zero_grad_flat()
+        loss, acc = self._forward(True, self.train_mask, self.w_train)
+        loss.backward()
+        if self.part is not None:
+            self.part.all_reduce_sum_(self.model.flat_grad)
+        self.opt.step()
+        return loss.detach(), acc
+
+    def eval_step(self, mask=None, weight=None):
+        """sess.run([loss, accuracy]) with drop = 0.0 (ex_acm3025.py:199-218)."""
+        mask = self.val_mask if mask is None else mask
+        weight = self.w_val if weight is None else weight
+        loss, acc = self._forward(False, mask, weight)
+        return loss, acc
+
+    def epoch(self):
+        """One reference epoch; returns device tensors (no host sync)."""
+        tl, ta = self.train_step()
+        vl, va = self.eval_step()
+        return tl, ta, vl, va
+
+    def reduce_metrics(self, *vals):
+        """Sum per-rank partial losses/accuracies (they are already weighted by
+        the global mask count) -- logging only, not needed for training."""
+        t = torch.stack([v.reshape(()) for v in vals])
+        if self.part is not None:
+            self.part.all_reduce_sum_(t)
+        return [float(x) for x in t.tolist()]
+
+    def early_stopping(self, val_loss: float, val_acc: float) -> bool:
+        """ex_acm3025.py:225-240: checkpoint when val acc >= best AND val loss <= best;
+        stop after `patience` epochs without either improving.  Returns True to stop."""
+        if val_acc >= self.vacc_mx or val_loss <= self.vlss_mn:
+            if val_acc >= self.vacc_mx and val_loss <= self.vlss_mn:
+                self.best_state = self.model.flat.detach().clone()
+            self.vacc_mx = max(val_acc, self.vacc_mx)
+            self.vlss_mn = min(val_loss, self.vlss_mn)
+            self.curr_step = 0
+            return False
+        self.curr_step += 1
+        return self.curr_step == self.patience
+
+    def restore_best(self):
+        """saver.restore(sess, checkpt_file) (ex_acm3025.py:247)."""
+        if self.best_state is not None:
+            self.model.flat.copy_(self.best_state)

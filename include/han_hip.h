@@ -1,0 +1,177 @@
+/* han_hip.h -- C ABI of libhan_hip.so: the MI355X (gfx950) HAN hot path.
+ *
+ * Every entry point takes raw DEVICE pointers plus a hipStream_t (passed as
+ * void*), launches on that stream, never allocates, never synchronises, and
+ * returns 0 on success or a negative HAN_E_* / positive hipError_t code.
+ * The caller owns every buffer.  Shapes use the notation of SURVEY.md sec. 8:
+ *   N   destination rows owned by this call (local rows of a node partition)
+ *   NT  rows of the gather tables (== N on one GPU; local + halo otherwise)
+ *   F   input feature width          K  attention heads (n_heads[0])
+ *   FP  features per head (hid_units[0])     D = K*FP  (this build: D == 64)
+ *   P   meta-paths     A  mp_att_size     C  classes
+ * All floating-point data is fp32, row-major, dense; indices are int64
+ * (row/col pointers) and int32 (neighbour ids).
+ *
+ * The reference has no native interface for this path: it is Python on
+ * TensorFlow 1.x.  Each function names the reference call site it replaces
+ * (paths relative to the reference root); the Python binding that mirrors the
+ * reference's own layer API is han_amd/layers.py.
+ */
+#ifndef HAN_HIP_H
+#define HAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAN_ABI_VERSION 1
+
+#define HAN_E_BADARG   (-1)   /* null pointer, negative size, inconsistent shape */
+#define HAN_E_UNSUPPORTED (-2) /* shape outside this build (e.g. K*FP != 64)     */
+#define HAN_E_WORKSPACE (-3)  /* workspace too small                            */
+
+#define HAN_ACT_IDENTITY 0
+#define HAN_ACT_ELU      1
+
+int han_abi_version(void);
+const char *han_error_string(int code);
+
+/* ---- K1: feature projection + attention scores ---------------------------
+ * utils/layers.py:18-24 for all K heads of one meta-path:
+ *   Xk = dropout_k(X, keep=1-in_drop)      (re-sampled per head, :18-19)
+ *   H[:, k*FP:(k+1)*FP] = Xk @ W[:, k*FP:(k+1)*FP]          (:20)
+ *   f1[:,k] = H_k . a1[k] + b1[k];  f2[:,k] = H_k . a2[k] + b2[k]   (:23-24)
+ * and the dropped copy the aggregation gathers (:31-32, applied AFTER the
+ * scores were taken from the undropped rows):
+ *   Hd = dropout(H, keep=1-fts_drop)        (only if fts_drop > 0; else untouched)
+ * X (N,F) ldx>=F; W (F,D); a1,a2 (K,FP); b1,b2 (K); H,Hd (N,D); f1,f2 (N,K).
+ * in_drop == 0 -> no input dropout.  row_offset = global id of row 0 (RNG key). */
+int han_project_fwd(const float *X, int64_t ldx, const float *W, const float *a1,
+                    const float *a2, const float *b1, const float *b2, float *H,
+                    float *Hd, float *f1, float *f2, int64_t N, int F, int K, int FP,
+                    float in_drop, float fts_drop, uint64_t seed, int64_t row_offset,
+                    void *stream);
+
+/* dW = Xk^T dH (per head dropout masks regenerated from the seed).
+ * workspace: han_project_bwd_workspace() bytes, any contents.              */
+size_t han_project_bwd_workspace(int64_t N, int F, int K, int FP);
+int han_project_bwd(const float *X, int64_t ldx, const float *dH, float *dW,
+                    void *workspace, size_t workspace_bytes, int64_t N, int F, int K,
+                    int FP, float in_drop, uint64_t seed, int64_t row_offset, void *stream);
+
+/* ---- K2: node-level attention ---------------------------------------------
+ * utils/layers.py:26-35,46 (dense mask form) == :95-118,127 (sparse form) over
+ * the stored neighbours only:
+ *   e_ij = LeakyReLU(f1_i + f2_j), alpha = softmax_j, out_i = act(sum_j
+ *   drop(alpha_ij) drop(H_j) + c).
+ * rowptr (N+1) int64, colidx (E) int32 indexing the NT-row tables H (NT,D) and
+ * f2 (NT,K); f1 (N,K) for the local rows; c (D).  out row i is written at
+ * out + i*out_stride (so the K heads land directly in M[:,p,:], models/gat.py:46,58-60).
+ * Training extras (all or none may be NULL): pre (N,D) pre-activation,
+ * lse (N,K) log-sum-exp of the scores, aggp (N,D) and tsum (N,K) -- the
+ * LeakyReLU'-weighted aggregates that make df1 row-local in the backward.  */
+int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float *H,
+                      const float *f1, const float *f2, const float *c, float *out,
+                      int64_t out_stride, float *pre, float *lse, float *aggp,
+                      float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
+                      float coef_drop, uint64_t seed, int64_t row_offset,
+                      int activation, void *stream);
+
+/* Backward, step 1 (row-local): from dOut (N,D; row stride dout_stride) and
+ * the saved pre/aggp/tsum/f1/lse compute
+ *   g = dOut * act'(pre)                    -> g (N,D)
+ *   s_i[k] = g_i[k] . (pre_i - c)[k]
+ *   df1_i[k] = g_i[k] . aggp_i[k] - s_i[k] * tsum_i[k]        -> df1 (N,K)
+ *   stats_i[k] = (f1, lse, s, 0)                            -> stats (N,K,4)
+ *   dc += sum_i g_i  (written, not accumulated)              -> dc (D)
+ * workspace: han_node_attn_bwd_workspace() bytes.                          */
+size_t han_node_attn_bwd_workspace(int64_t N, int K, int FP);
+int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *pre,
+                           const float *aggp, const float *tsum, const float *f1,
+                           const float *lse, const float *c, float *g, float *stats,
+                           float *df1, float *dc, void *workspace, size_t workspace_bytes,
+                           int64_t N, int K, int FP, int activation, void *stream);
+
+/* Backward, step 2 (gather over the TRANSPOSED graph, no float atomics):
+ * colptr (NS+1) / rowidx (E) list, for each source row j owned by this call,
+ * the destination rows i (indices into the NT-row tables g (NT,D) and
+ * stats (NT,K,4)).  Produces for each source j
+ *   df2_j[k] = sum_i dl_ij,   dH_j = mH_j/keep * sum_i drop(alpha_ij) g_i
+ *                                     + df1_j a1 + df2_j a2
+ * H, f2, df1 are the NS local source rows; dH (NS,D), df2 (NS,K) outputs.
+ * src_offset / the ids in rowidx + dst_offset are the global ids used as RNG
+ * keys (must match the forward).                                            */
+int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const float *g,
+                           const float *stats, const float *H, const float *f2,
+                           const float *df1, const float *a1, const float *a2,
+                           float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
+                           float coef_drop, float fts_drop, uint64_t seed,
+                           int64_t src_offset, int64_t dst_offset, void *stream);
+
+/* Backward, step 3: gradients of the score parameters
+ *   da1[k,f] = sum_n df1[n,k] H[n,k,f]   da2 likewise with df2
+ *   db1[k] = sum_n df1[n,k]              db2[k] = sum_n df2[n,k]            */
+size_t han_score_param_bwd_workspace(int64_t N, int K, int FP);
+int han_score_param_bwd(const float *H, const float *df1, const float *df2, float *da1,
+                        float *da2, float *db1, float *db2, void *workspace,
+                        size_t workspace_bytes, int64_t N, int K, int FP, void *stream);
+
+/* ---- K3: semantic-level (meta-path) attention ------------------------------
+ * utils/layers.py:152-159: v = tanh(M Womega + bomega); s = v . uomega;
+ * beta = softmax over P PER NODE; Z = sum_p beta_p M_p.
+ * M (N,P,D); Womega (D,A); bomega,uomega (A); Z (N,D); beta (N,P).          */
+int han_sem_attn_fwd(const float *M, const float *w_omega, const float *b_omega,
+                     const float *u_omega, float *Z, float *beta, int64_t N, int P,
+                     int D, int A, void *stream);
+
+/* dZ (N,D) -> dM (N,P,D), dWomega (D,A), dbomega (A), duomega (A).
+ * beta is the forward's output.                                            */
+size_t han_sem_attn_bwd_workspace(int64_t N, int P, int D, int A);
+int han_sem_attn_bwd(const float *M, const float *w_omega, const float *b_omega,
+                     const float *u_omega, const float *beta, const float *dZ, float *dM,
+                     float *dw_omega, float *db_omega, float *du_omega, void *workspace,
+                     size_t workspace_bytes, int64_t N, int P, int D, int A, void *stream);
+
+/* ---- classifier + masked loss ----------------------------------------------
+ * models/gat.py:65-72: logits = (1/HC) sum_h (Z Wc[h] + bc[h]);  Wc (HC,D,C).
+ * models/base_gattn.py:41-48,61-69: per-row masked softmax-CE and accuracy
+ * terms with row weight w_i = mask_i * inv_mask_mean / n_total:
+ *   loss_acc[0] = sum_i w_i CE_i,  loss_acc[1] = sum_i w_i [argmax == label]
+ * labels are class ids (int32, argmax of the one-hot rows); mask uint8.
+ * If dZ != NULL also writes dlogits (N,C) = w_i (softmax - onehot) and
+ * dZ = dlogits @ mean_h(Wc[h])^T, dWc (HC,D,C), dbc (HC,C).                 */
+size_t han_classifier_workspace(int64_t N, int D, int C, int HC);
+int han_classifier_loss(const float *Z, const float *Wc, const float *bc,
+                        const int32_t *labels, const uint8_t *mask, float row_weight,
+                        float *logits, float *loss_acc, float *dZ, float *dWc, float *dbc,
+                        void *workspace, size_t workspace_bytes, int64_t N, int D, int C,
+                        int HC, void *stream);
+
+/* ---- optimiser --------------------------------------------------------------
+ * models/base_gattn.py:12-24: L2 on every trainable + tf.train.AdamOptimizer:
+ *   g' = g + l2_coef * p;  m,v EMAs;  p -= lr_t * m / (sqrt(v) + eps)
+ * with lr_t = lr * sqrt(1-beta2^t)/(1-beta1^t) computed by the caller.      */
+int han_adam_step(float *param, const float *grad, float *m, float *v, int64_t n,
+                  float lr_t, float beta1, float beta2, float eps, float l2_coef,
+                  void *stream);
+
+/* sum over all parameters of p^2/2 (the L2 term of the reported loss).
+ * out[0] written.  workspace: 4096 floats.                                 */
+int han_l2_half_sumsq(const float *param, int64_t n, float *out, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
+/* ---- input format: additive bias matrix -> CSR ----------------------------
+ * utils/process.py:14-25 produces bias (N,N) in {0,-1e9}; an edge is an entry
+ * > -1e8.  Two launches: counts per row (then the caller scans) and fill.  */
+int han_bias_row_counts(const float *bias, int64_t N, int64_t ld, int64_t *counts,
+                        void *stream);
+int han_bias_fill_csr(const float *bias, int64_t N, int64_t ld, const int64_t *rowptr,
+                      int32_t *colidx, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAN_HIP_H */

@@ -1,0 +1,202 @@
+"""Torch-CPU autograd restatement of the HAN hot path -- TEST INFRASTRUCTURE.
+
+Second, independent restatement of the reference arithmetic (the first is
+``oracle/han_oracle.py``) whose purpose is gradients (autograd, float64) and
+the timed ``cpu_baseline`` leg of ``bench.py`` (float32, all host cores).
+PARITY UNPINNED, for the reasons given in ``oracle/han_oracle.py``.
+
+Parameters use the batched layout of the HIP implementation:
+  W (P,F,D)  a1,a2 (P,K,F')  b1,b2 (P,K)  c (P,D)      D = K*F', column d = k*F'+f'
+  w_omega (D,A)  b_omega (A,)  u_omega (A,)  Wc (Hc,D,C)  bc (Hc,C)
+``to_batched`` converts from the per-head dicts of ``han_oracle.init_params``.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline may
+import this module.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as Fnn
+
+LEAKY_ALPHA = 0.2
+
+
+def to_batched(params, dtype=torch.float64):
+    """per-head dict params (han_oracle.init_params) -> batched torch tensors."""
+    heads = params['heads']
+    P, K = len(heads), len(heads[0])
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=dtype)
+    out = {
+        'W': torch.stack([torch.cat([t(h['W']) for h in hp], dim=1) for hp in heads]),
+        'a1': torch.stack([torch.stack([t(h['a1']) for h in hp]) for hp in heads]),
+        'a2': torch.stack([torch.stack([t(h['a2']) for h in hp]) for hp in heads]),
+        'b1': torch.stack([torch.stack([t(h['b1']) for h in hp]) for hp in heads]),
+        'b2': torch.stack([torch.stack([t(h['b2']) for h in hp]) for hp in heads]),
+        'c': torch.stack([torch.cat([t(h['c']) for h in hp]) for hp in heads]),
+        'w_omega': t(params['w_omega']), 'b_omega': t(params['b_omega']),
+        'u_omega': t(params['u_omega']),
+        'Wc': torch.stack([t(c['W']) for c in params['cls']]),
+        'bc': torch.stack([t(c['b']) for c in params['cls']]),
+    }
+    assert out['W'].shape[0] == P and out['a1'].shape[1] == K
+    return out
+
+
+PARAM_ORDER = ('W', 'a1', 'b1', 'a2', 'b2', 'c', 'w_omega', 'b_omega', 'u_omega', 'Wc', 'bc')
+
+
+def node_attention_dense(x, bias_mat, W, a1, b1, a2, b2, c, keep_in=1.0, keep_coef=1.0,
+                         masks=None):
+    """All K heads of one meta-path, dense additive-mask form.
+    utils/layers.py:18-35,46 per head; head concat models/gat.py:46.
+    x (N,F); bias_mat (N,N); W (F,D); a1,a2 (K,F'); b1,b2 (K,); c (D,).
+    masks: None or dict 'seq' (K,N,F), 'coef' (K,N,N), 'fts' (N,D) of {0,1}.
+    Returns (N,D) = ELU(coefs @ H + c).
+    """
+    K, Fp = a1.shape
+    outs = []
+    for k in range(K):
+        xs = x
+        if masks is not None and 'seq' in masks:
+            xs = x / keep_in * masks['seq'][k]                         # layers.py:19
+        h = xs @ W[:, k * Fp:(k + 1) * Fp]                             # :20
+        f1 = h @ a1[k] + b1[k]                                         # :23
+        f2 = h @ a2[k] + b2[k]                                         # :24
+        logits = f1[:, None] + f2[None, :]                             # :26
+        coefs = torch.softmax(Fnn.leaky_relu(logits, LEAKY_ALPHA) + bias_mat, dim=-1)  # :27
+        if masks is not None and 'coef' in masks:
+            coefs = coefs / keep_coef * masks['coef'][k]               # :30
+        if masks is not None and 'fts' in masks:
+            h = h / keep_in * masks['fts'][:, k * Fp:(k + 1) * Fp]     # :32
+        vals = coefs @ h                                               # :34
+        outs.append(Fnn.elu(vals + c[k * Fp:(k + 1) * Fp]))            # :35,46
+    return torch.cat(outs, dim=-1)
+
+
+def node_attention_csr(x, rowptr, colidx, W, a1, b1, a2, b2, c, keep_in=1.0, keep_coef=1.0,
+                       masks=None, adj_vals=None):
+    """All K heads of one meta-path over CSR neighbours only -- what
+    sp_attn_head (utils/layers.py:85-127) computes; heads batched.
+    masks: 'seq' (K,N,F), 'coef' (E,K), 'fts' (N,D).
+    """
+    N = x.shape[0]
+    K, Fp = a1.shape
+    D = K * Fp
+    deg = rowptr[1:] - rowptr[:-1]
+    rows = torch.repeat_interleave(torch.arange(N), deg)
+    cols = colidx.long()
+    if masks is not None and 'seq' in masks:
+        h = torch.cat([(x / keep_in * masks['seq'][k]) @ W[:, k * Fp:(k + 1) * Fp]
+                       for k in range(K)], dim=1)                       # :87-90 per head
+    else:
+        h = x @ W                                                       # :90
+    hk = h.view(N, K, Fp)
+    f1 = (hk * a1[None]).sum(-1) + b1[None]                             # :93  (N,K)
+    f2 = (hk * a2[None]).sum(-1) + b2[None]                             # :94
+    if adj_vals is None:
+        lg = f1[rows] + f2[cols]                                        # :95-96 binary adj
+    else:
+        lg = adj_vals[:, None] * f1[rows] + adj_vals[:, None] * f2[cols]
+    lg = Fnn.leaky_relu(lg, LEAKY_ALPHA)                                # :97-99  (E,K)
+    mx = torch.full((N, K), -float('inf'), dtype=lg.dtype)
+    mx = mx.scatter_reduce(0, rows[:, None].expand(-1, K), lg, reduce='amax')
+    ex = torch.exp(lg - mx[rows])
+    den = torch.zeros((N, K), dtype=lg.dtype).index_add(0, rows, ex)
+    coefs = ex / den[rows]                                              # :100
+    if masks is not None and 'coef' in masks:
+        coefs = coefs / keep_coef * masks['coef']                       # :102-106
+    if masks is not None and 'fts' in masks:
+        h = h / keep_in * masks['fts']                                  # :107-108
+    msg = coefs[:, :, None] * h.view(N, K, Fp)[cols]                    # (E,K,F')
+    vals = torch.zeros((N, K, Fp), dtype=h.dtype).index_add(0, rows, msg)   # :113
+    return Fnn.elu(vals.reshape(N, D) + c)                              # :118,127
+
+
+def semantic_attention(m, w_omega, b_omega, u_omega):
+    """utils/layers.py:152-159.  m (N,P,D) -> (N,D), (N,P)."""
+    v = torch.tanh(m @ w_omega + b_omega)
+    vu = v @ u_omega
+    alphas = torch.softmax(vu, dim=-1)
+    return (m * alphas[..., None]).sum(1), alphas
+
+
+def hetegat_forward(x_list, graphs, bp, keep_in=1.0, keep_coef=1.0, masks=None, dense=False):
+    """models/gat.py:34-77 with hid_units=[F'], batched heads.
+    x_list[p] (N,F); graphs[p] = bias_mat (N,N) if dense else (rowptr, colidx).
+    Returns logits (N,C), final_embed (N,D), att_val (N,P)."""
+    embeds = []
+    for p, (x, g) in enumerate(zip(x_list, graphs)):                    # gat.py:39
+        mk = masks[p] if masks is not None else None
+        args = (bp['W'][p], bp['a1'][p], bp['b1'][p], bp['a2'][p], bp['b2'][p], bp['c'][p])
+        if dense:
+            e = node_attention_dense(x, g, *args, keep_in=keep_in, keep_coef=keep_coef, masks=mk)
+        else:
+            e = node_attention_csr(x, g[0], g[1], *args, keep_in=keep_in, keep_coef=keep_coef,
+                                   masks=mk)
+        embeds.append(e[:, None, :])                                    # gat.py:58
+    m = torch.cat(embeds, dim=1)                                        # gat.py:60
+    final_embed, att = semantic_attention(m, bp['w_omega'], bp['b_omega'], bp['u_omega'])
+    hc = bp['Wc'].shape[0]
+    logits = sum(final_embed @ bp['Wc'][i] + bp['bc'][i] for i in range(hc)) / hc   # gat.py:66-72
+    return logits, final_embed, att
+
+
+def masked_softmax_cross_entropy(logits, labels, mask):
+    """models/base_gattn.py:41-48."""
+    loss = -(labels * torch.log_softmax(logits, dim=-1)).sum(-1)
+    mask = mask.to(logits.dtype)
+    mask = mask / mask.mean()
+    return (loss * mask).mean()
+
+
+def masked_accuracy(logits, labels, mask):
+    """models/base_gattn.py:61-69."""
+    correct = (logits.argmax(1) == labels.argmax(1)).to(logits.dtype)
+    mask = mask.to(logits.dtype)
+    mask = mask / mask.mean()
+    return (correct * mask).mean()
+
+
+def l2_all(bp, l2_coef):
+    """models/base_gattn.py:14-16 (applies to every trainable, biases included)."""
+    return l2_coef * sum((bp[k] ** 2).sum() / 2 for k in PARAM_ORDER)
+
+
+def adam_step_tf_(bp, grads, state, lr=0.005, beta1=0.9, beta2=0.999, eps=1e-8):
+    """In-place tf.train.AdamOptimizer step (models/base_gattn.py:19-22)."""
+    state['t'] += 1
+    t = state['t']
+    lr_t = lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    with torch.no_grad():
+        for k in PARAM_ORDER:
+            m, v = state['m'][k], state['v'][k]
+            m.mul_(beta1).add_(grads[k], alpha=1 - beta1)
+            v.mul_(beta2).addcmul_(grads[k], grads[k], value=1 - beta2)
+            bp[k].sub_(lr_t * m / (v.sqrt() + eps))
+
+
+def new_adam_state(bp):
+    return {'t': 0, 'm': {k: torch.zeros_like(bp[k]) for k in PARAM_ORDER},
+            'v': {k: torch.zeros_like(bp[k]) for k in PARAM_ORDER}}
+
+
+def train_epoch(x_list, graphs, bp, state, labels, train_mask, val_mask, lr=0.005,
+                l2_coef=0.001, keep=0.4, masks=None, dense=False):
+    """One reference epoch (ex_acm3025.py:171-218): one fwd+bwd+Adam step with
+    dropout 0.6/0.6 on the train mask, then one eval forward on the val mask."""
+    for k in PARAM_ORDER:
+        bp[k].requires_grad_(True)
+        bp[k].grad = None
+    logits, _, _ = hetegat_forward(x_list, graphs, bp, keep_in=keep, keep_coef=keep,
+                                   masks=masks, dense=dense)
+    loss = masked_softmax_cross_entropy(logits, labels, train_mask) + l2_all(bp, l2_coef)
+    loss.backward()
+    grads = {k: bp[k].grad for k in PARAM_ORDER}
+    for k in PARAM_ORDER:
+        bp[k].requires_grad_(False)
+    adam_step_tf_(bp, grads, state, lr=lr)
+    with torch.no_grad():
+        vlogits, _, _ = hetegat_forward(x_list, graphs, bp, dense=dense)
+        vloss = masked_softmax_cross_entropy(vlogits, labels, val_mask)
+        vacc = masked_accuracy(vlogits, labels, val_mask)
+    return float(loss.detach()), float(vloss), float(vacc)

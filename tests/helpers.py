@@ -1,0 +1,72 @@
+"""Shared builders for the parity tests (test infrastructure)."""
+import numpy as np
+import torch
+
+from oracle import han_oracle as ho
+from oracle import han_oracle_torch as ht
+
+
+def random_adj(rng, n, density, symmetric=True, special_rows=True):
+    """Binary adjacency WITHOUT self-loops (adj_to_bias re-adds I, as
+    ex_acm3025.py:61 / utils/process.py:18-20).  special_rows plants the edge
+    cases of SURVEY.md section 4: an isolated node (degree 1 after +I: the
+    self-loop only) and a node adjacent to everybody (degree N)."""
+    a = (rng.random((n, n)) < density).astype(np.float64)
+    if symmetric:
+        a = np.maximum(a, a.T)
+    np.fill_diagonal(a, 0.0)
+    if special_rows and n >= 4:
+        a[1, :] = 0.0
+        a[:, 1] = 0.0          # isolated node
+        a[2, :] = 1.0
+        a[:, 2] = 1.0          # hub
+        a[2, 2] = 0.0
+        a[1, 2] = a[2, 1] = 0.0
+    return a
+
+
+def make_problem(seed, n, f, p, c, densities, dtype=np.float64, nonzero_biases=True):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((1, n, f)).astype(dtype)
+    adjs = [random_adj(rng, n, densities[i % len(densities)])[None] for i in range(p)]
+    biases = [ho.adj_to_bias(a, [n], 1) for a in adjs]
+    params = ho.init_params(rng, p, f, c, nonzero_biases=nonzero_biases)
+    labels = rng.integers(0, c, size=n)
+    onehot = np.eye(c)[labels]
+    mask = rng.random(n) < 0.4
+    mask[0] = True
+    return dict(x=x, adjs=adjs, biases=biases, params=params, labels=labels, onehot=onehot,
+                mask=mask, n=n, f=f, p=p, c=c)
+
+
+def load_params(model, bp):
+    """Copy batched oracle parameters (han_oracle_torch.to_batched) into a built model."""
+    with torch.no_grad():
+        for k in ht.PARAM_ORDER:
+            getattr(model, k).copy_(bp[k].to(torch.float32))
+
+
+def build_model(prob, dev, mp_att_size=128):
+    from han_amd.gat import HeteGAT_multi
+    model = HeteGAT_multi()
+    model.build(prob["p"], prob["f"], prob["c"], (8,), (8, len(prob["params"]["cls"])),
+                mp_att_size, device=dev)
+    bp = ht.to_batched(prob["params"])
+    load_params(model, bp)
+    return model, bp
+
+
+def gpu_inputs(prob, dev):
+    from han_amd.graph import CSRGraph
+    x = torch.tensor(prob["x"][0], dtype=torch.float32, device=dev)
+    graphs = []
+    for b in prob["biases"]:
+        rp, ci = ho.bias_to_csr(b)
+        graphs.append(CSRGraph.from_arrays(rp, ci, prob["n"], device=dev))
+    return x, graphs
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))

@@ -1,0 +1,487 @@
+"""GPU parity tests: every HIP kernel, through the C ABI (han_amd.ops -> ctypes ->
+libhan_hip.so), against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32 kernels vs float64 oracle): 1e-4 absolute on logits / outputs
+(the bar BASELINE.json's north_star states), 2e-3 relative-to-max on gradients.
+PARITY UNPINNED with respect to TensorFlow itself (oracle/han_oracle.py header).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import han_oracle as ho
+from oracle import han_oracle_torch as ht
+from tests import rng_ref
+from tests.helpers import build_model, gpu_inputs, make_problem, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+GTOL = 2e-3
+
+
+def _t(a, dev, dtype=torch.float32):
+    return torch.tensor(np.asarray(a), dtype=dtype, device=dev)
+
+
+# ----------------------------------------------------------------------------- K1
+@pytest.mark.parametrize("n,f", [(1, 5), (7, 13), (64, 32), (130, 77), (512, 334)])
+def test_project_fwd_matches_oracle(dev, n, f):
+    from han_amd import ops
+    rng = np.random.default_rng(n * 1000 + f)
+    x = rng.standard_normal((n, f))
+    W = rng.standard_normal((f, 64)) * 0.2
+    a1, a2 = rng.standard_normal((8, 8)), rng.standard_normal((8, 8))
+    b1, b2 = rng.standard_normal(8), rng.standard_normal(8)
+    H, Hd, f1, f2 = ops.project_fwd(_t(x, dev), _t(W, dev), _t(a1, dev), _t(a2, dev), _t(b1, dev),
+                                    _t(b2, dev))
+    Href = x @ W
+    assert Hd is None
+    assert np.abs(H.cpu().numpy() - Href).max() < TOL * max(1.0, np.abs(Href).max())
+    f1ref = (Href.reshape(n, 8, 8) * a1[None]).sum(-1) + b1
+    f2ref = (Href.reshape(n, 8, 8) * a2[None]).sum(-1) + b2
+    assert np.abs(f1.cpu().numpy() - f1ref).max() < 1e-3 * max(1.0, np.abs(f1ref).max())
+    assert np.abs(f2.cpu().numpy() - f2ref).max() < 1e-3 * max(1.0, np.abs(f2ref).max())
+
+
+@pytest.mark.parametrize("n,f", [(7, 13), (130, 77)])
+def test_project_dropout_matches_hash_masks(dev, n, f):
+    """Input dropout re-sampled per head (layers.py:18-19) and projected-row
+    dropout (layers.py:31-32) with the masks regenerated in NumPy."""
+    from han_amd import ops
+    rng = np.random.default_rng(5)
+    seed, drop, off = 0x1234ABCD5678, 0.6, 11
+    x = rng.standard_normal((n, f))
+    W = rng.standard_normal((f, 64)) * 0.2
+    a1, a2 = rng.standard_normal((8, 8)), rng.standard_normal((8, 8))
+    b1, b2 = rng.standard_normal(8), rng.standard_normal(8)
+    H, Hd, f1, _ = ops.project_fwd(_t(x, dev), _t(W, dev), _t(a1, dev), _t(a2, dev), _t(b1, dev),
+                                   _t(b2, dev), in_drop=drop, fts_drop=drop, seed=seed, row_offset=off)
+    keep = rng_ref.keep_prob32(drop)
+    sm = rng_ref.seq_mask(seed, n, f, 8, drop, row_offset=off)
+    Href = np.concatenate([(x / keep * sm[k]) @ W[:, 8 * k:8 * k + 8] for k in range(8)], 1)
+    assert np.abs(H.cpu().numpy() - Href).max() < TOL * max(1.0, np.abs(Href).max())
+    fm = rng_ref.fts_mask(seed, n, 64, drop, row_offset=off)
+    assert np.abs(Hd.cpu().numpy() - Href / keep * fm).max() < 2 * TOL * max(1.0, np.abs(Href).max())
+    # backward: dW = sum_k masked X^T dH_k
+    dH = rng.standard_normal((n, 64))
+    dW = ops.project_bwd(_t(x, dev), _t(dH, dev), 8, 8, in_drop=drop, seed=seed, row_offset=off)
+    dWref = np.concatenate([(x / keep * sm[k]).T @ dH[:, 8 * k:8 * k + 8] for k in range(8)], 1)
+    assert rel_err(dW.cpu().numpy(), dWref) < 1e-4
+
+
+@pytest.mark.parametrize("n,f", [(33, 70), (3025, 130)])
+def test_project_bwd_no_dropout(dev, n, f):
+    from han_amd import ops
+    rng = np.random.default_rng(9)
+    x, dH = rng.standard_normal((n, f)), rng.standard_normal((n, 64))
+    dW = ops.project_bwd(_t(x, dev), _t(dH, dev), 8, 8)
+    assert rel_err(dW.cpu().numpy(), x.T @ dH) < 1e-4
+
+
+# ----------------------------------------------------------------------------- K2
+def _k2_inputs(rng, n, density, dev):
+    from han_amd.graph import CSRGraph
+    from tests.helpers import random_adj
+    adj = random_adj(rng, n, density)
+    bias = ho.adj_to_bias(adj[None], [n], 1)
+    rp, ci = ho.bias_to_csr(bias)
+    H = rng.standard_normal((n, 64))
+    f1, f2 = rng.standard_normal((n, 8)) * 2, rng.standard_normal((n, 8)) * 2
+    c = rng.standard_normal(64) * 0.1
+    g = CSRGraph.from_arrays(rp, ci, n, device=dev)
+    return bias, rp, ci, H, f1, f2, c, g
+
+
+def _k2_oracle(bias, H, f1, f2, c):
+    """layers.py:26-35,46 per head from given H, f1, f2 (dense additive mask)."""
+    n = H.shape[0]
+    out = np.zeros((n, 64))
+    lse = np.zeros((n, 8))
+    for k in range(8):
+        logits = ho.leaky_relu(f1[:, k][:, None] + f2[:, k][None, :]) + bias[0]
+        coefs = ho.softmax(logits, axis=-1)
+        out[:, 8 * k:8 * k + 8] = coefs @ H[:, 8 * k:8 * k + 8] + c[8 * k:8 * k + 8]
+        mx = logits.max(1)
+        lse[:, k] = mx + np.log(np.exp(logits - mx[:, None]).sum(1))
+    return ho.elu(out), out, lse
+
+
+@pytest.mark.parametrize("n,density", [(7, 0.3), (64, 0.05), (64, 0.5), (512, 0.01), (512, 0.3),
+                                        (1000, 0.002)])
+def test_node_attn_fwd_matches_dense_mask_oracle(dev, n, density):
+    """CSR gather kernel == the reference's dense -1e9 additive-mask softmax,
+    incl. a self-loop-only row, a full row, low- and high-degree variants."""
+    from han_amd import ops
+    rng = np.random.default_rng(int(n * 100 + density * 1000))
+    bias, rp, ci, H, f1, f2, c, g = _k2_inputs(rng, n, density, dev)
+    ref, pre_ref, lse_ref = _k2_oracle(bias, H, f1, f2, c)
+    out, saved = ops.node_attn_fwd(g, _t(H, dev), _t(f1, dev), _t(f2, dev), _t(c, dev))
+    assert saved is None
+    assert np.abs(out.cpu().numpy() - ref).max() < TOL
+    out2, saved = ops.node_attn_fwd(g, _t(H, dev), _t(f1, dev), _t(f2, dev), _t(c, dev), train=True)
+    pre, lse, aggp, tsum = saved
+    assert np.abs(out2.cpu().numpy() - ref).max() < TOL
+    assert np.abs(pre.cpu().numpy() - pre_ref).max() < TOL
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() < 1e-4 * max(1.0, np.abs(lse_ref).max())
+    # strided output straight into M[:, p, :]
+    M = torch.zeros((n, 3, 64), device=dev)
+    ops.node_attn_fwd(g, _t(H, dev), _t(f1, dev), _t(f2, dev), _t(c, dev), out=M[:, 1, :])
+    assert np.abs(M[:, 1, :].cpu().numpy() - ref).max() < TOL
+    assert float(M[:, 0, :].abs().max()) == 0.0 and float(M[:, 2, :].abs().max()) == 0.0
+
+
+def test_node_attn_online_softmax_rescale(dev):
+    """Forces the running-max rescale: the largest score arrives LAST in a long
+    row, after hundreds of small ones, with a spread > 80 (exp underflow range)."""
+    from han_amd import ops
+    from han_amd.graph import CSRGraph
+    n = 700
+    rng = np.random.default_rng(3)
+    H = rng.standard_normal((n, 64))
+    f1 = np.zeros((n, 8))
+    f2 = rng.standard_normal((n, 8))
+    f2[-1] = 90.0            # last neighbour of every row dominates
+    f2[-2] = -90.0
+    rp = np.arange(0, n * n + 1, n)
+    ci = np.tile(np.arange(n), n).astype(np.int32)
+    bias = np.zeros((1, n, n))
+    c = np.zeros(64)
+    ref, _, _ = _k2_oracle(bias, H, f1, f2, c)
+    g = CSRGraph.from_arrays(rp, ci, n, device=dev)
+    out, _ = ops.node_attn_fwd(g, _t(H, dev), _t(f1, dev), _t(f2, dev), _t(c, dev))
+    assert np.abs(out.cpu().numpy() - ref).max() < TOL
+
+
+def test_node_attn_empty_rows_and_determinism(dev):
+    from han_amd import ops
+    from han_amd.graph import CSRGraph
+    n = 9
+    rp = np.array([0, 0, 2, 2, 5, 5, 5, 6, 6, 6])
+    ci = np.array([0, 3, 1, 2, 8, 7], dtype=np.int32)
+    rng = np.random.default_rng(0)
+    H, f1, f2 = rng.standard_normal((n, 64)), rng.standard_normal((n, 8)), rng.standard_normal((n, 8))
+    c = rng.standard_normal(64)
+    g = CSRGraph.from_arrays(rp, ci, n, device=dev)
+    out, _ = ops.node_attn_fwd(g, _t(H, dev), _t(f1, dev), _t(f2, dev), _t(c, dev))
+    o = out.cpu().numpy()
+    assert np.isfinite(o).all()
+    # a row with no stored entry aggregates nothing: out = act(0 + c) (sp_attn_head, layers.py:113-118)
+    assert np.abs(o[0] - ho.elu(c)).max() < 1e-6
+    out_b, _ = ops.node_attn_fwd(g, _t(H, dev), _t(f1, dev), _t(f2, dev), _t(c, dev))
+    assert torch.equal(out, out_b)      # no float atomics: bitwise reproducible
+
+
+# ------------------------------------------------------------------- full forward
+@pytest.mark.parametrize("n,f,p,dens", [(7, 5, 1, [0.4]), (64, 20, 2, [0.1, 0.6]),
+                                         (512, 48, 3, [0.004, 0.05, 0.4])])
+def test_inference_matches_oracle(dev, n, f, p, dens):
+    """HeteGAT_multi.inference == oracle restatement of models/gat.py:34-77
+    (dense bias_mat path), logits within 1e-4."""
+    prob = make_problem(100 + n, n, f, p, 3, dens)
+    lg, fe, att = ho.hetegat_multi_inference([prob["x"]] * p, 3, n, False, 0.0, 0.0, prob["biases"],
+                                             [8], [8, 1], prob["params"])
+    model, _ = build_model(prob, dev)
+    x = _t(prob["x"], dev)                                    # (1,N,F) as the reference feeds
+    biases = [_t(b, dev) for b in prob["biases"]]             # dense (1,N,N) masks -> GPU CSR builder
+    with torch.no_grad():
+        logits, final_embed, att_val = model.inference([x] * (p + 1), 3, n, False, 0.0, 0.0, biases,
+                                                       [8], [8, 1])
+    assert logits.shape == (1, n, 3) and final_embed.shape == (n, 64) and att_val.shape == (n, p)
+    assert np.abs(logits.cpu().numpy() - lg).max() < TOL
+    assert np.abs(final_embed.cpu().numpy() - fe).max() < TOL
+    assert np.abs(att_val.cpu().numpy() - att).max() < TOL
+
+
+def test_inference_matches_golden_fixture(dev):
+    """Committed fixture (tests/golden/han_forward_n64.npz, generated by
+    tests/golden/gen_fixtures.py from the float64 oracle)."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "han_forward_n64.npz")
+    z = np.load(path)
+    from han_amd.gat import HeteGAT_multi
+    from han_amd.graph import CSRGraph
+    from tests.helpers import load_params
+    P = int(z["P"])
+    model = HeteGAT_multi().build(P, int(z["F"]), int(z["C"]), (8,), (8, 1), 128, device=dev)
+    bp = {k: torch.tensor(z["param_" + k]) for k in ht.PARAM_ORDER}
+    load_params(model, bp)
+    graphs = [CSRGraph.from_arrays(z[f"rowptr_{p}"], z[f"colidx_{p}"], int(z["N"]), device=dev)
+              for p in range(P)]
+    x = _t(z["x"], dev)
+    with torch.no_grad():
+        logits, fe, att = model.inference([x] * P, int(z["C"]), int(z["N"]), False, 0.0, 0.0, graphs,
+                                          [8], [8, 1])
+    assert np.abs(logits[0].cpu().numpy() - z["logits"]).max() < TOL
+    assert np.abs(fe.cpu().numpy() - z["final_embed"]).max() < TOL
+    assert np.abs(att.cpu().numpy() - z["att_val"]).max() < TOL
+
+
+# ------------------------------------------------------------------------ backward
+def _oracle_grads(prob, bp, masks=None, keep=1.0, dense=True):
+    bp = {k: v.clone().requires_grad_(True) for k, v in bp.items()}
+    xt = torch.tensor(prob["x"][0])
+    if dense:
+        graphs = [torch.tensor(b[0]) for b in prob["biases"]]
+    else:
+        graphs = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]
+    logits, _, _ = ht.hetegat_forward([xt] * prob["p"], graphs, bp, keep_in=keep, keep_coef=keep,
+                                      masks=masks, dense=dense)
+    loss = ht.masked_softmax_cross_entropy(logits, torch.tensor(prob["onehot"]),
+                                           torch.tensor(prob["mask"]))
+    loss.backward()
+    return float(loss), {k: bp[k].grad.numpy() for k in ht.PARAM_ORDER}, logits.detach().numpy()
+
+
+def _gpu_loss_and_grads(model, prob, dev, attn_drop=0.0, ffd_drop=0.0):
+    from han_amd import layers, ops
+    x, graphs = gpu_inputs(prob, dev)
+    labels = _t(prob["labels"], dev, torch.int32)
+    mask = _t(prob["mask"].astype(np.uint8), dev, torch.uint8)
+    model.zero_grad_flat()
+    M = model.node_level([x] * prob["p"], graphs, attn_drop, ffd_drop, True, ops.ACT_ELU)
+    Z, _ = layers.SemanticAttention.apply(M, model.w_omega, model.b_omega, model.u_omega)
+    loss, acc, logits = layers.ClassifierLoss.apply(Z, model.Wc, model.bc, labels, mask,
+                                                    1.0 / int(prob["mask"].sum()))
+    loss.backward()
+    grads = {k: getattr(model, k).grad.detach().cpu().numpy().copy() for k in ht.PARAM_ORDER}
+    return float(loss), grads, logits.cpu().numpy(), float(acc)
+
+
+@pytest.mark.parametrize("n,f,p,dens", [(7, 5, 1, [0.4]), (64, 20, 2, [0.1, 0.6]),
+                                         (300, 40, 3, [0.005, 0.05, 0.5])])
+def test_gradients_match_autograd_oracle(dev, n, f, p, dens):
+    """Hand-written K1/K2/K3/classifier backward vs float64 autograd of the
+    dense restatement (SURVEY.md section 8a 'Backward')."""
+    prob = make_problem(7 + n, n, f, p, 3, dens)
+    model, bp = build_model(prob, dev)
+    loss_ref, gref, lg_ref = _oracle_grads(prob, bp)
+    loss, grads, lg, acc = _gpu_loss_and_grads(model, prob, dev)
+    assert abs(loss - loss_ref) < 1e-4
+    assert np.abs(lg - lg_ref).max() < TOL
+    acc_ref = float(ht.masked_accuracy(torch.tensor(lg_ref), torch.tensor(prob["onehot"]),
+                                       torch.tensor(prob["mask"])))
+    assert abs(acc - acc_ref) < 1e-5
+    for k in ht.PARAM_ORDER:
+        assert rel_err(grads[k], gref[k]) < GTOL, k
+
+
+@pytest.mark.parametrize("n,f,p,dens", [(40, 12, 2, [0.1, 0.5]), (200, 30, 1, [0.01])])
+def test_dropout_forward_backward_match_oracle_with_same_masks(dev, n, f, p, dens):
+    """Training step with dropout 0.6/0.6: regenerate the kernels' hash masks in
+    NumPy, feed them to the oracle, compare loss and every gradient."""
+    from han_amd import rng as hrng
+    prob = make_problem(33 + n, n, f, p, 3, dens)
+    model, bp = build_model(prob, dev)
+    drop = 0.6
+    hrng.manual_seed(99)
+    seeds = [hrng.next_seed() for _ in range(p)]
+    hrng.manual_seed(99)                       # the model will draw the same seeds
+    keep = rng_ref.keep_prob32(drop)
+    masks = []
+    for q in range(p):
+        rp, ci = ho.bias_to_csr(prob["biases"][q])
+        masks.append({"seq": torch.tensor(rng_ref.seq_mask(seeds[q], n, f, 8, drop)),
+                      "coef": torch.tensor(rng_ref.coef_mask_csr(seeds[q], rp, ci, 8, drop)),
+                      "fts": torch.tensor(rng_ref.fts_mask(seeds[q], n, 64, drop))})
+    loss_ref, gref, lg_ref = _oracle_grads(prob, bp, masks=masks, keep=keep, dense=False)
+    loss, grads, lg, _ = _gpu_loss_and_grads(model, prob, dev, attn_drop=drop, ffd_drop=drop)
+    assert np.abs(lg - lg_ref).max() < 5 * TOL
+    assert abs(loss - loss_ref) < 5e-4
+    for k in ht.PARAM_ORDER:
+        assert rel_err(grads[k], gref[k]) < GTOL, k
+
+
+def test_dropout_statistics(dev):
+    """Keep rate of each stream ~ 0.4 and mean-preserving scaling (1/keep)."""
+    from han_amd import ops
+    n, f = 4096, 64
+    x = torch.ones((n, f), device=dev)
+    W = torch.zeros((f, 64), device=dev)
+    W[:, ::8] = 1.0                      # column k*8 of head k sums the kept inputs
+    z8 = torch.zeros((8, 8), device=dev)
+    z = torch.zeros(8, device=dev)
+    H, Hd, _, _ = ops.project_fwd(x, W, z8, z8, z, z, in_drop=0.6, fts_drop=0.6, seed=12345)
+    kept = H[:, ::8] * 0.4               # = number of kept inputs per (row, head)
+    rate = float(kept.sum() / (n * f * 8))
+    assert abs(rate - 0.4) < 0.003
+    assert abs(float((Hd != 0).float()[:, ::8].mean()) - 0.4) < 0.02
+    # heads draw different masks
+    assert not torch.equal(H[:, 0], H[:, 8])
+
+
+# ----------------------------------------------------------------------------- K3
+@pytest.mark.parametrize("n,p,a", [(1, 1, 128), (50, 2, 128), (333, 4, 128), (40, 3, 64)])
+def test_semantic_attention_fwd_bwd(dev, n, p, a):
+    from han_amd import ops
+    rng = np.random.default_rng(n + p)
+    M = rng.standard_normal((n, p, 64))
+    w, b, u = rng.standard_normal((64, a)) * 0.2, rng.standard_normal(a) * 0.2, rng.standard_normal(a)
+    Zr, br = ho.simple_att_layer(M, w, b, u, return_alphas=True)
+    Z, beta = ops.sem_attn_fwd(_t(M, dev), _t(w, dev), _t(b, dev), _t(u, dev))
+    assert np.abs(Z.cpu().numpy() - Zr).max() < TOL
+    assert np.abs(beta.cpu().numpy() - br).max() < TOL
+    dZ = rng.standard_normal((n, 64))
+    tM, tw, tb, tu = (torch.tensor(v, requires_grad=True) for v in (M, w, b, u))
+    Zt, _ = ht.semantic_attention(tM, tw, tb, tu)
+    (Zt * torch.tensor(dZ)).sum().backward()
+    dM, dw, db, du = ops.sem_attn_bwd(_t(M, dev), _t(w, dev), _t(b, dev), _t(u, dev), beta, _t(dZ, dev))
+    assert rel_err(dM.cpu().numpy(), tM.grad.numpy()) < GTOL
+    assert rel_err(dw.cpu().numpy(), tw.grad.numpy()) < GTOL
+    assert rel_err(db.cpu().numpy(), tb.grad.numpy()) < GTOL
+    assert rel_err(du.cpu().numpy(), tu.grad.numpy()) < GTOL
+
+
+# ----------------------------------------------------------- classifier / loss / opt
+@pytest.mark.parametrize("n,c,hc", [(5, 3, 1), (257, 4, 1), (100, 7, 2), (64, 16, 1)])
+def test_classifier_loss_matches_oracle(dev, n, c, hc):
+    from han_amd import ops
+    rng = np.random.default_rng(n + c)
+    Z = rng.standard_normal((n, 64))
+    Wc, bc = rng.standard_normal((hc, 64, c)) * 0.3, rng.standard_normal((hc, c)) * 0.1
+    labels = rng.integers(0, c, n)
+    mask = rng.random(n) < 0.5
+    mask[0] = True
+    tZ, tW, tb = (torch.tensor(v, requires_grad=True) for v in (Z, Wc, bc))
+    logits_t = sum(tZ @ tW[i] + tb[i] for i in range(hc)) / hc
+    onehot = torch.tensor(np.eye(c)[labels])
+    loss_t = ht.masked_softmax_cross_entropy(logits_t, onehot, torch.tensor(mask))
+    acc_t = ht.masked_accuracy(logits_t, onehot, torch.tensor(mask))
+    loss_t.backward()
+    # also the NumPy restatement (models/base_gattn.py:41-48)
+    assert abs(float(loss_t) - ho.masked_softmax_cross_entropy(logits_t.detach().numpy(),
+                                                               np.eye(c)[labels], mask)) < 1e-12
+    logits, la, grads = ops.classifier_loss(_t(Z, dev), _t(Wc, dev), _t(bc, dev),
+                                            _t(labels, dev, torch.int32),
+                                            _t(mask.astype(np.uint8), dev, torch.uint8),
+                                            1.0 / mask.sum(), backward=True)
+    assert np.abs(logits.cpu().numpy() - logits_t.detach().numpy()).max() < TOL
+    assert abs(float(la[0]) - float(loss_t)) < 1e-4
+    assert abs(float(la[1]) - float(acc_t)) < 1e-5
+    dZ, dWc, dbc = grads
+    assert rel_err(dZ.cpu().numpy(), tZ.grad.numpy()) < GTOL
+    assert rel_err(dWc.cpu().numpy(), tW.grad.numpy()) < GTOL
+    assert rel_err(dbc.cpu().numpy(), tb.grad.numpy()) < GTOL
+
+
+def test_adam_matches_tf_form(dev):
+    from han_amd.base_gattn import TFAdam
+    rng = np.random.default_rng(1)
+    p0 = rng.standard_normal(1000)
+    p = _t(p0, dev)
+    g = torch.zeros_like(p)
+    opt = TFAdam(p, g, lr=0.005, l2_coef=0.001)
+    pr, m, v = p0.copy(), np.zeros(1000), np.zeros(1000)
+    for t in range(1, 6):
+        gr = rng.standard_normal(1000)
+        g.copy_(_t(gr, dev))
+        opt.step()
+        pr, m, v = ho.adam_step_tf(pr, gr + 0.001 * pr, m, v, t)
+    assert np.abs(p.cpu().numpy() - pr).max() < 1e-5
+
+
+# --------------------------------------------------------------------- input format
+@pytest.mark.parametrize("n", [1, 5, 64, 129, 1000])
+def test_bias_to_csr_gpu(dev, n):
+    from han_amd.graph import CSRGraph
+    rng = np.random.default_rng(n)
+    from tests.helpers import random_adj
+    bias = ho.adj_to_bias(random_adj(rng, n, 0.1)[None], [n], 1)
+    rp, ci = ho.bias_to_csr(bias)
+    g = CSRGraph.from_bias(_t(bias, dev))
+    assert np.array_equal(g.rowptr.cpu().numpy(), rp)
+    assert np.array_equal(g.colidx.cpu().numpy(), ci)
+    gt = g.transpose()
+    import scipy.sparse as sp
+    a = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(n, n)).T.tocsr()
+    a.sort_indices()
+    assert np.array_equal(gt.rowptr.cpu().numpy(), a.indptr)
+    assert np.array_equal(gt.colidx.cpu().numpy(), a.indices)
+
+
+# ------------------------------------------------------------------- layer API
+def test_attn_head_and_sp_attn_head_api(dev):
+    """Reference-named single-head calls (layers.py:7,85) == oracle; attn_head
+    on the dense mask == sp_attn_head on the same binary graph."""
+    import torch.nn.functional as Fnn
+    from han_amd import layers
+    prob = make_problem(5, 50, 9, 1, 3, [0.2])
+    head = prob["params"]["heads"][0][0]
+    ref = ho.attn_head(prob["x"], head, prob["biases"][0])
+    params = {k: _t(v, dev) for k, v in head.items()}
+    x = _t(prob["x"], dev)
+    with torch.no_grad():
+        out = layers.attn_head(x, 8, _t(prob["biases"][0], dev), Fnn.elu, params=params)
+        rp, ci = ho.bias_to_csr(prob["biases"][0])
+        idx = np.stack([np.zeros(len(ci)), np.repeat(np.arange(50), np.diff(rp)), ci])
+        sp_adj = torch.sparse_coo_tensor(torch.tensor(idx, dtype=torch.long), torch.ones(len(ci)),
+                                         (1, 50, 50)).to(dev)
+        out_sp = layers.sp_attn_head(x, 8, sp_adj, Fnn.elu, 50, params=params)
+    assert out.shape == (1, 50, 8)
+    assert np.abs(out.cpu().numpy() - ref).max() < TOL
+    assert np.abs(out_sp.cpu().numpy() - ref).max() < TOL
+    ref_sp = ho.sp_attn_head(prob["x"], head, rp, ci)
+    assert np.abs(out_sp.cpu().numpy() - ref_sp).max() < TOL
+
+
+def test_errors_are_loud(dev):
+    from han_amd import ops
+    from han_amd.graph import CSRGraph
+    with pytest.raises(ValueError):
+        ops.sem_attn_fwd(torch.zeros(4, 2, 64), torch.zeros(64, 128), torch.zeros(128), torch.zeros(128))
+    with pytest.raises(ValueError):
+        ops.sem_attn_fwd(torch.zeros(4, 2, 64, device=dev, dtype=torch.float64),
+                         torch.zeros(64, 128, device=dev), torch.zeros(128, device=dev),
+                         torch.zeros(128, device=dev))
+    with pytest.raises(NotImplementedError):
+        ops._check_heads(4, 8)
+    with pytest.raises(ValueError):
+        CSRGraph.from_arrays([0, 2], [0, 5], 2, device=dev)     # colidx out of range
+
+
+# ------------------------------------------------------------------- training loop
+def test_three_training_steps_match_oracle(dev):
+    """fwd + bwd + L2 + TF-form Adam for 3 steps (dropout 0) == oracle loop
+    (ex_acm3025.py:171-218 semantics, models/base_gattn.py:12-24)."""
+    from han_amd.trainer import HANTrainer
+    prob = make_problem(11, 80, 16, 2, 3, [0.05, 0.4])
+    model, bp = build_model(prob, dev)
+    x, graphs = gpu_inputs(prob, dev)
+    tm = torch.tensor(prob["mask"].astype(np.uint8))
+    vm = torch.tensor((~prob["mask"]).astype(np.uint8))
+    tr = HANTrainer(model, [x] * 2, graphs, _t(prob["labels"], dev, torch.int32), tm, vm,
+                    lr=0.005, l2_coef=0.001, attn_drop=0.0, ffd_drop=0.0)
+    bpo = {k: v.clone() for k, v in bp.items()}
+    state = ht.new_adam_state(bpo)
+    xt = torch.tensor(prob["x"][0])
+    og = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]
+    onehot = torch.tensor(prob["onehot"])
+    for _ in range(3):
+        tl, ta, vl, va = tr.epoch()
+        _, vloss_ref, vacc_ref = ht.train_epoch([xt] * 2, og, bpo, state, onehot,
+                                                torch.tensor(prob["mask"]), torch.tensor(~prob["mask"]),
+                                                keep=1.0)
+        assert abs(float(vl) - vloss_ref) < 2e-4
+        assert abs(float(va) - vacc_ref) < 1e-5
+    for k in ht.PARAM_ORDER:
+        assert np.abs(getattr(model, k).detach().cpu().numpy() - bpo[k].numpy()).max() < 2e-4, k
+
+
+def test_training_with_dropout_reduces_loss(dev):
+    from han_amd.trainer import HANTrainer
+    from han_amd import synth
+    wl = synth.make_workload("tiny", device="cpu")
+    from han_amd.gat import HeteGAT_multi
+    model = HeteGAT_multi().build(wl["p"], wl["f"], wl["c"], device=dev)
+    x = wl["x"].to(dev)
+    # make labels learnable: class = argmax of three fixed feature columns
+    labels = x[:, :3].argmax(1).to(torch.int32)
+    graphs = [g.to(dev) for g in wl["graphs"]]
+    tr = HANTrainer(model, [x] * wl["p"], graphs, labels, wl["train_mask"] | 1, wl["val_mask"])
+    first = None
+    for ep in range(60):
+        tl, ta, vl, va = tr.epoch()
+        if first is None:
+            first = float(vl)
+    assert float(vl) < 0.8 * first
+    assert np.isfinite(float(tl))
