@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: full-graph HAN train epochs/s + node-attention (K2) bandwidth.
+
+    python bench.py --gpus N --steps K --warmup W [--workload syn-1m]
+
+One "step" is one reference epoch (ex_acm3025.py:171-218): one full-graph
+fwd+bwd+Adam step with dropout 0.6/0.6 plus one eval forward.  The workload is
+BASELINE.json's configs[3] (SYN-1M: 1M nodes, 4 meta-paths, deg 50, 256-d feats,
+8 heads x 8), synthetic data, random-init weights, node-partitioned over N GPUs
+(strong scaling: the graph is fixed, each rank owns N/G rows).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel -- the K2
+node-attention forward (eval instantiation) -- from ALGORITHMIC bytes
+(E*(4+256+4K) + N*(256+4K+8) per launch) over its mean launch
+duration measured with HIP events on the launch stream inside the timed region.
+`cpu_baseline` is the torch-CPU port of the reference algorithm
+(oracle/han_oracle_torch.py, CSR form) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def k2_algorithmic_bytes(n_rows, nnz, K=8, D=64, s=4, train=False):
+    per_edge = 4 + D * s + K * 4
+    per_row = D * s + K * 4 + 8
+    if train:                       # + pre, aggp rows and lse, tsum
+        per_row += 2 * D * s + 2 * K * 4
+    return nnz * per_edge + n_rows * per_row
+
+
+def cpu_baseline(workload_name, n_full, sample_n, seed=1234):
+    """The reference algorithm (CSR restatement, torch CPU fp32, all cores) on a
+    bounded sample: same degree / feature width / meta-path count, fewer nodes.
+    epochs/s is scaled by sample_n / n_full (every term of the algorithm is
+    linear in N at fixed degree)."""
+    from han_amd import synth
+    from oracle import han_oracle as ho
+    from oracle import han_oracle_torch as ht
+    import numpy as np
+    wl = synth.make_workload(workload_name, device="cpu", seed=seed, n_override=sample_n)
+    rng = np.random.default_rng(0)
+    params = ho.init_params(rng, wl["p"], wl["f"], wl["c"])
+    bp = ht.to_batched(params, dtype=torch.float32)
+    state = ht.new_adam_state(bp)
+    graphs = [(g.rowptr, g.colidx) for g in wl["graphs"]]
+    onehot = torch.nn.functional.one_hot(wl["labels"].long(), wl["c"]).float()
+    xs = [wl["x"]] * wl["p"]
+    g = torch.Generator().manual_seed(0)
+    masks = []
+    for (rp, ci) in graphs:      # dropout draws are part of the timed work, as in TF
+        masks.append(None)
+
+    def one_epoch():
+        mk = []
+        for (rp, ci) in graphs:
+            mk.append({"seq": (torch.rand((8, sample_n, wl["f"]), generator=g) < 0.4).float(),
+                       "coef": (torch.rand((ci.numel(), 8), generator=g) < 0.4).float(),
+                       "fts": (torch.rand((sample_n, 64), generator=g) < 0.4).float()})
+        ht.train_epoch(xs, graphs, bp, state, onehot, wl["train_mask"].bool(), wl["val_mask"].bool(),
+                       keep=0.4, masks=mk)
+
+    one_epoch()                  # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 2 or time.perf_counter() - t0 < 10.0:
+        one_epoch()
+        reps += 1
+        if time.perf_counter() - t0 > 30.0:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": (1.0 / dt) * sample_n / n_full, "unit": "epochs/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{workload_name} shape at N={sample_n} (deg/F/P unchanged), {reps} epochs of "
+                      f"{dt:.2f} s, scaled by {sample_n}/{n_full}; torch-CPU fp32 CSR restatement "
+                      f"of the reference (not TensorFlow)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="syn-1m")
+    ap.add_argument("--nodes", type=int, default=0, help="override N (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=5000)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from han_amd import ops, rng, synth
+    from han_amd.dist import NodePartition
+    from han_amd.gat import HeteGAT_multi
+    from han_amd.trainer import HANTrainer
+
+    rng.manual_seed(2024)
+    wl = synth.make_workload(args.workload, device=dev, n_override=args.nodes or None)
+    n, p = wl["n"], wl["p"]
+    part = NodePartition(n, rank, world) if world > 1 else None
+    gen = torch.Generator().manual_seed(0)
+    model = HeteGAT_multi().build(p, wl["f"], wl["c"], (8,), (8, 1), 128, device=dev, generator=gen)
+
+    def loc(t):
+        return part.local_rows(t).contiguous() if part is not None else t
+
+    x_local = loc(wl["x"])
+    trainer = HANTrainer(model, [x_local] * p, wl["graphs"], loc(wl["labels"]), loc(wl["train_mask"]),
+                         loc(wl["val_mask"]), lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
+                         part=part)
+    if part is not None:
+        wl["graphs"] = None          # the global graphs are no longer needed on this rank
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.epoch()
+    barrier()
+    ops.K2_TIMING = []
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = trainer.epoch()
+    barrier()
+    dt = time.perf_counter() - t0
+    timing, ops.K2_TIMING = ops.K2_TIMING, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tl, ta, vl, va = trainer.reduce_metrics(*last)
+
+    # --- roofline of the dominant kernel (K2 forward, eval instantiation) -------------
+    ms = {"eval": [], "train": []}
+    shape = {}
+    for tag, e0, e1, nr, nnz in timing:
+        ms[tag].append(e0.elapsed_time(e1))
+        shape[tag] = (nr, nnz)
+    roof = None
+    extra = {}
+    if ms["eval"]:
+        nr, nnz = shape["eval"]
+        avg_ms = sum(ms["eval"]) / len(ms["eval"])
+        alg = k2_algorithmic_bytes(nr, nnz)
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "k2_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload and tj.get("n_gpus", 1) == world:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": "node_attn_fwd_kernel<FP=8,TRAIN=0> (K2 forward)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg_ms, 4),
+                "launches_timed": len(ms["eval"])}
+        if ms["train"]:
+            nr, nnz = shape["train"]
+            tavg = sum(ms["train"]) / len(ms["train"])
+            talg = k2_algorithmic_bytes(nr, nnz, train=True)
+            extra["k2_train_fwd"] = {"avg_launch_ms": round(tavg, 4),
+                                     "achieved_GBs": round(talg / (tavg * 1e-3) / 1e9, 1)}
+
+    if rank == 0:
+        out = {
+            "metric": "full-graph train epochs/sec (1 epoch = fwd+bwd+Adam step + eval forward), "
+                      "8-head HAN; node-attn HBM GB/s in roofline",
+            "value": round(args.steps / dt, 4), "unit": "epochs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: N={n} nodes, P={p} meta-paths, "
+                                   f"E={sum(g.nnz for g in trainer.graphs) if world == 1 else 'sharded'} "
+                                   f"edges, F={wl['f']}, K=8 heads x F'=8, A=128, C={wl['c']}",
+                       "parallelism": f"node-partition x{world}" if world > 1 else "single GPU",
+                       "dropout": "0.6/0.6 (train step)", "optimizer": "TF-form Adam lr 0.005, L2 0.001"},
+            "final": {"train_loss": round(tl, 5), "train_acc": round(ta, 5),
+                      "val_loss": round(vl, 5), "val_acc": round(va, 5)},
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, n, min(args.cpu_sample, n))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

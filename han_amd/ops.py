@@ -18,6 +18,10 @@ D = 64                     # K * F' of this build
 
 _workspaces: dict = {}
 
+# Optional timing hook (bench.py): a list to which node_attn_fwd appends
+# (tag, start_event, end_event, N, E) recorded on the launch stream.
+K2_TIMING: list | None = None
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -151,11 +155,18 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, f2_tab, c, out=None, train=False, 
         tsum = torch.empty((N, K), dtype=torch.float32, device=dev)
         saved = (pre, lse, aggp, tsum)
         ptrs = [pre.data_ptr(), lse.data_ptr(), aggp.data_ptr(), tsum.data_ptr()]
+    timing = K2_TIMING
+    if timing is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _lib.check(lib.han_node_attn_fwd(
         graph.rowptr.data_ptr(), graph.colidx.data_ptr(), H_tab.data_ptr(), f1.data_ptr(),
         f2_tab.data_ptr(), c.data_ptr(), out.data_ptr(), out.stride(0) if N > 1 else D,
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop,
         int(seed), int(row_offset), int(activation), _stream()), "han_node_attn_fwd")
+    if timing is not None:
+        ev1.record()
+        timing.append(("train" if train else "eval", ev0, ev1, N, graph.nnz))
     return out, saved
 
 

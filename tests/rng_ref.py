@@ -16,10 +16,10 @@ def han_hash(seed, stream, a, b):
     lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
     a, b = _u32(a), _u32(b)
     h = _u32(a * np.uint64(0x9E3779B1)) ^ _u32(lo + np.uint64(stream) * np.uint64(0x7F4A7C15))
-    h ^= h >> np.uint64(16); h = _u32(h * np.uint64(0x85EBCA6B)); h ^= h >> np.uint64(13)
-    h ^= _u32(_u32(b * np.uint64(0xC2B2AE35)) + hi)
-    h ^= h >> np.uint64(16); h = _u32(h * np.uint64(0x85EBCA6B)); h ^= h >> np.uint64(13)
-    h = _u32(h * np.uint64(0xC2B2AE35)); h ^= h >> np.uint64(16)
+    h = h ^ (h >> np.uint64(16)); h = _u32(h * np.uint64(0x85EBCA6B)); h = h ^ (h >> np.uint64(13))
+    h = h ^ _u32(_u32(b * np.uint64(0xC2B2AE35)) + hi)
+    h = h ^ (h >> np.uint64(16)); h = _u32(h * np.uint64(0x85EBCA6B)); h = h ^ (h >> np.uint64(13))
+    h = _u32(h * np.uint64(0xC2B2AE35)); h = h ^ (h >> np.uint64(16))
     return h
 
 
