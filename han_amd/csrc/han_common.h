@@ -58,6 +58,59 @@ __device__ __forceinline__ float han_wave_sum(float v) {
     return v;
 }
 
+// ---------------------------------------------------------------------------
+// Deterministic second stage of every cross-block reduction:
+//   out[n] = scale * sum_b slab[b*row_stride + n],  n in [0, width)
+// routed to up to 4 output segments (segment i covers [seg_end[i-1], seg_end[i]))
+// and replicated `rep` times at stride rep_stride (classifier heads).  A block
+// owns 16 consecutive n; its 16 slices of blocks are summed in a fixed order.
+// ---------------------------------------------------------------------------
+struct HanReduceOut {
+    float *ptr[4];
+    int seg_end[4];
+    int nseg;
+    float scale;
+    int rep;
+    int64_t rep_stride;
+};
+
+static __global__ __launch_bounds__(256) void han_reduce_slabs_kernel(const float *slab, int nblocks,
+                                                                     int64_t row_stride, int width,
+                                                                     HanReduceOut o) {
+    __shared__ float part[16][17];
+    const int nn = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + nn;
+    float s = 0.f;
+    if (n < width)
+        for (int b = sl; b < nblocks; b += 16) s += slab[(int64_t)b * row_stride + n];
+    part[sl][nn] = s;
+    __syncthreads();
+    if (sl == 0 && n < width) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += part[r][nn];
+        t *= o.scale;
+        int seg = 0, base = 0;
+        while (seg < o.nseg - 1 && n >= o.seg_end[seg]) { base = o.seg_end[seg]; ++seg; }
+        for (int r = 0; r < o.rep; ++r) o.ptr[seg][(int64_t)r * o.rep_stride + (n - base)] = t;
+    }
+}
+
+// slab rows are `row_stride` floats apart; columns [0, width) of each row are reduced
+static inline hipError_t han_reduce_slabs(const float *slab, int nblocks, int64_t row_stride, int width,
+                                          const HanReduceOut &o, hipStream_t st) {
+    han_reduce_slabs_kernel<<<(width + 15) / 16, 256, 0, st>>>(slab, nblocks, row_stride, width, o);
+    return hipGetLastError();
+}
+
+static inline HanReduceOut han_reduce_to(float *out, int width) {
+    HanReduceOut o;
+    o.ptr[0] = out; o.ptr[1] = o.ptr[2] = o.ptr[3] = nullptr;
+    o.seg_end[0] = width; o.seg_end[1] = o.seg_end[2] = o.seg_end[3] = width;
+    o.nseg = 1; o.scale = 1.f; o.rep = 1; o.rep_stride = 0;
+    return o;
+}
+
 static inline int han_grid_for(int64_t items, int per_block, int cap) {
     int64_t b = (items + per_block - 1) / per_block;
     if (b < 1) b = 1;

@@ -149,25 +149,6 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
     }
 }
 
-__global__ void classifier_finish_kernel(const float *slab, int nblocks, int C, int HC, float *loss_acc,
-                                         float *dWc, float *dbc) {
-    const int width = 64 * C + C + 2;
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= width) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += slab[(int64_t)b * width + n];
-    const float invh = 1.f / (float)HC;
-    if (n < 64 * C) {
-        if (dWc)
-            for (int h = 0; h < HC; ++h) dWc[(int64_t)h * 64 * C + n] = s * invh;
-    } else if (n < 64 * C + C) {
-        if (dbc)
-            for (int h = 0; h < HC; ++h) dbc[h * C + (n - 64 * C)] = s * invh;
-    } else {
-        loss_acc[n - 64 * C - C] = s;
-    }
-}
-
 __global__ void adam_kernel(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1,
                             float b2, float eps, float l2) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -256,10 +237,21 @@ extern "C" int han_classifier_loss(const float *Z, const float *Wc, const float 
     else classifier_kernel<false><<<grid, 256, 0, st>>>(a);
     HAN_CHECK_LAUNCH();
     const int width = 64 * C + C + 2;
-    classifier_finish_kernel<<<(width + 255) / 256, 256, 0, st>>>((const float *)workspace, grid, C, HC,
-                                                                  loss_acc, bwd ? dWc : nullptr,
-                                                                  bwd ? dbc : nullptr);
-    HAN_CHECK_LAUNCH();
+    // loss / accuracy (the last two slab columns), then the head gradients: every
+    // head receives the same (1/HC)-scaled gradient (models/gat.py:72 averages them)
+    const float *slab = (const float *)workspace;
+    hipError_t e = han_reduce_slabs(slab + 64 * C + C, grid, width, 2, han_reduce_to(loss_acc, 2), st);
+    if (e != hipSuccess) return (int)e;
+    if (bwd) {
+        HanReduceOut ow = han_reduce_to(dWc, 64 * C);
+        ow.scale = 1.f / (float)HC; ow.rep = HC; ow.rep_stride = (int64_t)64 * C;
+        e = han_reduce_slabs(slab, grid, width, 64 * C, ow, st);
+        if (e != hipSuccess) return (int)e;
+        HanReduceOut ob = han_reduce_to(dbc, C);
+        ob.scale = 1.f / (float)HC; ob.rep = HC; ob.rep_stride = C;
+        e = han_reduce_slabs(slab + 64 * C, grid, width, C, ob, st);
+        if (e != hipSuccess) return (int)e;
+    }
     return 0;
 }
 

@@ -312,15 +312,6 @@ __global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsAr
     }
 }
 
-// out[n] = sum_b slab[b][n]   (deterministic second stage of every reduction)
-__global__ void reduce_slabs_kernel(const float *slab, int nblocks, int width, float *out) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= width) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += slab[(int64_t)b * width + n];
-    out[n] = s;
-}
-
 // ---------------------------------------------------------------------------
 // backward step 2: gather over the transposed graph (one wave per source row)
 // ---------------------------------------------------------------------------
@@ -481,20 +472,8 @@ __global__ __launch_bounds__(256) void score_param_bwd_kernel(const float *H, co
         float sacc = 0.f;
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) sacc += red[rr][threadIdx.x];
-        slab[(int64_t)blockIdx.x * HAN_SP_WIDTH + threadIdx.x] = sacc;
+        slab[(int64_t)blockIdx.x * (128 + 2 * K) + threadIdx.x] = sacc;
     }
-}
-
-__global__ void score_param_finish_kernel(const float *slab, int nblocks, int K, float *da1, float *da2,
-                                          float *db1, float *db2) {
-    const int n = threadIdx.x;
-    if (n >= 128 + 2 * K) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += slab[(int64_t)b * HAN_SP_WIDTH + n];
-    if (n < 64) da1[n] = s;
-    else if (n < 128) da2[n - 64] = s;
-    else if (n < 128 + K) db1[n - 128] = s;
-    else db2[n - 128 - K] = s;
 }
 
 constexpr int kReduceBlocks = 1024;
@@ -582,8 +561,8 @@ extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, co
     const int grid = han_grid_for(N, 16, kReduceBlocks);
     HAN_DISPATCH_FP(FP, { node_attn_bwd_rows_kernel<FPC><<<grid, 256, 0, st>>>(a); })
     HAN_CHECK_LAUNCH();
-    reduce_slabs_kernel<<<1, 64, 0, st>>>((const float *)workspace, grid, 64, dc);
-    HAN_CHECK_LAUNCH();
+    hipError_t e = han_reduce_slabs((const float *)workspace, grid, 64, 64, han_reduce_to(dc, 64), st);
+    if (e != hipSuccess) return (int)e;
     return 0;
 }
 
@@ -634,7 +613,11 @@ extern "C" int han_score_param_bwd(const float *H, const float *df1, const float
         score_param_bwd_kernel<FPC><<<grid, 256, 0, st>>>(H, df1, df2, (float *)workspace, N);
     })
     HAN_CHECK_LAUNCH();
-    score_param_finish_kernel<<<1, 256, 0, st>>>((const float *)workspace, grid, K, da1, da2, db1, db2);
-    HAN_CHECK_LAUNCH();
+    HanReduceOut o = han_reduce_to(da1, HAN_SP_WIDTH);
+    o.ptr[1] = da2; o.ptr[2] = db1; o.ptr[3] = db2;
+    o.seg_end[0] = 64; o.seg_end[1] = 128; o.seg_end[2] = 128 + K; o.seg_end[3] = 128 + 2 * K;
+    o.nseg = 4;
+    hipError_t e = han_reduce_slabs((const float *)workspace, grid, 128 + 2 * K, 128 + 2 * K, o, st);
+    if (e != hipSuccess) return (int)e;
     return 0;
 }

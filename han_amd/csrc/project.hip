@@ -260,21 +260,13 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const ProjBwdArgs a) {
     }
 }
 
-__global__ void project_bwd_reduce_kernel(const float *slab, int64_t nchunks, int64_t width, float *dW) {
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= width) return;
-    float s = 0.f;
-    for (int64_t ch = 0; ch < nchunks; ++ch) s += slab[ch * width + n];
-    dW[n] = s;
-}
-
 bool fp_ok(int K, int FP) {
     return K * FP == HAN_D && (FP == 4 || FP == 8 || FP == 16 || FP == 32 || FP == 64);
 }
 
 void bwd_geometry(int64_t N, int F, int *ftiles, int64_t *rows_per_chunk, int64_t *nchunks) {
     *ftiles = (F + BF - 1) / BF;
-    int64_t target = 2048 / *ftiles;
+    int64_t target = 1024 / *ftiles;
     if (target < 1) target = 1;
     int64_t rpc = (N + target - 1) / target;
     rpc = ((rpc + BN - 1) / BN) * BN;
@@ -360,9 +352,8 @@ extern "C" int han_project_bwd(const float *X, int64_t ldx, const float *dH, flo
         else project_bwd_kernel<FPC, false><<<grid, 256, 0, st>>>(a);
     })
     HAN_CHECK_LAUNCH();
-    const int64_t width = (int64_t)F * HAN_D;
-    project_bwd_reduce_kernel<<<(unsigned)((width + 255) / 256), 256, 0, st>>>((const float *)workspace, nch,
-                                                                               width, dW);
-    HAN_CHECK_LAUNCH();
+    const int width = F * HAN_D;
+    hipError_t e = han_reduce_slabs((const float *)workspace, (int)nch, width, width, han_reduce_to(dW, width), st);
+    if (e != hipSuccess) return (int)e;
     return 0;
 }

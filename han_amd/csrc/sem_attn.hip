@@ -4,19 +4,35 @@
 //   v = tanh(M @ Womega + bomega)   (N,P,A)      s = v . uomega   (N,P)
 //   beta = softmax over P, PER NODE (the code, not the paper's node average)
 //   Z = sum_p beta_p M_p            (N,D)
-// v (2 GB at N = 1M, P = 4) is never written: one wave owns one node, holds the
-// node's P rows in registers one at a time (lane l = feature l, 256-B coalesced
-// loads), keeps Womega in LDS and runs the D x A contraction on the VALU with
-// v_readlane broadcasts of the row, then an online softmax over P.
-// Roofline: the M / Z streams are HBM-bound (N*(P+1)*256 B); the contraction is
-// 2*N*P*D*A flop of fp32 (65.5 GF at N = 1M, P = 4) -- VALU-bound in this version.
+// M is (N,P,64) contiguous = R = N*P rows of 256 B.  v (2 GB at N = 1M, P = 4)
+// is never written.  The D x A contraction runs on exact-fp32 MFMA
+// (v_mfma_f32_16x16x4_f32, no xf32 on gfx950); everything around it (tanh, the
+// score dot, the per-node softmax, the weighted sum) is fused in the same kernel.
+//
+// Forward, per block iteration: a chunk of NB = 64/P whole nodes (<= 64 rows);
+// wave w owns rows 16w..16w+15: pre = M_tile(16x64) . Womega(64xA) with the M
+// fragments loaded straight from global/L1 and Womega fragments from LDS; the
+// scores go to LDS; then each wave finishes whole nodes (lane = feature: softmax
+// over P scores, Z = sum beta_p M_p with 256-B coalesced row loads).
+//
+// Backward, per 16-row tile and wave, three MFMA products of 128 MFMAs each:
+//   G1  pre   = M_tile . Womega                       (recompute; rows r x cols a)
+//   G3  dW   += M_tile^T . dpre      reduction over r = the ROW index of G1's
+//                                    accumulator, so dpre is fed as the B operand
+//                                    straight from the accumulator registers
+//   G2  dMx   = dpre . Womega^T      reduction over a -> dpre goes through a
+//                                    wave-private LDS tile to become the A operand
+// with dpre = ds_r * u * (1 - v^2), ds_p = beta_p (dbeta_p - sum_q beta_q dbeta_q),
+// dbeta_p = dZ . M_p.  dW/db/du are summed in registers over the wave's tiles,
+// across waves through LDS, across blocks through a slab + reduce kernel.
+//
+// Roofline: MFMA fp32 (155 TF): forward 2*R*64*A flop = 65.5 GF at N = 1M, P = 4
+// (0.42 ms at peak), backward 3x that; the M / Z / dM streams are 1-2 GB (HBM, ~0.3 ms).
 #include "han_common.h"
 
 namespace {
 
-__device__ __forceinline__ float bcast_lane(float v, int src) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float fast_tanh(float x) {
     // 1 - 2/(1+e^{2x}); absolute error ~1e-7, saturates cleanly at +-1
@@ -24,154 +40,250 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - __fdividef(2.f, 1.f + e);
 }
 
-template <int CA>
-__device__ __forceinline__ void row_matvec(const float *Wl, float mval, int lane, const float (&b)[CA],
-                                           float (&pre)[CA]) {
-    constexpr int A = 64 * CA;
-#pragma unroll
-    for (int ca = 0; ca < CA; ++ca) pre[ca] = b[ca];
-#pragma unroll
-    for (int k = 0; k < 64; ++k) {
-        const float mk = bcast_lane(mval, k);
-        const float *wrow = Wl + k * A + lane * CA;
-#pragma unroll
-        for (int ca = 0; ca < CA; ++ca) pre[ca] += mk * wrow[ca];
-    }
-}
+constexpr int ROWS = 64;   // rows per block iteration (4 waves x 16)
 
 template <int CA>
-__global__ __launch_bounds__(256) void sem_attn_fwd_kernel(const float *M, const float *Wg, const float *bw,
-                                                           const float *uw, float *Z, float *beta, int64_t N,
-                                                           int P) {
+__global__ __launch_bounds__(256) void sem_attn_fwd_kernel(const float *__restrict__ M, const float *Wg,
+                                                           const float *bw, const float *uw, float *Z,
+                                                           float *beta, int64_t N, int P) {
     constexpr int A = 64 * CA;
+    constexpr int TA = A / 16;
+    constexpr int WLD = A + 16;   // (WLD mod 32) == 16: rows k and k+1 hit disjoint bank halves
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Wl = smem;   // [64][A]
-    for (int i = threadIdx.x; i < 64 * A; i += 256) Wl[i] = Wg[i];
+    float *Wl = smem;                 // [64][WLD]
+    float *sc = smem + 64 * WLD;      // [2][ROWS]
+    for (int i = threadIdx.x; i < 64 * A; i += 256) Wl[(i / A) * WLD + (i % A)] = Wg[i];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    float bcol[TA], ucol[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        bcol[t] = bw[16 * t + l15];
+        ucol[t] = uw[16 * t + l15];
+    }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    float b[CA], u[CA];
+    const int NB = ROWS / P;
+    const int64_t nchunks = (N + NB - 1) / NB;
+    int buf = 0;
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x, buf ^= 1) {
+        const int64_t node0 = ch * NB;
+        const int nodes = (int)((N - node0) < NB ? (N - node0) : NB);
+        const int rows = nodes * P;
+        const int64_t row0 = node0 * P;
+        // ---- scores of this wave's 16 rows
+        {
+            const int lr = 16 * w + l15;
+            const float *mrow = M + (row0 + (lr < rows ? lr : rows - 1)) * 64 + l4;
+            f32x4 acc[TA];
 #pragma unroll
-    for (int ca = 0; ca < CA; ++ca) {
-        b[ca] = bw[lane * CA + ca];
-        u[ca] = uw[lane * CA + ca];
-    }
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t n = wave0; n < N; n += nwaves) {
-        float zacc = 0.f, mrun = HAN_NEG_BIG, lrun = 0.f, sreg = 0.f;
-        for (int p = 0; p < P; ++p) {
-            const float mval = M[(n * P + p) * 64 + lane];
-            float pre[CA];
-            row_matvec<CA>(Wl, mval, lane, b, pre);
-            float part = 0.f;
+            for (int t = 0; t < TA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ca = 0; ca < CA; ++ca) part += fast_tanh(pre[ca]) * u[ca];
-            const float s = han_wave_sum(part);
-            if (lane == p) sreg = s;
-            const float mn = fmaxf(mrun, s);
-            const float sc = __expf(mrun - mn), pe = __expf(s - mn);
-            lrun = lrun * sc + pe;
-            zacc = zacc * sc + pe * mval;
-            mrun = mn;
+            for (int ks = 0; ks < 16; ++ks) {
+                const float a = mrow[4 * ks];
+                const float *wr = Wl + (4 * ks + l4) * WLD + l15;
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wr[16 * t], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < TA; ++t) s += fast_tanh(acc[t][reg] + bcol[t]) * ucol[t];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+                if (l15 == 0) sc[buf * ROWS + 16 * w + 4 * l4 + reg] = s;
+            }
         }
-        const float inv = 1.f / lrun;
-        Z[n * 64 + lane] = zacc * inv;
-        if (lane < P) beta[n * P + lane] = __expf(sreg - mrun) * inv;
+        __syncthreads();
+        // ---- whole nodes: softmax over P, weighted sum (lane = feature)
+        for (int nd = w; nd < nodes; nd += 4) {
+            const int64_t n = node0 + nd;
+            float zacc = 0.f, mrun = HAN_NEG_BIG, lrun = 0.f, sreg = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const float s = sc[buf * ROWS + nd * P + p];
+                const float mval = M[(n * P + p) * 64 + lane];
+                if (lane == p) sreg = s;
+                const float mn = fmaxf(mrun, s);
+                const float scl = __expf(mrun - mn), pe = __expf(s - mn);
+                lrun = lrun * scl + pe;
+                zacc = zacc * scl + pe * mval;
+                mrun = mn;
+            }
+            const float inv = 1.f / lrun;
+            Z[n * 64 + lane] = zacc * inv;
+            if (lane < P) beta[n * P + lane] = __expf(sreg - mrun) * inv;
+        }
+        // no second barrier: the next iteration writes the other score buffer, and
+        // the barrier inside it orders this iteration's reads before the reuse after.
     }
 }
 
-// slab row per block: [64*A] dW, [A] db, [A] du
+// slab row per block: [64*A] dW | [A] db | [A] du
 template <int CA>
-__global__ __launch_bounds__(256) void sem_attn_bwd_kernel(const float *M, const float *Wg, const float *bw,
-                                                           const float *uw, const float *beta,
-                                                           const float *dZ, float *dM, float *slab,
-                                                           int64_t N, int P) {
+__global__ __launch_bounds__(256) void sem_attn_bwd_kernel(const float *__restrict__ M, const float *Wg,
+                                                           const float *bw, const float *uw,
+                                                           const float *beta, const float *dZ, float *dM,
+                                                           float *slab, int64_t N, int P) {
     constexpr int A = 64 * CA;
+    constexpr int TA = A / 16;
+    constexpr int WLD1 = A + 16;   // G1 B-operand reads: lanes step a, lane groups step f
+    constexpr int WLD2 = A + 2;    // G2 reads: lanes step f / r, lane groups step a
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Wl = smem;            // [64][A]
-    float *WT = smem + 64 * A;   // [A][64]
+    float *W1 = smem;                         // [64][WLD1]
+    float *W2 = W1 + 64 * WLD1;               // [64][WLD2]
+    float *dp = W2 + 64 * WLD2;               // [4 waves][16][WLD2]
+    float *dsb = dp + 4 * 16 * WLD2;          // [2][ROWS]  d s_r
+    float *btb = dsb + 2 * ROWS;              // [2][ROWS]  beta_r
     for (int i = threadIdx.x; i < 64 * A; i += 256) {
-        const float w = Wg[i];
-        Wl[i] = w;
-        WT[(i % A) * 64 + (i / A)] = w;
+        const float v = Wg[i];
+        W1[(i / A) * WLD1 + (i % A)] = v;
+        W2[(i / A) * WLD2 + (i % A)] = v;
     }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    float bcol[TA], ucol[TA], du[TA], db[TA];
+    f32x4 dW[4][TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        bcol[t] = bw[16 * t + l15];
+        ucol[t] = uw[16 * t + l15];
+        du[t] = 0.f;
+        db[t] = 0.f;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) dW[ft][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float *mydp = dp + w * 16 * WLD2;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float b[CA], u[CA], du[CA], db[CA];
-    float dWacc[64][CA];
-#pragma unroll
-    for (int ca = 0; ca < CA; ++ca) {
-        b[ca] = bw[lane * CA + ca];
-        u[ca] = uw[lane * CA + ca];
-        du[ca] = 0.f;
-        db[ca] = 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < 64; ++k)
-#pragma unroll
-        for (int ca = 0; ca < CA; ++ca) dWacc[k][ca] = 0.f;
-
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t n = wave0; n < N; n += nwaves) {
-        const float dz = dZ[n * 64 + lane];
-        const float breg = lane < P ? beta[n * P + lane] : 0.f;
-        float dbreg = 0.f;
-        for (int p = 0; p < P; ++p) {
-            const float mval = M[(n * P + p) * 64 + lane];
-            const float d = han_wave_sum(dz * mval);   // d beta_p = dZ . M_p
-            if (lane == p) dbreg = d;
+    const int NB = ROWS / P;
+    const int64_t nchunks = (N + NB - 1) / NB;
+    int buf = 0;
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x, buf ^= 1) {
+        const int64_t node0 = ch * NB;
+        const int nodes = (int)((N - node0) < NB ? (N - node0) : NB);
+        const int rows = nodes * P;
+        const int64_t row0 = node0 * P;
+        float *dsr = dsb + buf * ROWS, *btr = btb + buf * ROWS;
+        // ---- P0: d beta, d s per node (lane = feature)
+        if (threadIdx.x < ROWS && threadIdx.x >= rows) {
+            dsr[threadIdx.x] = 0.f;
+            btr[threadIdx.x] = 0.f;
         }
-        const float S = han_wave_sum(breg * dbreg);
-        const float dsreg = breg * (dbreg - S);        // d s_p on lane p
-        for (int p = 0; p < P; ++p) {
-            const float mval = M[(n * P + p) * 64 + lane];
-            float pre[CA], dpre[CA];
-            row_matvec<CA>(Wl, mval, lane, b, pre);
-            const float ds = __shfl(dsreg, p, 64);
-            const float bp = __shfl(breg, p, 64);
-#pragma unroll
-            for (int ca = 0; ca < CA; ++ca) {
-                const float v = fast_tanh(pre[ca]);
-                dpre[ca] = ds * u[ca] * (1.f - v * v);
-                du[ca] += ds * v;
-                db[ca] += dpre[ca];
+        for (int nd = w; nd < nodes; nd += 4) {
+            const int64_t n = node0 + nd;
+            const float dz = dZ[n * 64 + lane];
+            const float breg = lane < P ? beta[n * P + lane] : 0.f;
+            float dbreg = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const float d = han_wave_sum(dz * M[(n * P + p) * 64 + lane]);
+                if (lane == p) dbreg = d;
             }
-#pragma unroll
-            for (int k = 0; k < 64; ++k) {
-                const float mk = bcast_lane(mval, k);
-#pragma unroll
-                for (int ca = 0; ca < CA; ++ca) dWacc[k][ca] += mk * dpre[ca];
+            const float S = han_wave_sum(breg * dbreg);
+            if (lane < P) {
+                dsr[nd * P + lane] = breg * (dbreg - S);
+                btr[nd * P + lane] = breg;
             }
-            float dm = bp * dz;
+        }
+        __syncthreads();
+        // ---- G1: pre = M_tile . Womega
+        f32x4 acc[TA];
 #pragma unroll
-            for (int src = 0; src < 64; ++src) {
+        for (int t = 0; t < TA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            const int lr = 16 * w + l15;
+            const float *mrow = M + (row0 + (lr < rows ? lr : rows - 1)) * 64 + l4;
 #pragma unroll
-                for (int ca = 0; ca < CA; ++ca) {
-                    const float dp = bcast_lane(dpre[ca], src);
-                    dm += WT[(src * CA + ca) * 64 + lane] * dp;
+            for (int ks = 0; ks < 16; ++ks) {
+                const float a = mrow[4 * ks];
+                const float *wr = W1 + (4 * ks + l4) * WLD1 + l15;
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wr[16 * t], acc[t], 0, 0, 0);
+            }
+        }
+        // ---- dpre in the accumulator layout (row r = 4*l4 + reg, col a = 16t + l15)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float ds = dsr[16 * w + 4 * l4 + reg];
+#pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                const float v = fast_tanh(acc[t][reg] + bcol[t]);
+                const float d = ds * ucol[t] * (1.f - v * v);
+                du[t] += ds * v;
+                db[t] += d;
+                acc[t][reg] = d;
+                mydp[(4 * l4 + reg) * WLD2 + 16 * t + l15] = d;
+            }
+        }
+        // ---- G3: dW += M_tile^T . dpre   (k-step `reg` holds rows 4g + reg, g = lane group)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int lr = 16 * w + 4 * l4 + reg;
+            const float *mrow = M + (row0 + (lr < rows ? lr : rows - 1)) * 64 + l15;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const float a = mrow[16 * ft];
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+                    dW[ft][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, acc[t][reg], dW[ft][t], 0, 0, 0);
+            }
+        }
+        // ---- G2: dMx = dpre . Womega^T   (A operand from the wave's LDS tile)
+        f32x4 acc2[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) acc2[ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int ks = 0; ks < A / 4; ++ks) {
+            const float a = mydp[l15 * WLD2 + 4 * ks + l4];
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const float b = W2[(16 * ft + l15) * WLD2 + 4 * ks + l4];
+                acc2[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc2[ft], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int lr = 16 * w + 4 * l4 + reg;
+            if (lr < rows) {
+                const int64_t n = node0 + lr / P;
+                const float bt = btr[lr];
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) {
+                    const int f = 16 * ft + l15;
+                    dM[(row0 + lr) * 64 + f] = acc2[ft][reg] + bt * dZ[n * 64 + f];
                 }
             }
-            dM[(n * P + p) * 64 + lane] = dm;
         }
     }
-    // block reduction of the parameter gradients through LDS, then one slab row
+    // ---- parameter gradients: lane groups -> waves (LDS) -> slab row
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            du[t] += __shfl_xor(du[t], o, 64);
+            db[t] += __shfl_xor(db[t], o, 64);
+        }
+    }
     __syncthreads();
-    float *red = smem;   // reuse: [64*A] dW | [A] db | [A] du   (fits: 2*64*A floats available)
-    for (int w = 0; w < 4; ++w) {
-        if (wv == w) {
+    float *red = smem;   // [64*A] dW | [A] db | [A] du  (fits inside W1 + W2)
+    for (int ww = 0; ww < 4; ++ww) {
+        if (w == ww) {
 #pragma unroll
-            for (int k = 0; k < 64; ++k)
+            for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-                for (int ca = 0; ca < CA; ++ca) {
-                    const int idx = k * A + lane * CA + ca;
-                    red[idx] = (w == 0 ? 0.f : red[idx]) + dWacc[k][ca];
+                for (int t = 0; t < TA; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int idx = (16 * ft + 4 * l4 + reg) * A + 16 * t + l15;
+                        red[idx] = (ww == 0 ? 0.f : red[idx]) + dW[ft][t][reg];
+                    }
+            if (l4 == 0) {
+#pragma unroll
+                for (int t = 0; t < TA; ++t) {
+                    const int idx = 64 * A + 16 * t + l15;
+                    red[idx] = (ww == 0 ? 0.f : red[idx]) + db[t];
+                    red[idx + A] = (ww == 0 ? 0.f : red[idx + A]) + du[t];
                 }
-#pragma unroll
-            for (int ca = 0; ca < CA; ++ca) {
-                const int idx = 64 * A + lane * CA + ca;
-                red[idx] = (w == 0 ? 0.f : red[idx]) + db[ca];
-                red[idx + A] = (w == 0 ? 0.f : red[idx + A]) + du[ca];
             }
         }
         __syncthreads();
@@ -180,20 +292,46 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_kernel(const float *M, const
     for (int i = threadIdx.x; i < 64 * A + 2 * A; i += 256) out[i] = red[i];
 }
 
-__global__ void sem_reduce_kernel(const float *slab, int nblocks, int width, int A, float *dW, float *db,
-                                  float *du) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= width) return;
-    float s = 0.f;
-    for (int bk = 0; bk < nblocks; ++bk) s += slab[(int64_t)bk * width + n];
-    if (n < 64 * A) dW[n] = s;
-    else if (n < 64 * A + A) db[n - 64 * A] = s;
-    else du[n - 64 * A - A] = s;
+constexpr int kSemBwdBlocks = 256;   // one 4-wave block per CU (104 KB of LDS at A = 128)
+
+template <int CA>
+size_t fwd_lds() { return (size_t)(64 * (64 * CA + 16) + 2 * ROWS) * sizeof(float); }
+template <int CA>
+size_t bwd_lds() {
+    constexpr int A = 64 * CA;
+    return (size_t)(64 * (A + 16) + 64 * (A + 2) + 4 * 16 * (A + 2) + 4 * ROWS) * sizeof(float);
 }
 
-constexpr int kSemBwdBlocks = 512;
+template <int CA>
+int launch_fwd(const float *M, const float *w, const float *b, const float *u, float *Z, float *beta,
+               int64_t N, int P, hipStream_t st) {
+    const size_t lds = fwd_lds<CA>();
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)sem_attn_fwd_kernel<CA>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int NB = ROWS / P;
+    const int grid = han_grid_for(N, NB, 256 * 3);
+    sem_attn_fwd_kernel<CA><<<grid, 256, lds, st>>>(M, w, b, u, Z, beta, N, P);
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
 
-int sem_grid(int64_t N, int cap) { return han_grid_for(N, 4, cap); }
+template <int CA>
+int launch_bwd(const float *M, const float *w, const float *b, const float *u, const float *beta,
+               const float *dZ, float *dM, float *slab, int64_t N, int P, int *grid_out, hipStream_t st) {
+    const size_t lds = bwd_lds<CA>();
+    hipError_t e = hipFuncSetAttribute((const void *)sem_attn_bwd_kernel<CA>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    const int NB = ROWS / P;
+    const int grid = han_grid_for(N > 0 ? N : 1, NB, kSemBwdBlocks);
+    *grid_out = grid;
+    sem_attn_bwd_kernel<CA><<<grid, 256, lds, st>>>(M, w, b, u, beta, dZ, dM, slab, N, P);
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
 
 }  // namespace
 
@@ -201,24 +339,11 @@ extern "C" int han_sem_attn_fwd(const float *M, const float *w_omega, const floa
                                 const float *u_omega, float *Z, float *beta, int64_t N, int P, int D, int A,
                                 void *stream) {
     if (!M || !w_omega || !b_omega || !u_omega || !Z || !beta || N < 0 || P <= 0) return HAN_E_BADARG;
-    if (D != HAN_D || P > 64 || (A != 64 && A != 128 && A != 256)) return HAN_E_UNSUPPORTED;
+    if (D != HAN_D || P > 64 || (A != 64 && A != 128)) return HAN_E_UNSUPPORTED;
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = sem_grid(N, 256 * 4);
-    const size_t lds = (size_t)64 * A * sizeof(float);
-    hipError_t e = hipSuccess;
-    if (A == 64) {
-        sem_attn_fwd_kernel<1><<<grid, 256, lds, st>>>(M, w_omega, b_omega, u_omega, Z, beta, N, P);
-    } else if (A == 128) {
-        sem_attn_fwd_kernel<2><<<grid, 256, lds, st>>>(M, w_omega, b_omega, u_omega, Z, beta, N, P);
-    } else {
-        e = hipFuncSetAttribute((const void *)sem_attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
-        if (e != hipSuccess) return (int)e;
-        sem_attn_fwd_kernel<4><<<grid, 256, lds, st>>>(M, w_omega, b_omega, u_omega, Z, beta, N, P);
-    }
-    HAN_CHECK_LAUNCH();
-    return 0;
+    if (A == 64) return launch_fwd<1>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
+    return launch_fwd<2>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
 }
 
 extern "C" size_t han_sem_attn_bwd_workspace(int64_t N, int P, int D, int A) {
@@ -236,20 +361,18 @@ extern "C" int han_sem_attn_bwd(const float *M, const float *w_omega, const floa
     if (D != HAN_D || P > 64 || (A != 64 && A != 128)) return HAN_E_UNSUPPORTED;
     if (workspace_bytes < han_sem_attn_bwd_workspace(N, P, D, A)) return HAN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = sem_grid(N > 0 ? N : 1, kSemBwdBlocks);
-    const size_t lds = (size_t)2 * 64 * A * sizeof(float);
     float *slab = (float *)workspace;
-    if (A == 64) {
-        sem_attn_bwd_kernel<1><<<grid, 256, lds, st>>>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P);
-    } else {
-        hipError_t e = hipFuncSetAttribute((const void *)sem_attn_bwd_kernel<2>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        sem_attn_bwd_kernel<2><<<grid, 256, lds, st>>>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P);
-    }
-    HAN_CHECK_LAUNCH();
+    int grid = 0;
+    int rc = (A == 64)
+                 ? launch_bwd<1>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, &grid, st)
+                 : launch_bwd<2>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, &grid, st);
+    if (rc != 0) return rc;
     const int width = 64 * A + 2 * A;
-    sem_reduce_kernel<<<(width + 255) / 256, 256, 0, st>>>(slab, grid, width, A, dw_omega, db_omega, du_omega);
-    HAN_CHECK_LAUNCH();
+    HanReduceOut o = han_reduce_to(dw_omega, width);
+    o.ptr[1] = db_omega; o.ptr[2] = du_omega;
+    o.seg_end[0] = 64 * A; o.seg_end[1] = 64 * A + A; o.seg_end[2] = width;
+    o.nseg = 3;
+    hipError_t e = han_reduce_slabs(slab, grid, width, width, o, st);
+    if (e != hipSuccess) return (int)e;
     return 0;
 }
