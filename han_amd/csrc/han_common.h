@@ -20,7 +20,8 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 // (seed, stream, a, b) so that forward and backward -- and any node partition --
 // regenerate the same mask from global ids.  tests/rng_ref.py restates it in
 // NumPy so that the oracle can be fed the identical masks.
-//   stream 0: input-feature dropout  a = global row,  b = f*K + k   (layers.py:19)
+//   stream 0: input-feature dropout  a = global row,  b = f*ceil(K/2) + k/2; TWO 16-bit
+//             draws per hash: head k uses bits [16*(k&1), 16*(k&1)+16)   (layers.py:19)
 //   stream 1: attention dropout      a = global dst i, b = j*K + k  (layers.py:30)
 //   stream 2: projected-row dropout  a = global row j, b = d        (layers.py:32)
 // ---------------------------------------------------------------------------
@@ -43,6 +44,14 @@ __host__ __device__ __forceinline__ uint32_t han_keep_threshold(float keep_prob)
 }
 __host__ __device__ __forceinline__ bool han_keep(uint32_t h, uint32_t thr) {
     return (h >> 8) < thr;
+}
+
+// 16-bit draws of stream 0: keep iff the 16-bit field is below keep_prob * 2^16
+__host__ __device__ __forceinline__ uint32_t han_keep_threshold16(float keep_prob) {
+    return (uint32_t)(keep_prob * 65536.0f);
+}
+__host__ __device__ __forceinline__ bool han_keep16(uint32_t h, int half, uint32_t thr16) {
+    return ((h >> (16 * half)) & 0xFFFFu) < thr16;
 }
 
 __device__ __forceinline__ float han_lrelu(float x, float slope) { return fmaxf(x, slope * x); }

@@ -6,27 +6,55 @@
 // materialised.
 //
 // Data layout (HBM): a projected row H_j is D = 64 fp32 = 256 B = two 128-B
-// lines; the per-head scores f2_j are K fp32 in a separate small table (hot in
-// L2 / Infinity Cache).  Lane mapping: a wave is 4 groups of 16 lanes; lane q of
-// a group owns features 4q..4q+3 (one dwordx4 = 16 B per lane, 256 B per group
-// per load instruction), i.e. head (4q)/FP.  The 4 groups take 4 different
-// neighbours of the same destination row per step, U steps are kept in flight,
-// so one wave has 4*U gathered rows (4 KiB at U=4) outstanding.  Softmax is an
-// online (running max / running sum) softmax per lane; the 4 groups' partial
-// (m, l, acc) are merged with two xor-shuffles (16, 32) at the end of the row.
+// lines.  Lane mapping: a wave is 4 groups of 16 lanes; lane q of a group owns
+// features 4q..4q+3 (one dwordx4 = 16 B per lane, 256 B per group per load
+// instruction), i.e. head (4q)/FP.  The 4 groups take 4 different neighbours of
+// the same destination row per step and U steps are kept in flight, so one wave
+// has 4*U gathered rows (4 KiB at U = 4) outstanding.
 //
-// Roofline: HBM / Infinity-Cache gather bandwidth.  Algorithmic bytes per edge:
-// 4 (colidx) + 256 (H_j) + 4K (f2_j) = 292 B at K = 8.
+// The neighbour's score f2_j = H_j[k,:] . a2[k] + b2[k] (layers.py:24) is
+// recomputed from the gathered row (4 FMAs + one DPP add per edge) instead of
+// being gathered from a second table: a 32-B gather costs a whole extra memory
+// sector per edge (measured round 1: 19.4 GB of fabric traffic per launch against
+// 14.9 GB algorithmic).  In training the gathered rows are the UNDROPPED H; the
+// projected-row dropout (layers.py:31-32) is applied from a 64-bit keep-mask per
+// row (8 B, written by K1) after the score was taken, exactly as the reference
+// orders it.
+//
+// Softmax is an online (running max / running sum) softmax per lane; the 4 groups'
+// partial (m, l, acc) are merged with two xor-shuffles (16, 32) at the end of the row.
+//
+// Roofline: HBM / Infinity-Cache gather bandwidth.  Algorithmic bytes per edge
+// (SURVEY.md sec. 8d): 4 (colidx) + 256 (H_j) + 4K (f2_j) = 292 B at K = 8.
 #include "han_common.h"
 
 namespace {
+
+// sum over the FP/4 lanes that share a head (contiguous, aligned lanes);
+// DPP quad permutes for the first two steps (pure VALU), bpermute beyond
+template <int FP>
+__device__ __forceinline__ float head_sum(float v) {
+    if (FP >= 8)
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));  // xor 1
+    if (FP >= 16)
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));  // xor 2
+    if (FP >= 32) v += __shfl_xor(v, 4, 64);
+    if (FP >= 64) v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+__device__ __forceinline__ float dot4(const float4_t &x, const float4_t &y) {
+    return x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+}
 
 struct FwdArgs {
     const int64_t *rowptr;
     const int32_t *colidx;
     const float *H;
+    const uint64_t *hmask;   // per table row: bit d set <=> H[j][d] kept (training with fts dropout)
     const float *f1;
-    const float *f2;
+    const float *a2;
+    const float *b2;
     const float *c;
     float *out;
     int64_t out_stride;
@@ -34,32 +62,101 @@ struct FwdArgs {
     int64_t N;
     float slope;
     uint32_t seed_lo, seed_hi, thr_coef;
-    float inv_keep_coef;
+    float inv_keep_coef, inv_keep_fts;
     int64_t row_offset;
     int activation;
 };
 
-// merge the online-softmax state of lane `lane ^ off` into this lane
-#define HAN_MERGE_STATE(off)                                                   \
-    {                                                                          \
-        const float m_o = __shfl_xor(m, off, 64);                              \
-        const float l_o = __shfl_xor(l, off, 64);                              \
-        const float M = fmaxf(m, m_o);                                         \
-        const float sa = __expf(m - M), sb = __expf(m_o - M);                  \
-        l = l * sa + l_o * sb;                                                 \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                          \
-            acc[t] = acc[t] * sa + __shfl_xor(acc[t], off, 64) * sb;           \
-        if (TRAIN) {                                                           \
-            tl = tl * sa + __shfl_xor(tl, off, 64) * sb;                       \
-            _Pragma("unroll") for (int t = 0; t < 4; ++t)                      \
-                accp[t] = accp[t] * sa + __shfl_xor(accp[t], off, 64) * sb;    \
-        }                                                                      \
-        m = M;                                                                 \
+template <bool TRAIN>
+struct RowState {
+    float m, l, tl;
+    float acc[4], accp[4];
+    __device__ __forceinline__ void init() {
+        m = HAN_NEG_BIG; l = 0.f; tl = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc[t] = 0.f; accp[t] = 0.f; }
     }
+    // merge the state of lane `lane ^ off`
+    __device__ __forceinline__ void merge(int off) {
+        const float m_o = __shfl_xor(m, off, 64);
+        const float l_o = __shfl_xor(l, off, 64);
+        const float M = fmaxf(m, m_o);
+        const float sa = __expf(m - M), sb = __expf(m_o - M);
+        l = l * sa + l_o * sb;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = acc[t] * sa + __shfl_xor(acc[t], off, 64) * sb;
+        if (TRAIN) {
+            tl = tl * sa + __shfl_xor(tl, off, 64) * sb;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) accp[t] = accp[t] * sa + __shfl_xor(accp[t], off, 64) * sb;
+        }
+        m = M;
+    }
+};
+
+// Gather U neighbour rows and fold them into the running softmax state.
+template <int FP, bool TRAIN, int U>
+__device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U], const bool (&valid)[U],
+                                              const float f1h, const uint32_t gi, const int q, const int head,
+                                              const float4_t &a24, const float b2h, const bool drop_c,
+                                              RowState<TRAIN> &st) {
+    constexpr int K = HAN_D / FP;
+    float4_t hv[U];
+    uint64_t mw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        hv[u] = *reinterpret_cast<const float4_t *>(a.H + (int64_t)j[u] * HAN_D + 4 * q);
+        if (TRAIN) mw[u] = a.hmask ? a.hmask[j[u]] : ~0ull;
+    }
+    float ev[U], sg[U];
+    float mc = st.m;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const float x = f1h + (head_sum<FP>(dot4(hv[u], a24)) + b2h);   // layers.py:24,26
+        sg[u] = x > 0.f ? 1.f : a.slope;
+        ev[u] = valid[u] ? han_lrelu(x, a.slope) : HAN_NEG_BIG;          // layers.py:27
+        mc = fmaxf(mc, ev[u]);
+    }
+    const float sc = __expf(st.m - mc);
+    st.l *= sc;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) st.acc[t] *= sc;
+    if (TRAIN) {
+        st.tl *= sc;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st.accp[t] *= sc;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const float p = valid[u] ? __expf(ev[u] - mc) : 0.f;
+        st.l += p;
+        float pd = p;
+        if (TRAIN) {
+            if (drop_c) {   // attention dropout, layers.py:29-30
+                const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
+                                            (uint32_t)j[u] * (uint32_t)K + (uint32_t)head);
+                pd = han_keep(h, a.thr_coef) ? p * a.inv_keep_coef : 0.f;
+            }
+            // projected-row dropout, layers.py:31-32 (after the score was taken)
+            const uint32_t nib = (uint32_t)(mw[u] >> (4 * q)) & 15u;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hv[u][t] = ((nib >> t) & 1u) ? hv[u][t] * a.inv_keep_fts : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st.acc[t] += pd * hv[u][t];
+        if (TRAIN) {
+            st.tl += p * sg[u];
+            const float pds = pd * sg[u];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) st.accp[t] += pds * hv[u][t];
+        }
+    }
+    st.m = mc;
+}
 
 // One wave per destination row (RPW = 1) or one 16-lane group per row (RPW = 4,
 // for low-degree graphs).  TRAIN also produces pre / lse / aggp / tsum and
-// applies attention dropout when thr_coef < 2^24.
+// applies the two dropouts.
 template <int FP, bool TRAIN, int RPW, int U>
 __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
     constexpr int K = HAN_D / FP;
@@ -69,7 +166,9 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const float4_t c4 = *reinterpret_cast<const float4_t *>(a.c + 4 * q);
-    const bool drop = TRAIN && a.thr_coef < 16777216u;
+    const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
+    const float b2h = a.b2[head];
+    const bool drop_c = TRAIN && a.thr_coef < 16777216u;
     const int64_t nunits = (a.N + RPW - 1) / RPW;   // wave-sized work units
 
     for (int64_t unit = wave0; unit < nunits; unit += nwaves) {
@@ -80,10 +179,8 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
         const int64_t e = row_ok ? a.rowptr[row + 1] : s;
         const float f1h = a.f1[row * K + head];
         const uint32_t gi = (uint32_t)(row + a.row_offset);
-
-        float m = HAN_NEG_BIG, l = 0.f, tl = 0.f;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        float accp[4] = {0.f, 0.f, 0.f, 0.f};
+        RowState<TRAIN> st;
+        st.init();
 
         if (RPW == 1) {
             for (int64_t base = s; base < e; base += 64) {
@@ -92,64 +189,20 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
                 for (int it = 0; it * 4 < cnt; it += U) {
                     int j[U];
                     bool valid[U];
-                    float4_t hv[U];
-                    float s2[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int idx = (it + u) * 4 + g;
                         valid[u] = idx < cnt;
                         j[u] = __shfl(mycol, idx & 63, 64);
                     }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        hv[u] = *reinterpret_cast<const float4_t *>(a.H + (int64_t)j[u] * HAN_D + 4 * q);
-                        s2[u] = a.f2[(int64_t)j[u] * K + head];
-                    }
-                    float ev[U], sg[U];
-                    float mc = m;
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const float x = f1h + s2[u];
-                        sg[u] = x > 0.f ? 1.f : a.slope;
-                        ev[u] = valid[u] ? han_lrelu(x, a.slope) : HAN_NEG_BIG;
-                        mc = fmaxf(mc, ev[u]);
-                    }
-                    const float sc = __expf(m - mc);
-                    l *= sc;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] *= sc;
-                    if (TRAIN) {
-                        tl *= sc;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) accp[t] *= sc;
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const float p = valid[u] ? __expf(ev[u] - mc) : 0.f;
-                        l += p;
-                        float pd = p;
-                        if (drop) {
-                            const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
-                                                        (uint32_t)j[u] * (uint32_t)K + (uint32_t)head);
-                            pd = han_keep(h, a.thr_coef) ? p * a.inv_keep_coef : 0.f;
-                        }
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[t] += pd * hv[u][t];
-                        if (TRAIN) {
-                            tl += p * sg[u];
-                            const float pds = pd * sg[u];
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) accp[t] += pds * hv[u][t];
-                        }
-                    }
-                    m = mc;
+                    consume_edges<FP, TRAIN, U>(a, j, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
                 }
             }
-            HAN_MERGE_STATE(16)
-            HAN_MERGE_STATE(32)
+            st.merge(16);
+            st.merge(32);
         } else {
             // each 16-lane group walks its own row; the wave loops to the longest
-            int64_t len = e - s;
+            const int64_t len = e - s;
             int64_t maxlen = len;
             {
                 int64_t o = __shfl_xor(maxlen, 16, 64);
@@ -160,67 +213,22 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
             for (int64_t it = 0; it < maxlen; it += U) {
                 int j[U];
                 bool valid[U];
-                float4_t hv[U];
-                float s2[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     valid[u] = it + u < len;
-                    const int64_t pos = valid[u] ? s + it + u : (len > 0 ? s : 0);
-                    j[u] = (len > 0) ? a.colidx[pos] : 0;
+                    j[u] = (len > 0) ? a.colidx[valid[u] ? s + it + u : s] : 0;
                 }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    hv[u] = *reinterpret_cast<const float4_t *>(a.H + (int64_t)j[u] * HAN_D + 4 * q);
-                    s2[u] = a.f2[(int64_t)j[u] * K + head];
-                }
-                float ev[U], sg[U];
-                float mc = m;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float x = f1h + s2[u];
-                    sg[u] = x > 0.f ? 1.f : a.slope;
-                    ev[u] = valid[u] ? han_lrelu(x, a.slope) : HAN_NEG_BIG;
-                    mc = fmaxf(mc, ev[u]);
-                }
-                const float sc = __expf(m - mc);
-                l *= sc;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] *= sc;
-                if (TRAIN) {
-                    tl *= sc;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) accp[t] *= sc;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float p = valid[u] ? __expf(ev[u] - mc) : 0.f;
-                    l += p;
-                    float pd = p;
-                    if (drop) {
-                        const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
-                                                    (uint32_t)j[u] * (uint32_t)K + (uint32_t)head);
-                        pd = han_keep(h, a.thr_coef) ? p * a.inv_keep_coef : 0.f;
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] += pd * hv[u][t];
-                    if (TRAIN) {
-                        tl += p * sg[u];
-                        const float pds = pd * sg[u];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) accp[t] += pds * hv[u][t];
-                    }
-                }
-                m = mc;
+                consume_edges<FP, TRAIN, U>(a, j, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
             }
         }
 
         // epilogue: normalise, bias, activation (layers.py:35,46)
         const bool writer = row_ok && (RPW == 4 || g == 0);
-        const float inv = l > 0.f ? 1.f / l : 0.f;
+        const float inv = st.l > 0.f ? 1.f / st.l : 0.f;
         float4_t pv, ov;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            pv[t] = acc[t] * inv + c4[t];
+            pv[t] = st.acc[t] * inv + c4[t];
             ov[t] = a.activation == HAN_ACT_ELU ? han_elu(pv[t]) : pv[t];
         }
         if (writer) {
@@ -228,12 +236,12 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
             if (TRAIN) {
                 float4_t ap;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) ap[t] = accp[t] * inv;
+                for (int t = 0; t < 4; ++t) ap[t] = st.accp[t] * inv;
                 *reinterpret_cast<float4_t *>(a.pre + row * HAN_D + 4 * q) = pv;
                 *reinterpret_cast<float4_t *>(a.aggp + row * HAN_D + 4 * q) = ap;
                 if ((4 * q) % FP == 0) {
-                    a.lse[row * K + head] = l > 0.f ? m + __logf(l) : HAN_NEG_BIG;
-                    a.tsum[row * K + head] = tl * inv;
+                    a.lse[row * K + head] = st.l > 0.f ? st.m + __logf(st.l) : HAN_NEG_BIG;
+                    a.tsum[row * K + head] = st.tl * inv;
                 }
             }
         }
@@ -254,14 +262,6 @@ struct BwdRowsArgs {
 };
 
 template <int FP>
-__device__ __forceinline__ float head_sum(float v) {
-    // sum over the FP/4 lanes that share a head (contiguous, aligned lanes)
-#pragma unroll
-    for (int o = 1; o < FP / 4; o <<= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-template <int FP>
 __global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsArgs a) {
     constexpr int K = HAN_D / FP;
     const int q = threadIdx.x & 15;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsAr
     const int64_t ngrp = (int64_t)gridDim.x * 16;
     const float4_t c4 = *reinterpret_cast<const float4_t *>(a.c + 4 * q);
     float dc[4] = {0.f, 0.f, 0.f, 0.f};
-    // all 16 lanes of a group run the same trip count -> shuffles are safe
+    // all 16 lanes of a group run the same trip count -> the in-head sums are safe
     for (int64_t row = grp0; row < a.N; row += ngrp) {
         const float4_t d4 = *reinterpret_cast<const float4_t *>(a.dOut + row * a.dout_stride + 4 * q);
         const float4_t p4 = *reinterpret_cast<const float4_t *>(a.pre + row * HAN_D + 4 * q);
@@ -319,10 +319,11 @@ struct BwdColsArgs {
     const int64_t *colptr;
     const int32_t *rowidx;
     const float *g, *stats, *H, *f2, *df1, *a1, *a2;
+    const uint64_t *hmask;   // local source rows, or null
     float *dH, *df2;
     int64_t NS;
     float slope;
-    uint32_t seed_lo, seed_hi, thr_coef, thr_fts;
+    uint32_t seed_lo, seed_hi, thr_coef;
     float inv_keep_coef, inv_keep_fts;
     int64_t src_offset, dst_offset;
 };
@@ -336,7 +337,6 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const bool drop_c = a.thr_coef < 16777216u;
-    const bool drop_f = a.thr_fts < 16777216u;
     const float4_t a14 = *reinterpret_cast<const float4_t *>(a.a1 + 4 * q);
     const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
     const int64_t nunits = (a.NS + RPW - 1) / RPW;
@@ -352,11 +352,11 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
         // the dropped projected row H~_j = H_j * mask / keep (layers.py:32)
         float4_t hd = *reinterpret_cast<const float4_t *>(a.H + src * HAN_D + 4 * q);
         float mk[4] = {1.f, 1.f, 1.f, 1.f};
-        if (drop_f) {
+        if (a.hmask) {
+            const uint32_t nib = (uint32_t)(a.hmask[src] >> (4 * q)) & 15u;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_FTS, gj, (uint32_t)(4 * q + t));
-                mk[t] = han_keep(h, a.thr_fts) ? a.inv_keep_fts : 0.f;
+                mk[t] = ((nib >> t) & 1u) ? a.inv_keep_fts : 0.f;
                 hd[t] *= mk[t];
             }
         }
@@ -401,8 +401,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
                                                 gj * (uint32_t)K + (uint32_t)head);
                     am = han_keep(h, a.thr_coef) ? a.inv_keep_coef : 0.f;
                 }
-                float dot = gv[u][0] * hd[0] + gv[u][1] * hd[1] + gv[u][2] * hd[2] + gv[u][3] * hd[3];
-                dot = head_sum<FP>(dot);
+                const float dot = head_sum<FP>(dot4(gv[u], hd));
                 dfacc += alpha * sg * (am * dot - st[u][2]);
                 const float w = alpha * am;
 #pragma unroll
@@ -433,12 +432,11 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
 // backward step 3: score-parameter gradients (da1, da2, db1, db2)
 // slab row layout: [0,64) da1, [64,128) da2, [128,128+K) db1, [128+K,128+2K) db2
 // ---------------------------------------------------------------------------
-#define HAN_SP_WIDTH 160   // 128 + 2*16 (K <= 16)
-
 template <int FP>
 __global__ __launch_bounds__(256) void score_param_bwd_kernel(const float *H, const float *df1,
                                                               const float *df2, float *slab, int64_t N) {
     constexpr int K = HAN_D / FP;
+    constexpr int WIDTH = 128 + 2 * K;
     const int q = threadIdx.x & 15;
     const int head = (4 * q) / FP;
     const int64_t grp0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -456,7 +454,7 @@ __global__ __launch_bounds__(256) void score_param_bwd_kernel(const float *H, co
         s1 += x1;
         s2 += x2;
     }
-    __shared__ float red[16][HAN_SP_WIDTH];
+    __shared__ float red[16][WIDTH];
     const int r = threadIdx.x >> 4;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -468,11 +466,11 @@ __global__ __launch_bounds__(256) void score_param_bwd_kernel(const float *H, co
         red[r][128 + K + head] = s2;
     }
     __syncthreads();
-    if (threadIdx.x < 128 + 2 * K) {
+    if (threadIdx.x < WIDTH) {
         float sacc = 0.f;
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) sacc += red[rr][threadIdx.x];
-        slab[(int64_t)blockIdx.x * (128 + 2 * K) + threadIdx.x] = sacc;
+        slab[(int64_t)blockIdx.x * WIDTH + threadIdx.x] = sacc;
     }
 }
 
@@ -485,10 +483,13 @@ bool fp_supported(int K, int FP) {
 // Launch geometry: 256-thread blocks, 4 waves each; cap the grid and grid-stride.
 int attn_grid(int64_t units) { return han_grid_for(units, 4, 256 * 8 * 4); }
 
+// mean degree (E / N) below which a 16-lane group per row beats a wave per row
+constexpr double kLowDegree = 12.0;
+
 }  // namespace
 
-#define HAN_DISPATCH_FP(FPV, ...)                     \
-    switch (FPV) {                                    \
+#define HAN_DISPATCH_FP(FPV, ...)                                \
+    switch (FPV) {                                               \
         case 4: { constexpr int FPC = 4; __VA_ARGS__; } break;   \
         case 8: { constexpr int FPC = 8; __VA_ARGS__; } break;   \
         case 16: { constexpr int FPC = 16; __VA_ARGS__; } break; \
@@ -496,30 +497,29 @@ int attn_grid(int64_t units) { return han_grid_for(units, 4, 256 * 8 * 4); }
         default: { constexpr int FPC = 64; __VA_ARGS__; } break; \
     }
 
-// mean degree (E / N) below which a 16-lane group per row beats a wave per row
-static constexpr double kLowDegree = 12.0;
-
 extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float *H,
-                                 const float *f1, const float *f2, const float *c, float *out,
-                                 int64_t out_stride, float *pre, float *lse, float *aggp, float *tsum,
-                                 int64_t N, int64_t E, int K, int FP, float slope, float coef_drop,
-                                 uint64_t seed, int64_t row_offset, int activation, void *stream) {
-    if (!rowptr || !colidx || !H || !f1 || !f2 || !c || !out || N < 0 || E < 0 || out_stride < HAN_D)
+                                 const uint64_t *hmask, const float *f1, const float *a2, const float *b2,
+                                 const float *c, float *out, int64_t out_stride, float *pre, float *lse,
+                                 float *aggp, float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
+                                 float coef_drop, float fts_drop, uint64_t seed, int64_t row_offset,
+                                 int activation, void *stream) {
+    if (!rowptr || !colidx || !H || !f1 || !a2 || !b2 || !c || !out || N < 0 || E < 0 || out_stride < HAN_D)
         return HAN_E_BADARG;
     if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
     const bool train = pre || lse || aggp || tsum;
     if (train && !(pre && lse && aggp && tsum)) return HAN_E_BADARG;
-    if (coef_drop < 0.f || coef_drop >= 1.f) return HAN_E_BADARG;
-    if (coef_drop > 0.f && !train) return HAN_E_BADARG;
+    if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
+    if ((coef_drop > 0.f || fts_drop > 0.f) && !train) return HAN_E_BADARG;
+    if ((fts_drop > 0.f) != (hmask != nullptr)) return HAN_E_BADARG;
     if (N == 0) return 0;
     FwdArgs a;
-    a.rowptr = rowptr; a.colidx = colidx; a.H = H; a.f1 = f1; a.f2 = f2; a.c = c;
+    a.rowptr = rowptr; a.colidx = colidx; a.H = H; a.hmask = hmask; a.f1 = f1; a.a2 = a2; a.b2 = b2; a.c = c;
     a.out = out; a.out_stride = out_stride; a.pre = pre; a.lse = lse; a.aggp = aggp; a.tsum = tsum;
     a.N = N; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-    const float keep = 1.f - coef_drop;
-    a.thr_coef = coef_drop > 0.f ? han_keep_threshold(keep) : 16777216u;
-    a.inv_keep_coef = 1.f / keep;
+    a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : 16777216u;
+    a.inv_keep_coef = 1.f / (1.f - coef_drop);
+    a.inv_keep_fts = 1.f / (1.f - fts_drop);
     a.row_offset = row_offset; a.activation = activation;
     hipStream_t st = (hipStream_t)stream;
     const bool low = (double)E < kLowDegree * (double)N;
@@ -567,22 +567,22 @@ extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, co
 }
 
 extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const float *g,
-                                      const float *stats, const float *H, const float *f2,
-                                      const float *df1, const float *a1, const float *a2, float *dH,
-                                      float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
+                                      const float *stats, const float *H, const uint64_t *hmask,
+                                      const float *f2, const float *df1, const float *a1, const float *a2,
+                                      float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                                       float coef_drop, float fts_drop, uint64_t seed, int64_t src_offset,
                                       int64_t dst_offset, void *stream) {
     if (!colptr || !rowidx || !g || !stats || !H || !f2 || !df1 || !a1 || !a2 || !dH || !df2 || NS < 0 || E < 0)
         return HAN_E_BADARG;
     if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
+    if ((fts_drop > 0.f) != (hmask != nullptr)) return HAN_E_BADARG;
     if (NS == 0) return 0;
     BwdColsArgs a;
-    a.colptr = colptr; a.rowidx = rowidx; a.g = g; a.stats = stats; a.H = H; a.f2 = f2; a.df1 = df1;
-    a.a1 = a1; a.a2 = a2; a.dH = dH; a.df2 = df2; a.NS = NS; a.slope = slope;
+    a.colptr = colptr; a.rowidx = rowidx; a.g = g; a.stats = stats; a.H = H; a.hmask = hmask; a.f2 = f2;
+    a.df1 = df1; a.a1 = a1; a.a2 = a2; a.dH = dH; a.df2 = df2; a.NS = NS; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : 16777216u;
-    a.thr_fts = fts_drop > 0.f ? han_keep_threshold(1.f - fts_drop) : 16777216u;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
     a.inv_keep_fts = 1.f / (1.f - fts_drop);
     a.src_offset = src_offset; a.dst_offset = dst_offset;
@@ -597,8 +597,8 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
 }
 
 extern "C" size_t han_score_param_bwd_workspace(int64_t N, int K, int FP) {
-    (void)N; (void)K; (void)FP;
-    return (size_t)kReduceBlocks * HAN_SP_WIDTH * sizeof(float);
+    (void)N; (void)FP;
+    return (size_t)kReduceBlocks * (size_t)(128 + 2 * K) * sizeof(float);
 }
 
 extern "C" int han_score_param_bwd(const float *H, const float *df1, const float *df2, float *da1,
@@ -613,7 +613,7 @@ extern "C" int han_score_param_bwd(const float *H, const float *df1, const float
         score_param_bwd_kernel<FPC><<<grid, 256, 0, st>>>(H, df1, df2, (float *)workspace, N);
     })
     HAN_CHECK_LAUNCH();
-    HanReduceOut o = han_reduce_to(da1, HAN_SP_WIDTH);
+    HanReduceOut o = han_reduce_to(da1, 128 + 2 * K);
     o.ptr[1] = da2; o.ptr[2] = db1; o.ptr[3] = db2;
     o.seg_end[0] = 64; o.seg_end[1] = 128; o.seg_end[2] = 128 + K; o.seg_end[3] = 128 + 2 * K;
     o.nseg = 4;

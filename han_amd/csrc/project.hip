@@ -42,6 +42,7 @@ struct HeadsPerTile { static constexpr int value = FP >= 16 ? 1 : 16 / FP; };
 template <int FP, bool DROP>
 __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
     constexpr int K = HAN_D / FP;
+    constexpr int KP = (K + 1) / 2;   // head pairs: one 32-bit hash = two 16-bit draws
     constexpr int HPT = HeadsPerTile<FP>::value;
     __shared__ float Xs[BM * XS_LD];
     __shared__ float Ws[BK * WS_LD];
@@ -93,9 +94,10 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
 #pragma unroll
                     for (int hh = 0; hh < HPT; ++hh) {
                         const int head = (16 * t) / FP + hh;
+                        // one hash serves the two heads of a pair (identical calls are CSE'd)
                         const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob,
-                                                    kglob * (uint32_t)K + (uint32_t)head);
-                        const float am = han_keep(h, a.thr_in) ? av : 0.f;
+                                                    kglob * (uint32_t)KP + (uint32_t)(head >> 1));
+                        const float am = han_keep16(h, head & 1, a.thr_in) ? av : 0.f;
                         const float bm = (HPT == 1 || (l15 / FP) == hh) ? bv : 0.f;
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, acc[t], 0, 0, 0);
                     }
@@ -115,10 +117,11 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
 }
 
 // Row-local epilogue: f1 = H_k.a1 + b1, f2 = H_k.a2 + b2 (layers.py:23-24) and the
-// dropped copy Hd = dropout(H) that the aggregation gathers (layers.py:31-32).
+// keep-mask of the projected-row dropout that K2 applies while gathering (layers.py:31-32).
 struct ScoreArgs {
     const float *H, *a1, *a2, *b1, *b2;
-    float *f1, *f2, *Hd;
+    float *f1, *f2;
+    uint64_t *hmask;
     int64_t N;
     uint32_t seed_lo, seed_hi, thr_fts;
     float inv_keep_fts;
@@ -148,15 +151,23 @@ __global__ __launch_bounds__(256) void project_scores_kernel(const ScoreArgs a) 
             a.f1[row * K + head] = s1 + b1;
             a.f2[row * K + head] = s2 + b2;
         }
-        if (a.Hd) {
-            float4_t d4;
+        if (a.hmask) {
+            // 64-bit keep mask of the projected row (layers.py:31-32): bit d <=> H[row][d] kept
             const uint32_t gr = (uint32_t)(row + a.row_offset);
+            uint32_t nib = 0;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_FTS, gr, (uint32_t)(4 * q + t));
-                d4[t] = han_keep(h, a.thr_fts) ? h4[t] * a.inv_keep_fts : 0.f;
+                nib |= (han_keep(h, a.thr_fts) ? 1u : 0u) << t;
             }
-            *reinterpret_cast<float4_t *>(a.Hd + row * HAN_D + 4 * q) = d4;
+            uint32_t lo = q < 8 ? nib << (4 * q) : 0u;
+            uint32_t hi = q >= 8 ? nib << (4 * (q - 8)) : 0u;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                lo |= (uint32_t)__shfl_xor((int)lo, o, 64);
+                hi |= (uint32_t)__shfl_xor((int)hi, o, 64);
+            }
+            if (q == 0) a.hmask[row] = ((uint64_t)hi << 32) | lo;
         }
     }
 }
@@ -186,6 +197,7 @@ struct ProjBwdArgs {
 template <int FP, bool DROP>
 __global__ __launch_bounds__(256) void project_bwd_kernel(const ProjBwdArgs a) {
     constexpr int K = HAN_D / FP;
+    constexpr int KP = (K + 1) / 2;   // head pairs: one 32-bit hash = two 16-bit draws
     constexpr int HPT = HeadsPerTile<FP>::value;
     __shared__ float Xs[BN * TS_LD];
     __shared__ float Gs[BN * TS_LD];
@@ -240,8 +252,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const ProjBwdArgs a) {
                     for (int hh = 0; hh < HPT; ++hh) {
                         const int head = (16 * t) / FP + hh;
                         const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob,
-                                                    fglob * (uint32_t)K + (uint32_t)head);
-                        const float am = han_keep(h, a.thr_in) ? av : 0.f;
+                                                    fglob * (uint32_t)KP + (uint32_t)(head >> 1));
+                        const float am = han_keep16(h, head & 1, a.thr_in) ? av : 0.f;
                         const float bm = (HPT == 1 || (l15 / FP) == hh) ? bv : 0.f;
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, acc[t], 0, 0, 0);
                     }
@@ -287,20 +299,20 @@ void bwd_geometry(int64_t N, int F, int *ftiles, int64_t *rows_per_chunk, int64_
     }
 
 extern "C" int han_project_fwd(const float *X, int64_t ldx, const float *W, const float *a1,
-                               const float *a2, const float *b1, const float *b2, float *H, float *Hd,
-                               float *f1, float *f2, int64_t N, int F, int K, int FP, float in_drop,
+                               const float *a2, const float *b1, const float *b2, float *H,
+                               uint64_t *hmask, float *f1, float *f2, int64_t N, int F, int K, int FP, float in_drop,
                                float fts_drop, uint64_t seed, int64_t row_offset, void *stream) {
     if (!X || !W || !a1 || !a2 || !b1 || !b2 || !H || !f1 || !f2 || N < 0 || F <= 0 || ldx < F)
         return HAN_E_BADARG;
     if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
     if (in_drop < 0.f || in_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
-    if (fts_drop > 0.f && !Hd) return HAN_E_BADARG;
+    if (fts_drop > 0.f && !hmask) return HAN_E_BADARG;
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     ProjFwdArgs a;
     a.X = X; a.ldx = ldx; a.W = W; a.H = H; a.N = N; a.F = F;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-    a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : 16777216u;
+    a.thr_in = in_drop > 0.f ? han_keep_threshold16(1.f - in_drop) : 65536u;
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
     const int grid = (int)((N + BM - 1) / BM);
@@ -311,7 +323,7 @@ extern "C" int han_project_fwd(const float *X, int64_t ldx, const float *W, cons
     HAN_CHECK_LAUNCH();
     ScoreArgs s;
     s.H = H; s.a1 = a1; s.a2 = a2; s.b1 = b1; s.b2 = b2; s.f1 = f1; s.f2 = f2;
-    s.Hd = fts_drop > 0.f ? Hd : nullptr;
+    s.hmask = fts_drop > 0.f ? hmask : nullptr;
     s.N = N; s.seed_lo = a.seed_lo; s.seed_hi = a.seed_hi;
     s.thr_fts = fts_drop > 0.f ? han_keep_threshold(1.f - fts_drop) : 16777216u;
     s.inv_keep_fts = 1.f / (1.f - fts_drop);
@@ -343,7 +355,7 @@ extern "C" int han_project_bwd(const float *X, int64_t ldx, const float *dH, flo
     a.X = X; a.ldx = ldx; a.dH = dH; a.slab = (float *)workspace; a.N = N; a.F = F;
     a.rows_per_chunk = rpc;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-    a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : 16777216u;
+    a.thr_in = in_drop > 0.f ? han_keep_threshold16(1.f - in_drop) : 65536u;
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
     dim3 grid(ftiles, (unsigned)nch);

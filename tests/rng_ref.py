@@ -34,11 +34,16 @@ def keep(seed, stream, a, b, drop):
 
 
 def seq_mask(seed, n, f, K, drop, row_offset=0):
-    """(K,N,F) -- layers.py:19, key (row, f*K + k)."""
+    """(K,N,F) -- layers.py:19.  One hash per (row, f, head pair): key
+    (row, f*ceil(K/2) + k//2); head k uses the 16-bit field k&1."""
+    KP = (K + 1) // 2
     rows = np.arange(n)[None, :, None] + row_offset
     fs = np.arange(f)[None, None, :]
     ks = np.arange(K)[:, None, None]
-    return keep(seed, STREAM_SEQ, rows, fs * K + ks, drop).astype(np.float64)
+    h = han_hash(seed, STREAM_SEQ, rows, fs * KP + ks // 2)
+    field = (h >> (np.uint64(16) * (ks % 2).astype(np.uint64))) & np.uint64(0xFFFF)
+    thr16 = np.uint64(int(np.float32(keep_prob32(drop)) * np.float32(65536.0)))
+    return (field < thr16).astype(np.float64)
 
 
 def coef_mask_csr(seed, rowptr, colidx, K, drop, row_offset=0):
