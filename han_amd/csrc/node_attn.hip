@@ -17,9 +17,10 @@
 // being gathered from a second table: a 32-B gather costs a whole extra memory
 // sector per edge (measured round 1: 19.4 GB of fabric traffic per launch against
 // 14.9 GB algorithmic).  In training the gathered rows are the UNDROPPED H; the
-// projected-row dropout (layers.py:31-32) is applied from a 64-bit keep-mask per
-// row (8 B, written by K1) after the score was taken, exactly as the reference
-// orders it.
+// Bernoulli draw of the projected-row dropout (layers.py:31-32) travels IN the row:
+// K1 stores each element's keep bit in the lowest mantissa bit of the float (a
+// 1-ulp perturbation that every consumer sees consistently), so the mask costs no
+// extra gather; it is applied after the score was taken, as the reference orders it.
 //
 // Softmax is an online (running max / running sum) softmax per lane; the 4 groups'
 // partial (m, l, acc) are merged with two xor-shuffles (16, 32) at the end of the row.
@@ -51,7 +52,7 @@ struct FwdArgs {
     const int64_t *rowptr;
     const int32_t *colidx;
     const float *H;
-    const uint64_t *hmask;   // per table row: bit d set <=> H[j][d] kept (training with fts dropout)
+    int lsb_mask;   // training with fts dropout: bit 0 of every H element is its keep bit
     const float *f1;
     const float *a2;
     const float *b2;
@@ -102,12 +103,9 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
                                               RowState<TRAIN> &st) {
     constexpr int K = HAN_D / FP;
     float4_t hv[U];
-    uint64_t mw[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U; ++u)
         hv[u] = *reinterpret_cast<const float4_t *>(a.H + (int64_t)j[u] * HAN_D + 4 * q);
-        if (TRAIN) mw[u] = a.hmask ? a.hmask[j[u]] : ~0ull;
-    }
     float ev[U], sg[U];
     float mc = st.m;
 #pragma unroll
@@ -138,9 +136,11 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
                 pd = han_keep(h, a.thr_coef) ? p * a.inv_keep_coef : 0.f;
             }
             // projected-row dropout, layers.py:31-32 (after the score was taken)
-            const uint32_t nib = (uint32_t)(mw[u] >> (4 * q)) & 15u;
+            if (a.lsb_mask) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) hv[u][t] = ((nib >> t) & 1u) ? hv[u][t] * a.inv_keep_fts : 0.f;
+                for (int t = 0; t < 4; ++t)
+                    hv[u][t] = (__float_as_uint(hv[u][t]) & 1u) ? hv[u][t] * a.inv_keep_fts : 0.f;
+            }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) st.acc[t] += pd * hv[u][t];
@@ -319,7 +319,7 @@ struct BwdColsArgs {
     const int64_t *colptr;
     const int32_t *rowidx;
     const float *g, *stats, *H, *f2, *df1, *a1, *a2;
-    const uint64_t *hmask;   // local source rows, or null
+    int lsb_mask;
     float *dH, *df2;
     int64_t NS;
     float slope;
@@ -352,11 +352,10 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
         // the dropped projected row H~_j = H_j * mask / keep (layers.py:32)
         float4_t hd = *reinterpret_cast<const float4_t *>(a.H + src * HAN_D + 4 * q);
         float mk[4] = {1.f, 1.f, 1.f, 1.f};
-        if (a.hmask) {
-            const uint32_t nib = (uint32_t)(a.hmask[src] >> (4 * q)) & 15u;
+        if (a.lsb_mask) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                mk[t] = ((nib >> t) & 1u) ? a.inv_keep_fts : 0.f;
+                mk[t] = (__float_as_uint(hd[t]) & 1u) ? a.inv_keep_fts : 0.f;
                 hd[t] *= mk[t];
             }
         }
@@ -498,7 +497,7 @@ constexpr double kLowDegree = 12.0;
     }
 
 extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float *H,
-                                 const uint64_t *hmask, const float *f1, const float *a2, const float *b2,
+                                 const float *f1, const float *a2, const float *b2,
                                  const float *c, float *out, int64_t out_stride, float *pre, float *lse,
                                  float *aggp, float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
                                  float coef_drop, float fts_drop, uint64_t seed, int64_t row_offset,
@@ -510,10 +509,9 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     if (train && !(pre && lse && aggp && tsum)) return HAN_E_BADARG;
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
     if ((coef_drop > 0.f || fts_drop > 0.f) && !train) return HAN_E_BADARG;
-    if ((fts_drop > 0.f) != (hmask != nullptr)) return HAN_E_BADARG;
     if (N == 0) return 0;
     FwdArgs a;
-    a.rowptr = rowptr; a.colidx = colidx; a.H = H; a.hmask = hmask; a.f1 = f1; a.a2 = a2; a.b2 = b2; a.c = c;
+    a.rowptr = rowptr; a.colidx = colidx; a.H = H; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.a2 = a2; a.b2 = b2; a.c = c;
     a.out = out; a.out_stride = out_stride; a.pre = pre; a.lse = lse; a.aggp = aggp; a.tsum = tsum;
     a.N = N; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
@@ -567,8 +565,7 @@ extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, co
 }
 
 extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const float *g,
-                                      const float *stats, const float *H, const uint64_t *hmask,
-                                      const float *f2, const float *df1, const float *a1, const float *a2,
+                                      const float *stats, const float *H, const float *f2, const float *df1, const float *a1, const float *a2,
                                       float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                                       float coef_drop, float fts_drop, uint64_t seed, int64_t src_offset,
                                       int64_t dst_offset, void *stream) {
@@ -576,10 +573,9 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
         return HAN_E_BADARG;
     if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
-    if ((fts_drop > 0.f) != (hmask != nullptr)) return HAN_E_BADARG;
     if (NS == 0) return 0;
     BwdColsArgs a;
-    a.colptr = colptr; a.rowidx = rowidx; a.g = g; a.stats = stats; a.H = H; a.hmask = hmask; a.f2 = f2;
+    a.colptr = colptr; a.rowidx = rowidx; a.g = g; a.stats = stats; a.H = H; a.lsb_mask = fts_drop > 0.f; a.f2 = f2;
     a.df1 = df1; a.a1 = a1; a.a2 = a2; a.dH = dH; a.df2 = df2; a.NS = NS; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : 16777216u;

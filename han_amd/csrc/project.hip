@@ -30,7 +30,7 @@ struct ProjFwdArgs {
     float *H;
     int64_t N;
     int F;
-    uint32_t seed_lo, seed_hi, thr_in;
+    uint32_t seed_lo, seed_hi, thr_in, thr_fts;   // thr_fts < 2^24: stamp keep bits into H
     float inv_keep_in;
     int64_t row_offset;
 };
@@ -111,21 +111,24 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t row = row0 + 16 * w + l4 * 4 + r;
-            if (row < a.N) a.H[row * HAN_D + 16 * t + l15] = DROP ? acc[t][r] * a.inv_keep_in : acc[t][r];
+            float v = DROP ? acc[t][r] * a.inv_keep_in : acc[t][r];
+            if (a.thr_fts < 16777216u) {
+                // projected-row dropout (layers.py:31-32): the keep bit rides in mantissa bit 0
+                const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_FTS,
+                                            (uint32_t)(row + a.row_offset), (uint32_t)(16 * t + l15));
+                v = __uint_as_float((__float_as_uint(v) & ~1u) | (han_keep(h, a.thr_fts) ? 1u : 0u));
+            }
+            if (row < a.N) a.H[row * HAN_D + 16 * t + l15] = v;
         }
     }
 }
 
-// Row-local epilogue: f1 = H_k.a1 + b1, f2 = H_k.a2 + b2 (layers.py:23-24) and the
-// keep-mask of the projected-row dropout that K2 applies while gathering (layers.py:31-32).
+// Row-local epilogue: f1 = H_k.a1 + b1, f2 = H_k.a2 + b2 (layers.py:23-24), taken from
+// the rows exactly as stored (i.e. including the keep bits stamped in training).
 struct ScoreArgs {
     const float *H, *a1, *a2, *b1, *b2;
     float *f1, *f2;
-    uint64_t *hmask;
     int64_t N;
-    uint32_t seed_lo, seed_hi, thr_fts;
-    float inv_keep_fts;
-    int64_t row_offset;
 };
 
 template <int FP>
@@ -150,24 +153,6 @@ __global__ __launch_bounds__(256) void project_scores_kernel(const ScoreArgs a) 
         if ((4 * q) % FP == 0) {
             a.f1[row * K + head] = s1 + b1;
             a.f2[row * K + head] = s2 + b2;
-        }
-        if (a.hmask) {
-            // 64-bit keep mask of the projected row (layers.py:31-32): bit d <=> H[row][d] kept
-            const uint32_t gr = (uint32_t)(row + a.row_offset);
-            uint32_t nib = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_FTS, gr, (uint32_t)(4 * q + t));
-                nib |= (han_keep(h, a.thr_fts) ? 1u : 0u) << t;
-            }
-            uint32_t lo = q < 8 ? nib << (4 * q) : 0u;
-            uint32_t hi = q >= 8 ? nib << (4 * (q - 8)) : 0u;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                lo |= (uint32_t)__shfl_xor((int)lo, o, 64);
-                hi |= (uint32_t)__shfl_xor((int)hi, o, 64);
-            }
-            if (q == 0) a.hmask[row] = ((uint64_t)hi << 32) | lo;
         }
     }
 }
@@ -300,19 +285,19 @@ void bwd_geometry(int64_t N, int F, int *ftiles, int64_t *rows_per_chunk, int64_
 
 extern "C" int han_project_fwd(const float *X, int64_t ldx, const float *W, const float *a1,
                                const float *a2, const float *b1, const float *b2, float *H,
-                               uint64_t *hmask, float *f1, float *f2, int64_t N, int F, int K, int FP, float in_drop,
+                               float *f1, float *f2, int64_t N, int F, int K, int FP, float in_drop,
                                float fts_drop, uint64_t seed, int64_t row_offset, void *stream) {
     if (!X || !W || !a1 || !a2 || !b1 || !b2 || !H || !f1 || !f2 || N < 0 || F <= 0 || ldx < F)
         return HAN_E_BADARG;
     if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
     if (in_drop < 0.f || in_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
-    if (fts_drop > 0.f && !hmask) return HAN_E_BADARG;
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     ProjFwdArgs a;
     a.X = X; a.ldx = ldx; a.W = W; a.H = H; a.N = N; a.F = F;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     a.thr_in = in_drop > 0.f ? han_keep_threshold16(1.f - in_drop) : 65536u;
+    a.thr_fts = fts_drop > 0.f ? han_keep_threshold(1.f - fts_drop) : 16777216u;
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
     const int grid = (int)((N + BM - 1) / BM);
@@ -323,11 +308,7 @@ extern "C" int han_project_fwd(const float *X, int64_t ldx, const float *W, cons
     HAN_CHECK_LAUNCH();
     ScoreArgs s;
     s.H = H; s.a1 = a1; s.a2 = a2; s.b1 = b1; s.b2 = b2; s.f1 = f1; s.f2 = f2;
-    s.hmask = fts_drop > 0.f ? hmask : nullptr;
-    s.N = N; s.seed_lo = a.seed_lo; s.seed_hi = a.seed_hi;
-    s.thr_fts = fts_drop > 0.f ? han_keep_threshold(1.f - fts_drop) : 16777216u;
-    s.inv_keep_fts = 1.f / (1.f - fts_drop);
-    s.row_offset = row_offset;
+    s.N = N;
     const int sgrid = han_grid_for(N, 16, 256 * 8);
     HAN_DISPATCH_FP(FP, { project_scores_kernel<FPC><<<sgrid, 256, 0, st>>>(s); })
     HAN_CHECK_LAUNCH();

@@ -65,20 +65,14 @@ class NodeLevelAttention(torch.autograd.Function):
         saved = []
         for p in range(P):
             seed = int(cfg["seeds"][p])
-            H, hmask, f1, f2 = ops.project_fwd(xs[p], W[p], a1[p], a2[p], b1[p], b2[p],
-                                               in_drop=in_drop, fts_drop=in_drop, seed=seed,
-                                               row_offset=row_offset)
-            if part is not None and part.world > 1:
-                H_tab = part.all_gather_rows(H)
-                hm_tab = part.all_gather_rows(hmask) if hmask is not None else None
-            else:
-                H_tab, hm_tab = H, hmask
+            H, f1, f2 = ops.project_fwd(xs[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
+                                        fts_drop=in_drop, seed=seed, row_offset=row_offset)
+            H_tab = part.all_gather_rows(H) if (part is not None and part.world > 1) else H
             _, sv = ops.node_attn_fwd(graphs[p], H_tab, f1, a2[p], b2[p], c[p], out=M[:, p, :],
-                                      train=train, coef_drop=coef_drop, fts_drop=in_drop,
-                                      hmask_tab=hm_tab, seed=seed, row_offset=row_offset,
-                                      activation=cfg["act"])
+                                      train=train, coef_drop=coef_drop, fts_drop=in_drop, seed=seed,
+                                      row_offset=row_offset, activation=cfg["act"])
             if train:
-                saved.append((H, hmask, f1, f2) + sv)
+                saved.append((H, f1, f2) + sv)
         ctx.cfg, ctx.xs, ctx.graphs = cfg, xs, graphs
         ctx.saved_per_p = saved
         ctx.in_drop, ctx.coef_drop = in_drop, coef_drop
@@ -102,7 +96,7 @@ class NodeLevelAttention(torch.autograd.Function):
         db1, db2 = torch.empty_like(b1), torch.empty_like(b2)
         dc = torch.empty_like(c)
         for p in range(P):
-            H, hmask, f1, f2, pre, lse, aggp, tsum = ctx.saved_per_p[p]
+            H, f1, f2, pre, lse, aggp, tsum = ctx.saved_per_p[p]
             seed = int(cfg["seeds"][p])
             g, stats, df1, dcp = ops.node_attn_bwd_rows(dM[:, p, :], pre, aggp, tsum, f1, lse, c[p],
                                                         activation=cfg["act"], K=K, FP=FP)
@@ -112,8 +106,8 @@ class NodeLevelAttention(torch.autograd.Function):
             else:
                 g_tab, stats_tab = g, stats
             dH, df2 = ops.node_attn_bwd_cols(graphs_t[p], g_tab, stats_tab, H, f2, df1, a1[p], a2[p],
-                                             coef_drop=ctx.coef_drop, fts_drop=ctx.in_drop, hmask=hmask,
-                                             seed=seed, src_offset=row_offset, dst_offset=0)
+                                             coef_drop=ctx.coef_drop, fts_drop=ctx.in_drop, seed=seed,
+                                             src_offset=row_offset, dst_offset=0)
             d1, d2, e1, e2 = ops.score_param_bwd(H, df1, df2, K=K, FP=FP)
             da1[p], da2[p], db1[p], db2[p], dc[p] = d1, d2, e1, e2, dcp
             dW[p] = ops.project_bwd(xs[p], dH, K, FP, in_drop=ctx.in_drop, seed=seed,

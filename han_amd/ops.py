@@ -73,8 +73,8 @@ def _check_drop(p: float, name: str):
 def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_offset=0):
     """utils/layers.py:18-24,31-32 for the K heads of one meta-path.
     X (N,F) [row stride >= F]; W (F,D); a1,a2 (K,F'); b1,b2 (K,).
-    Returns H (N,D), hmask (N,) int64 bit-mask of the projected-row dropout or
-    None, f1 (N,K), f2 (N,K)."""
+    Returns H (N,D), f1 (N,K), f2 (N,K).  With fts_drop > 0 the keep bit of the
+    projected-row dropout rides in mantissa bit 0 of every H element."""
     lib = _lib.load()
     if X.dim() != 2:
         raise ValueError(f"X: expected (N,F), got {tuple(X.shape)}")
@@ -93,15 +93,14 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
     in_drop = _check_drop(in_drop, "in_drop")
     fts_drop = _check_drop(fts_drop, "fts_drop")
     H = torch.empty((N, D), dtype=torch.float32, device=dev)
-    hmask = torch.empty((N,), dtype=torch.int64, device=dev) if fts_drop > 0 else None
     f1 = torch.empty((N, K), dtype=torch.float32, device=dev)
     f2 = torch.empty((N, K), dtype=torch.float32, device=dev)
     _lib.check(lib.han_project_fwd(
         X.data_ptr(), X.stride(0) if N > 1 else max(F, X.stride(0)), W.data_ptr(), a1.data_ptr(),
         a2.data_ptr(), b1.data_ptr(), b2.data_ptr(), H.data_ptr(),
-        hmask.data_ptr() if hmask is not None else None, f1.data_ptr(), f2.data_ptr(), N, F, K, FP,
+        f1.data_ptr(), f2.data_ptr(), N, F, K, FP,
         in_drop, fts_drop, int(seed), int(row_offset), _stream()), "han_project_fwd")
-    return H, hmask, f1, f2
+    return H, f1, f2
 
 
 def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0):
@@ -123,11 +122,11 @@ def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0):
 
 # --------------------------------------------------------------------------- K2
 def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=0.0,
-                  fts_drop=0.0, hmask_tab=None, seed=0, row_offset=0, activation=ACT_ELU):
+                  fts_drop=0.0, seed=0, row_offset=0, activation=ACT_ELU):
     """utils/layers.py:26-35,46.  H_tab (NT,D): gather table of UNDROPPED projected
     rows indexed by graph.colidx (f2_j is recomputed from the gathered row with
-    a2 (K,F'), b2 (K,)); hmask_tab (NT,) int64 keep masks when fts_drop > 0;
-    f1 (N,K) local rows; c (D,).  `out`: optional (N,D) view with unit inner
+    a2 (K,F'), b2 (K,)); with fts_drop > 0 bit 0 of each element is its keep bit
+    (as project_fwd stamped it); f1 (N,K) local rows; c (D,).  `out`: optional (N,D) view with unit inner
     stride (e.g. M[:,p,:]).  Returns out, saved where
     saved = (pre, lse, aggp, tsum) if train else None."""
     lib = _lib.load()
@@ -152,10 +151,6 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
     fts_drop = _check_drop(fts_drop, "fts_drop")
     if (coef_drop > 0 or fts_drop > 0) and not train:
         raise ValueError("dropout > 0 requires train=True")
-    if (fts_drop > 0) != (hmask_tab is not None):
-        raise ValueError("hmask_tab must be given exactly when fts_drop > 0")
-    if hmask_tab is not None:
-        _chk(hmask_tab, "hmask", (graph.n_cols,), dtype=torch.int64, device=dev)
     saved = None
     ptrs = [None, None, None, None]
     if train:
@@ -170,9 +165,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     _lib.check(lib.han_node_attn_fwd(
-        graph.rowptr.data_ptr(), graph.colidx.data_ptr(), H_tab.data_ptr(),
-        hmask_tab.data_ptr() if hmask_tab is not None else None, f1.data_ptr(), a2.data_ptr(),
-        b2.data_ptr(), c.data_ptr(), out.data_ptr(), out.stride(0) if N > 1 else D,
+        graph.rowptr.data_ptr(), graph.colidx.data_ptr(), H_tab.data_ptr(), f1.data_ptr(),
+        a2.data_ptr(), b2.data_ptr(), c.data_ptr(), out.data_ptr(), out.stride(0) if N > 1 else D,
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
         int(seed), int(row_offset), int(activation), _stream()), "han_node_attn_fwd")
     if timing is not None:
@@ -208,10 +202,10 @@ def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=
 
 
 def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=0.0,
-                       fts_drop=0.0, hmask=None, seed=0, src_offset=0, dst_offset=0):
+                       fts_drop=0.0, seed=0, src_offset=0, dst_offset=0):
     """Transposed-graph half of the K2 backward.  graph_t rows = local sources j,
     its colidx = destinations i indexing g_tab (NT,D) / stats_tab (NT,K,4).
-    H (NS,D) undropped local rows, hmask (NS,) int64 (when fts_drop > 0),
+    H (NS,D) undropped local rows (keep bits in bit 0 when fts_drop > 0),
     f2/df1 (NS,K).  Returns dH (NS,D), df2 (NS,K)."""
     lib = _lib.load()
     K, FP = a1.shape
@@ -226,16 +220,11 @@ def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, 
     _chk(a1, "a1", (K, FP), device=dev)
     _chk(a2, "a2", (K, FP), device=dev)
     fts_drop = _check_drop(fts_drop, "fts_drop")
-    if (fts_drop > 0) != (hmask is not None):
-        raise ValueError("hmask must be given exactly when fts_drop > 0")
-    if hmask is not None:
-        _chk(hmask, "hmask", (NS,), dtype=torch.int64, device=dev)
     dH = torch.empty((NS, D), dtype=torch.float32, device=dev)
     df2 = torch.empty((NS, K), dtype=torch.float32, device=dev)
     _lib.check(lib.han_node_attn_bwd_cols(
         graph_t.rowptr.data_ptr(), graph_t.colidx.data_ptr(), g_tab.data_ptr(),
-        stats_tab.data_ptr(), H.data_ptr(), hmask.data_ptr() if hmask is not None else None,
-        f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
+        stats_tab.data_ptr(), H.data_ptr(), f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
         NS, graph_t.nnz, K, FP, LEAKY_SLOPE, _check_drop(coef_drop, "coef_drop"), fts_drop,
         int(seed), int(src_offset), int(dst_offset), _stream()), "han_node_attn_bwd_cols")
     return dH, df2

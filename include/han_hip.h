@@ -45,14 +45,15 @@ const char *han_error_string(int code);
  *   H[:, k*FP:(k+1)*FP] = Xk @ W[:, k*FP:(k+1)*FP]          (:20)
  *   f1[:,k] = H_k . a1[k] + b1[k];  f2[:,k] = H_k . a2[k] + b2[k]   (:23-24)
  * and the Bernoulli draw of the projected-row dropout (:31-32, which the
- * reference applies AFTER the scores were taken from the undropped rows) as a
- * 64-bit keep mask per row, applied by K2 while it gathers:
- *   hmask[n] bit d set <=> H[n][d] kept     (only if fts_drop > 0; else untouched)
- * X (N,F) ldx>=F; W (F,D); a1,a2 (K,FP); b1,b2 (K); H (N,D); hmask (N) u64; f1,f2 (N,K).
+ * reference applies AFTER the scores were taken from the undropped rows): when
+ * fts_drop > 0 the keep bit of H[n][d] is stamped into mantissa bit 0 of that
+ * float (a 1-ulp perturbation seen consistently by f1/f2, K2 and the backward),
+ * so that K2 applies the mask while it gathers at no extra memory traffic.
+ * X (N,F) ldx>=F; W (F,D); a1,a2 (K,FP); b1,b2 (K); H (N,D); f1,f2 (N,K).
  * in_drop == 0 -> no input dropout.  row_offset = global id of row 0 (RNG key). */
 int han_project_fwd(const float *X, int64_t ldx, const float *W, const float *a1,
                     const float *a2, const float *b1, const float *b2, float *H,
-                    uint64_t *hmask, float *f1, float *f2, int64_t N, int F, int K, int FP,
+                    float *f1, float *f2, int64_t N, int F, int K, int FP,
                     float in_drop, float fts_drop, uint64_t seed, int64_t row_offset,
                     void *stream);
 
@@ -69,16 +70,15 @@ int han_project_bwd(const float *X, int64_t ldx, const float *dH, float *dW,
  *   e_ij = LeakyReLU(f1_i + f2_j), alpha = softmax_j, out_i = act(sum_j
  *   drop(alpha_ij) drop(H_j) + c).
  * rowptr (N+1) int64, colidx (E) int32 indexing the NT-row table H (NT,D) (the
- * UNDROPPED projected rows) and, in training with fts_drop > 0, hmask (NT) u64;
- * the neighbour score f2_j = H_j[k].a2[k] + b2[k] is recomputed from the gathered
- * row.  f1 (N,K) for the local rows; a2 (K,FP); b2 (K); c (D).  out row i is written
+ * UNDROPPED projected rows; with fts_drop > 0 bit 0 of every element is its keep
+ * bit, as han_project_fwd stamped it); the neighbour score
+ * f2_j = H_j[k].a2[k] + b2[k] is recomputed from the gathered row.  f1 (N,K) for the local rows; a2 (K,FP); b2 (K); c (D).  out row i is written
  * at out + i*out_stride (so the K heads land directly in M[:,p,:],
  * models/gat.py:46,58-60).  Training extras (all or none may be NULL): pre (N,D)
  * pre-activation, lse (N,K) log-sum-exp of the scores, aggp (N,D) and tsum (N,K)
  * -- the LeakyReLU'-weighted aggregates that make df1 row-local in the backward. */
 int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float *H,
-                      const uint64_t *hmask, const float *f1, const float *a2,
-                      const float *b2, const float *c, float *out, int64_t out_stride,
+                      const float *f1, const float *a2, const float *b2, const float *c, float *out, int64_t out_stride,
                       float *pre, float *lse, float *aggp, float *tsum, int64_t N,
                       int64_t E, int K, int FP, float slope, float coef_drop,
                       float fts_drop, uint64_t seed, int64_t row_offset, int activation,
@@ -105,13 +105,13 @@ int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *
  * stats (NT,K,4)).  Produces for each source j
  *   df2_j[k] = sum_i dl_ij,   dH_j = mH_j/keep * sum_i drop(alpha_ij) g_i
  *                                     + df1_j a1 + df2_j a2
- * H, hmask (or NULL when fts_drop == 0), f2, df1 are the NS local source rows;
+ * H (keep bits in bit 0 when fts_drop > 0), f2, df1 are the NS local source rows;
  * dH (NS,D), df2 (NS,K) outputs.
  * src_offset / the ids in rowidx + dst_offset are the global ids used as RNG
  * keys (must match the forward).                                            */
 int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const float *g,
-                           const float *stats, const float *H, const uint64_t *hmask,
-                           const float *f2, const float *df1, const float *a1, const float *a2,
+                           const float *stats, const float *H, const float *f2,
+                           const float *df1, const float *a1, const float *a2,
                            float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                            float coef_drop, float fts_drop, uint64_t seed,
                            int64_t src_offset, int64_t dst_offset, void *stream);

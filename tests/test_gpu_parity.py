@@ -33,10 +33,9 @@ def test_project_fwd_matches_oracle(dev, n, f):
     W = rng.standard_normal((f, 64)) * 0.2
     a1, a2 = rng.standard_normal((8, 8)), rng.standard_normal((8, 8))
     b1, b2 = rng.standard_normal(8), rng.standard_normal(8)
-    H, hmask, f1, f2 = ops.project_fwd(_t(x, dev), _t(W, dev), _t(a1, dev), _t(a2, dev), _t(b1, dev),
+    H, f1, f2 = ops.project_fwd(_t(x, dev), _t(W, dev), _t(a1, dev), _t(a2, dev), _t(b1, dev),
                                        _t(b2, dev))
     Href = x @ W
-    assert hmask is None
     assert np.abs(H.cpu().numpy() - Href).max() < TOL * max(1.0, np.abs(Href).max())
     f1ref = (Href.reshape(n, 8, 8) * a1[None]).sum(-1) + b1
     f2ref = (Href.reshape(n, 8, 8) * a2[None]).sum(-1) + b2
@@ -55,15 +54,15 @@ def test_project_dropout_matches_hash_masks(dev, n, f):
     W = rng.standard_normal((f, 64)) * 0.2
     a1, a2 = rng.standard_normal((8, 8)), rng.standard_normal((8, 8))
     b1, b2 = rng.standard_normal(8), rng.standard_normal(8)
-    H, hmask, f1, _ = ops.project_fwd(_t(x, dev), _t(W, dev), _t(a1, dev), _t(a2, dev), _t(b1, dev),
+    H, f1, _ = ops.project_fwd(_t(x, dev), _t(W, dev), _t(a1, dev), _t(a2, dev), _t(b1, dev),
                                       _t(b2, dev), in_drop=drop, fts_drop=drop, seed=seed, row_offset=off)
     keep = rng_ref.keep_prob32(drop)
     sm = rng_ref.seq_mask(seed, n, f, 8, drop, row_offset=off)
     Href = np.concatenate([(x / keep * sm[k]) @ W[:, 8 * k:8 * k + 8] for k in range(8)], 1)
     assert np.abs(H.cpu().numpy() - Href).max() < TOL * max(1.0, np.abs(Href).max())
     fm = rng_ref.fts_mask(seed, n, 64, drop, row_offset=off)
-    bits = (hmask.cpu().numpy().astype(np.uint64)[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & 1
-    assert np.array_equal(bits.astype(np.float64), fm)          # the keep mask K2 applies
+    bits = H.cpu().numpy().view(np.uint32) & 1                   # keep bits ride in mantissa bit 0
+    assert np.array_equal(bits.astype(np.float64), fm)
     # backward: dW = sum_k masked X^T dH_k
     dH = rng.standard_normal((n, 64))
     dW = ops.project_bwd(_t(x, dev), _t(dH, dev), 8, 8, in_drop=drop, seed=seed, row_offset=off)
@@ -312,12 +311,11 @@ def test_dropout_statistics(dev):
     W[:, ::8] = 1.0                      # column k*8 of head k sums the kept inputs
     z8 = torch.zeros((8, 8), device=dev)
     z = torch.zeros(8, device=dev)
-    H, hmask, _, _ = ops.project_fwd(x, W, z8, z8, z, z, in_drop=0.6, fts_drop=0.6, seed=12345)
+    H, _, _ = ops.project_fwd(x, W, z8, z8, z, z, in_drop=0.6, fts_drop=0.6, seed=12345)
     kept = H[:, ::8] * 0.4               # = number of kept inputs per (row, head)
     rate = float(kept.sum() / (n * f * 8))
     assert abs(rate - 0.4) < 0.003
-    hm = hmask.cpu().numpy().astype(np.uint64)
-    ones = sum(int(((hm >> np.uint64(b)) & np.uint64(1)).sum()) for b in range(64))
+    ones = int((H.cpu().numpy().view(np.uint32) & 1).sum())
     assert abs(ones / (64.0 * n) - 0.4) < 0.005
     # heads draw different masks
     assert not torch.equal(H[:, 0], H[:, 8])
