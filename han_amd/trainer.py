@@ -17,7 +17,7 @@ from . import layers, ops
 from .base_gattn import TFAdam
 from .dist import NodePartition
 from .gat import HeteGAT_multi
-from .graph import CSRGraph
+from .graph import CSRGraph, as_graph
 
 
 class HANTrainer:
@@ -25,7 +25,7 @@ class HANTrainer:
                  lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
                  part: NodePartition | None = None, patience=100):
         """xs: list of P (N_local,F) feature tensors (this rank's rows);
-        graphs: list of P CSRGraph -- the GLOBAL graphs when `part` is given
+        graphs: list of P CSRGraph (or dense masks / CSR tuples) -- the GLOBAL graphs when `part` is given
         (they are sharded here), else the local==global graphs;
         labels int32 (N_local,) class ids; masks uint8/bool (N_local,)."""
         if not model._built:
@@ -35,6 +35,7 @@ class HANTrainer:
         model.partition = self.part
         dev = model.flat.device
         self.xs = [x.contiguous() for x in xs]
+        graphs = [as_graph(g, dev) for g in graphs]     # dense masks / (rowptr, colidx) accepted
         if self.part is not None:
             sharded = [self.part.shard_graph(g) for g in graphs]
             self.graphs = [s[0] for s in sharded]

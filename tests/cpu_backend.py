@@ -1,0 +1,222 @@
+"""CPU stand-ins for ``han_amd.ops`` -- TEST INFRASTRUCTURE ONLY.
+
+``install()`` monkey-patches the functions of ``han_amd.ops`` with torch-CPU
+restatements of each kernel's CONTRACT (same arguments, same outputs, same
+dropout RNG streams), so that the host logic above the C ABI -- autograd wiring,
+flat parameter/gradient buffers, HANTrainer, NodePartition and its collectives --
+runs under ``gloo`` with world_size 2 on a machine without a GPU.  The product
+never imports this module and has no CPU path of its own.
+
+The formulas are the hand-derived backward of SURVEY.md section 8a; that they
+agree with float64 autograd of the oracle is itself tested (test_host_cpu.py).
+"""
+import numpy as np
+import torch
+
+from tests import rng_ref
+
+D = 64
+SLOPE = 0.2
+
+
+def _f64(t):
+    return t.detach().to(torch.float64)
+
+
+def _rows_of(graph):
+    return torch.repeat_interleave(torch.arange(graph.n_rows), graph.degrees())
+
+
+def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_offset=0):
+    N, F = X.shape
+    K, FP = a1.shape
+    x, w = _f64(X), _f64(W)
+    if in_drop > 0:
+        keep = rng_ref.keep_prob32(in_drop)
+        sm = torch.tensor(rng_ref.seq_mask(seed, N, F, K, in_drop, row_offset))
+        H = torch.cat([(x / keep * sm[k]) @ w[:, k * FP:(k + 1) * FP] for k in range(K)], 1)
+    else:
+        H = x @ w
+    H = H.to(torch.float32)
+    if fts_drop > 0:      # keep bits ride in mantissa bit 0 (han_project_fwd contract)
+        bits = torch.tensor(rng_ref.fts_mask(seed, N, D, fts_drop, row_offset)).to(torch.int32)
+        H = ((H.view(torch.int32) & ~1) | bits).view(torch.float32)
+    hk = _f64(H).view(N, K, FP)
+    f1 = (hk * _f64(a1)[None]).sum(-1) + _f64(b1)
+    f2 = (hk * _f64(a2)[None]).sum(-1) + _f64(b2)
+    return H, f1.to(torch.float32), f2.to(torch.float32)
+
+
+def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0):
+    N, F = X.shape
+    x, d = _f64(X), _f64(dH)
+    if in_drop > 0:
+        keep = rng_ref.keep_prob32(in_drop)
+        sm = torch.tensor(rng_ref.seq_mask(seed, N, F, K, in_drop, row_offset))
+        dW = torch.cat([(x / keep * sm[k]).t() @ d[:, k * FP:(k + 1) * FP] for k in range(K)], 1)
+    else:
+        dW = x.t() @ d
+    return dW.to(torch.float32)
+
+
+def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset):
+    K, FP = a2.shape
+    rows = _rows_of(graph)
+    cols = graph.colidx.long()
+    h = _f64(H_tab)
+    f2 = (h.view(-1, K, FP) * _f64(a2)[None]).sum(-1) + _f64(b2)
+    u = _f64(f1)[rows] + f2[cols]                                  # (E,K)
+    sg = torch.where(u > 0, torch.ones_like(u), torch.full_like(u, SLOPE))
+    e = torch.maximum(u, SLOPE * u)
+    mx = torch.full((graph.n_rows, K), -1e30, dtype=torch.float64)
+    mx = mx.scatter_reduce(0, rows[:, None].expand(-1, K), e, reduce="amax")
+    ex = torch.exp(e - mx[rows])
+    den = torch.zeros((graph.n_rows, K), dtype=torch.float64).index_add(0, rows, ex)
+    alpha = ex / den[rows]
+    lse = mx + torch.log(den)
+    am = torch.ones_like(alpha)
+    if coef_drop > 0:
+        keep = rng_ref.keep_prob32(coef_drop)
+        am = torch.tensor(rng_ref.coef_mask_csr(seed, graph.rowptr.numpy(), graph.colidx.numpy(), K,
+                                                coef_drop, row_offset)) / keep
+    hd = h
+    if fts_drop > 0:
+        keepf = rng_ref.keep_prob32(fts_drop)
+        bits = (H_tab.view(torch.int32) & 1).to(torch.float64)
+        hd = h * bits / keepf
+    return rows, cols, alpha, am, sg, lse, hd
+
+
+def node_attn_fwd(graph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=0.0, fts_drop=0.0,
+                  seed=0, row_offset=0, activation=1):
+    K, FP = a2.shape
+    N = graph.n_rows
+    rows, cols, alpha, am, sg, lse, hd = _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop,
+                                                     seed, row_offset)
+    hk = hd.view(-1, K, FP)[cols]                                    # (E,K,FP)
+    agg = torch.zeros((N, K, FP), dtype=torch.float64).index_add(0, rows, (alpha * am)[:, :, None] * hk)
+    pre = agg.reshape(N, D) + _f64(c)
+    o = torch.where(pre > 0, pre, torch.expm1(pre)) if activation == 1 else pre
+    if out is None:
+        out = torch.empty((N, D), dtype=torch.float32)
+    out.copy_(o.to(torch.float32))
+    saved = None
+    if train:
+        aggp = torch.zeros((N, K, FP), dtype=torch.float64).index_add(
+            0, rows, (alpha * am * sg)[:, :, None] * hk).reshape(N, D)
+        tsum = torch.zeros((N, K), dtype=torch.float64).index_add(0, rows, alpha * sg)
+        empty = graph.degrees() == 0
+        lse = torch.where(empty[:, None], torch.full_like(lse, -1e30), lse)
+        saved = tuple(t.to(torch.float32) for t in (pre, lse, aggp, tsum))
+    return out, saved
+
+
+def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=1, K=8, FP=8):
+    N = pre.shape[0]
+    p = _f64(pre)
+    da = torch.where(p <= 0, torch.exp(p), torch.ones_like(p)) if activation == 1 else torch.ones_like(p)
+    g = _f64(dOut) * da
+    s = (g * (p - _f64(c))).view(N, K, FP).sum(-1)
+    dp = (g * _f64(aggp)).view(N, K, FP).sum(-1)
+    df1 = dp - s * _f64(tsum)
+    stats = torch.stack([_f64(f1), _f64(lse), s, torch.zeros_like(s)], dim=-1)
+    return (g.to(torch.float32), stats.to(torch.float32).contiguous(), df1.to(torch.float32),
+            g.sum(0).to(torch.float32))
+
+
+def node_attn_bwd_cols(graph_t, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=0.0, fts_drop=0.0,
+                       seed=0, src_offset=0, dst_offset=0):
+    K, FP = a1.shape
+    NS = graph_t.n_rows
+    src = _rows_of(graph_t)                       # local source j per transposed edge
+    dst = graph_t.colidx.long()                   # destination i (table index)
+    st = _f64(stats_tab)
+    u = st[dst, :, 0] + _f64(f2)[src]
+    sg = torch.where(u > 0, torch.ones_like(u), torch.full_like(u, SLOPE))
+    alpha = torch.exp(torch.maximum(u, SLOPE * u) - st[dst, :, 1])
+    am = torch.ones_like(alpha)
+    if coef_drop > 0:
+        keep = rng_ref.keep_prob32(coef_drop)
+        KQ = K
+        h = rng_ref.han_hash(seed, rng_ref.STREAM_COEF, (dst.numpy() + dst_offset)[:, None],
+                             (src.numpy() + src_offset)[:, None].astype(np.uint64) * KQ
+                             + np.arange(K)[None, :])
+        thr = np.uint64(int(np.float32(keep) * np.float32(16777216.0)))
+        am = torch.tensor(((h >> np.uint64(8)) < thr).astype(np.float64)) / keep
+    h64 = _f64(H)
+    mk = torch.ones_like(h64)
+    if fts_drop > 0:
+        mk = (H.view(torch.int32) & 1).to(torch.float64) / rng_ref.keep_prob32(fts_drop)
+    hd = (h64 * mk).view(NS, K, FP)
+    gk = _f64(g_tab).view(-1, K, FP)[dst]                          # (E,K,FP)
+    dot = (gk * hd[src]).sum(-1)
+    dl = alpha * sg * (am * dot - st[dst, :, 2])
+    df2 = torch.zeros((NS, K), dtype=torch.float64).index_add(0, src, dl)
+    acc = torch.zeros((NS, K, FP), dtype=torch.float64).index_add(0, src, (alpha * am)[:, :, None] * gk)
+    dH = acc * mk.view(NS, K, FP) + _f64(df1)[:, :, None] * _f64(a1)[None] + df2[:, :, None] * _f64(a2)[None]
+    return dH.reshape(NS, D).to(torch.float32), df2.to(torch.float32)
+
+
+def score_param_bwd(H, df1, df2, K=8, FP=8):
+    hk = _f64(H).view(-1, K, FP)
+    da1 = (_f64(df1)[:, :, None] * hk).sum(0)
+    da2 = (_f64(df2)[:, :, None] * hk).sum(0)
+    return (da1.to(torch.float32), da2.to(torch.float32), _f64(df1).sum(0).to(torch.float32),
+            _f64(df2).sum(0).to(torch.float32))
+
+
+def sem_attn_fwd(M, w_omega, b_omega, u_omega):
+    m = _f64(M)
+    v = torch.tanh(m @ _f64(w_omega) + _f64(b_omega))
+    beta = torch.softmax(v @ _f64(u_omega), dim=-1)
+    return (m * beta[..., None]).sum(1).to(torch.float32), beta.to(torch.float32)
+
+
+def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ):
+    m, w, b, u = (_f64(t).requires_grad_(True) for t in (M, w_omega, b_omega, u_omega))
+    with torch.enable_grad():
+        v = torch.tanh(m @ w + b)
+        z = (m * torch.softmax(v @ u, dim=-1)[..., None]).sum(1)
+        (z * _f64(dZ)).sum().backward()
+    return tuple(t.grad.to(torch.float32) for t in (m, w, b, u))
+
+
+def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False):
+    z, w, b = (_f64(t).requires_grad_(True) for t in (Z, Wc, bc))
+    hc = w.shape[0]
+    with torch.enable_grad():
+        logits = sum(z @ w[i] + b[i] for i in range(hc)) / hc
+        wt = mask.to(torch.float64) * row_weight
+        logp = torch.log_softmax(logits, dim=-1)
+        ce = -logp.gather(1, labels.long()[:, None])[:, 0]
+        loss = (wt * ce).sum()
+        acc = (wt * (logits.argmax(1) == labels.long()).to(torch.float64)).sum()
+        grads = None
+        if backward:
+            loss.backward()
+            grads = (z.grad.to(torch.float32), w.grad.to(torch.float32), b.grad.to(torch.float32))
+    la = torch.stack([loss.detach(), acc]).to(torch.float32)
+    return logits.detach().to(torch.float32), la, grads
+
+
+def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, l2_coef=0.0):
+    g = grad + l2_coef * param
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    param.sub_(lr_t * m / (v.sqrt() + eps))
+
+
+def l2_half_sumsq(param):
+    return (param.double() ** 2).sum().mul(0.5).to(torch.float32).reshape(1)
+
+
+_NAMES = ("project_fwd", "project_bwd", "node_attn_fwd", "node_attn_bwd_rows", "node_attn_bwd_cols",
+          "score_param_bwd", "sem_attn_fwd", "sem_attn_bwd", "classifier_loss", "adam_step",
+          "l2_half_sumsq")
+
+
+def install():
+    """Patch han_amd.ops in THIS process (tests only)."""
+    from han_amd import ops
+    for n in _NAMES:
+        setattr(ops, n, globals()[n])

@@ -1,0 +1,69 @@
+"""Worker for the 2-rank tests: runs `epochs` reference epochs of a node-partitioned
+HANTrainer and dumps (flat params, per-epoch metrics) for rank 0 to compare with
+the single-process run.  Backend gloo (host-staged collectives) so that it runs
+both on CPU (with tests.cpu_backend patched in) and on ONE GPU shared by the ranks."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def build_problem(dev, n=257, f=24, p=2, c=3, seed=5):
+    from han_amd.graph import CSRGraph
+    rng = np.random.default_rng(seed)
+    x = torch.tensor(rng.standard_normal((n, f)), dtype=torch.float32, device=dev)
+    graphs = []
+    for q in range(p):
+        a = rng.random((n, n)) < (0.02 if q == 0 else 0.15)     # directed: exercises the CSC build
+        np.fill_diagonal(a, True)
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(a.sum(1), out=rowptr[1:])
+        graphs.append(CSRGraph.from_arrays(rowptr, np.nonzero(a)[1].astype(np.int32), n, device=dev))
+    labels = torch.tensor(rng.integers(0, c, n), dtype=torch.int32, device=dev)
+    u = rng.random(n)
+    tm = torch.tensor((u < 0.4).astype(np.uint8), device=dev)
+    vm = torch.tensor((u >= 0.6).astype(np.uint8), device=dev)
+    return x, graphs, labels, tm, vm, (n, f, p, c)
+
+
+def run(rank, world, device, epochs, drop, out_path, port, use_cpu_backend):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if use_cpu_backend:
+        from tests import cpu_backend
+        cpu_backend.install()
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from han_amd import rng as hrng
+    from han_amd.dist import NodePartition
+    from han_amd.gat import HeteGAT_multi
+    from han_amd.trainer import HANTrainer
+    dev = torch.device(device)
+    x, graphs, labels, tm, vm, (n, f, p, c) = build_problem(dev)
+    hrng.manual_seed(77)
+    gen = torch.Generator().manual_seed(3)
+    model = HeteGAT_multi().build(p, f, c, device=dev, generator=gen)
+    part = NodePartition(n, rank, world) if world > 1 else None
+    loc = (lambda t: part.local_rows(t).contiguous()) if part is not None else (lambda t: t)
+    tr = HANTrainer(model, [loc(x)] * p, graphs, loc(labels), loc(tm), loc(vm), attn_drop=drop,
+                    ffd_drop=drop, part=part)
+    hist = []
+    for _ in range(epochs):
+        hist.append(tr.reduce_metrics(*tr.epoch()))
+    if rank == 0:
+        np.savez(out_path, flat=model.flat.detach().cpu().numpy(), hist=np.array(hist))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    # python tests/dist_worker.py rank world device epochs drop out port cpu_backend
+    a = sys.argv[1:]
+    run(int(a[0]), int(a[1]), a[2], int(a[3]), float(a[4]), a[5], int(a[6]), a[7] == "1")

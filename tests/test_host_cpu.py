@@ -1,0 +1,224 @@
+"""CPU tests of the host logic above the C ABI (no GPU, no HIP compute): graph
+containers, partitioning, autograd wiring, flat buffers, trainer -- with the
+kernels replaced by tests/cpu_backend.py -- and the product's loud failures."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import han_oracle as ho
+from oracle import han_oracle_torch as ht
+from tests import rng_ref
+from tests.helpers import load_params, make_problem, rel_err
+
+
+@pytest.fixture()
+def cpu_ops(monkeypatch):
+    from han_amd import ops
+    from tests import cpu_backend
+    for n in cpu_backend._NAMES:
+        monkeypatch.setattr(ops, n, getattr(cpu_backend, n))
+    return ops
+
+
+def _cpu_model(prob):
+    from han_amd.gat import HeteGAT_multi
+    model = HeteGAT_multi().build(prob["p"], prob["f"], prob["c"], device="cpu")
+    bp = ht.to_batched(prob["params"])
+    load_params(model, bp)
+    return model, bp
+
+
+def _cpu_graphs(prob):
+    from han_amd.graph import CSRGraph
+    return [CSRGraph.from_bias(torch.tensor(b, dtype=torch.float32)) for b in prob["biases"]]
+
+
+# --------------------------------------------------------------------------- graphs
+def test_csr_from_bias_transpose_and_validation():
+    from han_amd.graph import CSRGraph, as_graph
+    prob = make_problem(3, 30, 4, 1, 3, [0.2])
+    g = CSRGraph.from_bias(torch.tensor(prob["biases"][0]))
+    rp, ci = ho.bias_to_csr(prob["biases"][0])
+    assert np.array_equal(g.rowptr.numpy(), rp) and np.array_equal(g.colidx.numpy(), ci)
+    t = g.transpose()
+    import scipy.sparse as sp
+    a = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(30, 30)).T.tocsr()
+    a.sort_indices()
+    assert np.array_equal(t.rowptr.numpy(), a.indptr) and np.array_equal(t.colidx.numpy(), a.indices)
+    assert t.transpose() is g
+    assert torch.equal(g.to_bias(torch.float64)[0], torch.tensor(prob["biases"][0][0]))
+    assert as_graph((rp, ci)).nnz == g.nnz
+    with pytest.raises(ValueError):
+        CSRGraph(torch.tensor([0, 2]), torch.tensor([0, 1], dtype=torch.int32))       # rowptr dtype
+    with pytest.raises(ValueError):
+        CSRGraph.from_arrays([0, 2], [0, 7], 2)                                       # col out of range
+    with pytest.raises(ValueError):
+        CSRGraph.from_arrays([0, 3], [0, 1], 2)                                       # rowptr[-1] != nnz
+    with pytest.raises(ValueError):
+        CSRGraph.from_bias(torch.zeros(2, 3, 3))                                      # batch must be 1
+    sp_t = torch.sparse_coo_tensor(torch.tensor([[0, 0, 0], [0, 1, 1], [1, 0, 1]]), torch.ones(3), (1, 2, 2))
+    gs = as_graph(sp_t)
+    assert gs.rowptr.tolist() == [0, 1, 3] and gs.colidx.tolist() == [1, 0, 1]
+
+
+def test_partition_shards_cover_the_graph():
+    from han_amd.dist import NodePartition
+    prob = make_problem(4, 41, 4, 1, 3, [0.15])
+    g = _cpu_graphs(prob)[0]
+    gt = g.transpose()
+    for world in (1, 2, 3, 8):
+        rows_seen, cols_seen = [], []
+        for r in range(world):
+            part = NodePartition(41, r, world)
+            assert part.n_table == part.shard * world >= 41
+            rl, cl = part.shard_graph(g)
+            assert rl.n_rows == part.n_local == cl.n_rows and rl.n_cols == part.n_table
+            rows_seen.append(rl.colidx)
+            cols_seen.append(cl.colidx)
+            assert torch.equal(rl.rowptr, g.rowptr[part.row_start:part.row_end + 1] - g.rowptr[part.row_start])
+        assert torch.equal(torch.cat(rows_seen), g.colidx)
+        assert torch.equal(torch.cat(cols_seen), gt.colidx)
+    with pytest.raises(ValueError):
+        NodePartition(10, 3, 2)
+
+
+# ------------------------------------------------------------- backward derivation
+@pytest.mark.parametrize("drop", [0.0, 0.6])
+def test_cpu_backend_gradients_match_oracle(cpu_ops, drop):
+    """The hand-derived backward + the autograd wiring + the flat
+    gradient buffer, against float64 autograd of the oracle."""
+    from han_amd import layers, rng as hrng
+    prob = make_problem(21, 60, 10, 2, 3, [0.08, 0.5])
+    model, bp = _cpu_model(prob)
+    graphs = _cpu_graphs(prob)
+    x = torch.tensor(prob["x"][0], dtype=torch.float32)
+    hrng.manual_seed(5)
+    seeds = [hrng.next_seed() for _ in range(2)]
+    hrng.manual_seed(5)
+    model.zero_grad_flat()
+    M = model.node_level([x, x], graphs, drop, drop, True, 1)
+    Z, _ = layers.SemanticAttention.apply(M, model.w_omega, model.b_omega, model.u_omega)
+    labels = torch.tensor(prob["labels"], dtype=torch.int32)
+    mask = torch.tensor(prob["mask"].astype(np.uint8))
+    loss, acc, logits = layers.ClassifierLoss.apply(Z, model.Wc, model.bc, labels, mask,
+                                                    1.0 / int(prob["mask"].sum()))
+    loss.backward()
+    masks = None
+    keep = 1.0
+    if drop > 0:
+        keep = rng_ref.keep_prob32(drop)
+        masks = []
+        for q in range(2):
+            rp, ci = ho.bias_to_csr(prob["biases"][q])
+            masks.append({"seq": torch.tensor(rng_ref.seq_mask(seeds[q], 60, 10, 8, drop)),
+                          "coef": torch.tensor(rng_ref.coef_mask_csr(seeds[q], rp, ci, 8, drop)),
+                          "fts": torch.tensor(rng_ref.fts_mask(seeds[q], 60, 64, drop))})
+    bpo = {k: v.clone().requires_grad_(True) for k, v in bp.items()}
+    og = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]
+    lg_ref, _, _ = ht.hetegat_forward([torch.tensor(prob["x"][0])] * 2, og, bpo, keep_in=keep,
+                                      keep_coef=keep, masks=masks)
+    loss_ref = ht.masked_softmax_cross_entropy(lg_ref, torch.tensor(prob["onehot"]),
+                                               torch.tensor(prob["mask"]))
+    loss_ref.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    off = 0
+    for k in ht.PARAM_ORDER:
+        g = getattr(model, k).grad
+        assert rel_err(g.numpy(), bpo[k].grad.numpy()) < 1e-4, k
+        n = g.numel()                       # .grad is a view of the flat buffer, in PARAM order
+        assert g.data_ptr() == model.flat_grad[off:off + n].data_ptr()
+        off += n
+    assert off == model.flat.numel()
+
+
+def test_trainer_epochs_match_oracle_on_cpu_backend(cpu_ops):
+    from han_amd.trainer import HANTrainer
+    prob = make_problem(31, 50, 8, 2, 3, [0.1, 0.4])
+    model, bp = _cpu_model(prob)
+    x = torch.tensor(prob["x"][0], dtype=torch.float32)
+    tr = HANTrainer(model, [x, x], _cpu_graphs(prob), torch.tensor(prob["labels"], dtype=torch.int32),
+                    torch.tensor(prob["mask"].astype(np.uint8)), torch.tensor((~prob["mask"]).astype(np.uint8)),
+                    attn_drop=0.0, ffd_drop=0.0)
+    bpo = {k: v.clone() for k, v in bp.items()}
+    st = ht.new_adam_state(bpo)
+    og = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]
+    for _ in range(3):
+        tl, ta, vl, va = tr.epoch()
+        _, vloss, vacc = ht.train_epoch([torch.tensor(prob["x"][0])] * 2, og, bpo, st,
+                                        torch.tensor(prob["onehot"]), torch.tensor(prob["mask"]),
+                                        torch.tensor(~prob["mask"]), keep=1.0)
+        assert abs(float(vl) - vloss) < 1e-5 and abs(float(va) - vacc) < 1e-6
+    for k in ht.PARAM_ORDER:
+        assert np.abs(getattr(model, k).detach().numpy() - bpo[k].numpy()).max() < 1e-5, k
+    # early-stopping bookkeeping of ex_acm3025.py:225-240
+    assert tr.early_stopping(1.0, 0.5) is False and tr.best_state is not None
+    tr.patience = 2
+    assert tr.early_stopping(2.0, 0.1) is False
+    assert tr.early_stopping(2.0, 0.1) is True
+
+
+# -------------------------------------------------------------------- model surface
+def test_model_variables_and_initialisers():
+    from han_amd.gat import HeteGAT_multi
+    g = torch.Generator().manual_seed(0)
+    m = HeteGAT_multi().build(2, 1870, 3, (8,), (8, 1), 128, device="cpu", generator=g)
+    shapes = {k: tuple(getattr(m, k).shape) for k in ht.PARAM_ORDER}
+    assert shapes == {"W": (2, 1870, 64), "a1": (2, 8, 8), "b1": (2, 8), "a2": (2, 8, 8), "b2": (2, 8),
+                      "c": (2, 64), "w_omega": (64, 128), "b_omega": (128,), "u_omega": (128,),
+                      "Wc": (1, 64, 3), "bc": (1, 3)}
+    # 248,419 trainables at F=1870
+    assert m.flat.numel() == 16 * (1870 * 8 + 8 + 1 + 8 + 1 + 8) + (64 * 128 + 128 + 128) + (64 * 3 + 3)
+    assert float(m.W.abs().max()) <= math.sqrt(6.0 / (1870 + 8)) + 1e-7      # glorot-uniform conv1d
+    assert float(m.a1.abs().max()) <= math.sqrt(6.0 / 9) + 1e-7
+    assert float(m.b1.abs().max()) == 0 and float(m.c.abs().max()) == 0 and float(m.bc.abs().max()) == 0
+    assert abs(float(m.w_omega.std()) - 0.1) < 0.01
+    with pytest.raises(NotImplementedError):
+        HeteGAT_multi().build(2, 10, 3, (8, 8), (8, 8, 1), device="cpu")       # multi-layer: not yet
+    with pytest.raises(NotImplementedError):
+        HeteGAT_multi().build(2, 10, 3, (8,), (4, 1), device="cpu")            # K*F' != 64
+
+
+def test_no_cpu_fallback_in_the_product():
+    """The product path must fail loudly on CPU tensors (no silent fallback)."""
+    from han_amd import layers, ops
+    from han_amd.gat import HeteGAT_multi
+    x = torch.zeros(4, 2, 64)
+    with pytest.raises(ValueError, match="GPU"):
+        ops.sem_attn_fwd(x, torch.zeros(64, 128), torch.zeros(128), torch.zeros(128))
+    with pytest.raises(ValueError, match="GPU"):
+        ops.project_fwd(torch.zeros(4, 5), torch.zeros(5, 64), torch.zeros(8, 8), torch.zeros(8, 8),
+                        torch.zeros(8), torch.zeros(8))
+    HeteGAT_multi.reset_default()
+    with pytest.raises(ValueError, match="GPU"):
+        HeteGAT_multi.inference([torch.zeros(1, 4, 5)], 3, 4, False, 0.0, 0.0, [torch.zeros(1, 4, 4)],
+                                [8], [8, 1])                                   # class-level call, as the reference
+    HeteGAT_multi.reset_default()
+    with pytest.raises(ValueError):
+        layers._squeeze_batch(torch.zeros(2, 4, 5))
+
+
+def test_rng_seed_stream_is_deterministic():
+    from han_amd import rng
+    rng.manual_seed(1)
+    a = [rng.next_seed() for _ in range(4)]
+    rng.manual_seed(1)
+    assert a == [rng.next_seed() for _ in range(4)] and len(set(a)) == 4
+    m = rng_ref.seq_mask(a[0], 64, 32, 8, 0.6)
+    assert abs(m.mean() - 0.4) < 0.02 and not np.array_equal(m[0], m[1])
+    assert np.array_equal(m, rng_ref.seq_mask(a[0], 64, 32, 8, 0.6))
+    # global-id keys: a row block of a partition draws the same bits
+    assert np.array_equal(rng_ref.fts_mask(a[1], 10, 64, 0.6, row_offset=7),
+                          rng_ref.fts_mask(a[1], 17, 64, 0.6)[7:])
+
+
+def test_base_gattn_loss_functions():
+    from han_amd.base_gattn import BaseGAttN
+    rng = np.random.default_rng(2)
+    logits, labels = rng.standard_normal((30, 4)), np.eye(4)[rng.integers(0, 4, 30)]
+    mask = rng.random(30) < 0.5
+    a = float(BaseGAttN.masked_softmax_cross_entropy(torch.tensor(logits), torch.tensor(labels), torch.tensor(mask)))
+    assert abs(a - ho.masked_softmax_cross_entropy(logits, labels, mask)) < 1e-12
+    b = float(BaseGAttN.masked_accuracy(torch.tensor(logits), torch.tensor(labels), torch.tensor(mask)))
+    assert abs(b - ho.masked_accuracy(logits, labels, mask)) < 1e-12
