@@ -19,6 +19,15 @@ SOURCES = ("node_attn.hip", "project.hip", "sem_attn.hip", "loss_opt.hip")
 P = c_void_p
 I64 = c_int64
 
+
+class HanRowSplit(ctypes.Structure):
+    """han_row_split_t of include/han_hip.h."""
+    _fields_ = [("split_deg", c_int64), ("n_long", c_int64), ("n_chunks", c_int64),
+                ("long_rows", c_void_p), ("long_ptr", c_void_p), ("chunk_long", c_void_p),
+                ("chunk_start", c_void_p), ("chunk_end", c_void_p), ("workspace", c_void_p),
+                ("workspace_bytes", c_size_t)]
+
+
 # name -> (restype, argtypes); mirrors include/han_hip.h one to one
 SIGNATURES = {
     "han_abi_version": (c_int, []),
@@ -28,13 +37,14 @@ SIGNATURES = {
     "han_project_bwd_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
     "han_project_bwd": (c_int, [P, I64, P, P, P, c_size_t, I64, c_int, c_int, c_int, c_float,
                                 c_uint64, I64, P]),
+    "han_row_split_workspace": (c_size_t, [I64]),
     "han_node_attn_fwd": (c_int, [P, P, P, P, P, P, P, P, I64, P, P, P, P, I64, I64, c_int,
-                                  c_int, c_float, c_float, c_float, c_uint64, I64, c_int, P]),
+                                  c_int, c_float, c_float, c_float, c_uint64, I64, c_int, P, P]),
     "han_node_attn_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
     "han_node_attn_bwd_rows": (c_int, [P, I64, P, P, P, P, P, P, P, P, P, P, P, c_size_t, I64,
                                        c_int, c_int, c_int, P]),
     "han_node_attn_bwd_cols": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, c_int,
-                                       c_float, c_float, c_float, c_uint64, I64, I64, P]),
+                                       c_float, c_float, c_float, c_uint64, I64, I64, P, P]),
     "han_score_param_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
     "han_score_param_bwd": (c_int, [P, P, P, P, P, P, P, P, c_size_t, I64, c_int, c_int, P]),
     "han_sem_attn_fwd": (c_int, [P, P, P, P, P, P, I64, c_int, c_int, c_int, P]),

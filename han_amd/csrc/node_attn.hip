@@ -66,7 +66,17 @@ struct FwdArgs {
     float inv_keep_coef, inv_keep_fts;
     int64_t row_offset;
     int activation;
+    // row splitting for skewed graphs (see HanRowSplit): rows longer than split_deg are
+    // skipped by the main launch and handled by the partial + finish launches
+    int64_t split_deg;
+    int64_t n_long, n_chunks;
+    const int64_t *long_rows, *long_ptr, *chunk_start, *chunk_end;
+    const int32_t *chunk_long;
+    float *split_ws;
 };
+
+constexpr int kFwdChunkStride = 192;   // floats per chunk: acc[64] | accp[64] | m[K] | l[K] | tl[K]
+constexpr int kBwdChunkStride = 80;    // acc[64] | df2[K]
 
 template <bool TRAIN>
 struct RowState {
@@ -154,6 +164,34 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
     st.m = mc;
 }
 
+// normalise, bias, activation (layers.py:35,46) and the training extras
+template <int FP, bool TRAIN>
+__device__ __forceinline__ void write_row(const FwdArgs &a, const int64_t row, const RowState<TRAIN> &st,
+                                          const int q, const int head, const float4_t &c4, const bool writer) {
+    constexpr int K = HAN_D / FP;
+    const float inv = st.l > 0.f ? 1.f / st.l : 0.f;
+    float4_t pv, ov;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        pv[t] = st.acc[t] * inv + c4[t];
+        ov[t] = a.activation == HAN_ACT_ELU ? han_elu(pv[t]) : pv[t];
+    }
+    if (writer) {
+        *reinterpret_cast<float4_t *>(a.out + row * a.out_stride + 4 * q) = ov;
+        if (TRAIN) {
+            float4_t ap;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ap[t] = st.accp[t] * inv;
+            *reinterpret_cast<float4_t *>(a.pre + row * HAN_D + 4 * q) = pv;
+            *reinterpret_cast<float4_t *>(a.aggp + row * HAN_D + 4 * q) = ap;
+            if ((4 * q) % FP == 0) {
+                a.lse[row * K + head] = st.l > 0.f ? st.m + __logf(st.l) : HAN_NEG_BIG;
+                a.tsum[row * K + head] = st.tl * inv;
+            }
+        }
+    }
+}
+
 // One wave per destination row (RPW = 1) or one 16-lane group per row (RPW = 4,
 // for low-degree graphs).  TRAIN also produces pre / lse / aggp / tsum and
 // applies the two dropouts.
@@ -176,7 +214,9 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
         const bool row_ok = row_raw < a.N;
         const int64_t row = row_ok ? row_raw : a.N - 1;
         const int64_t s = a.rowptr[row];
-        const int64_t e = row_ok ? a.rowptr[row + 1] : s;
+        const int64_t e_raw = row_ok ? a.rowptr[row + 1] : s;
+        const bool is_long = e_raw - s > a.split_deg;      // handled by the chunk kernels
+        const int64_t e = is_long ? s : e_raw;
         const float f1h = a.f1[row * K + head];
         const uint32_t gi = (uint32_t)(row + a.row_offset);
         RowState<TRAIN> st;
@@ -222,30 +262,95 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
             }
         }
 
-        // epilogue: normalise, bias, activation (layers.py:35,46)
-        const bool writer = row_ok && (RPW == 4 || g == 0);
-        const float inv = st.l > 0.f ? 1.f / st.l : 0.f;
-        float4_t pv, ov;
+        write_row<FP, TRAIN>(a, row, st, q, head, c4, row_ok && !is_long && (RPW == 4 || g == 0));
+    }
+}
+
+// Split rows, step 1: one wave per chunk of a long row -> un-normalised partial state.
+template <int FP, bool TRAIN, int U>
+__global__ __launch_bounds__(256) void node_attn_fwd_chunk_kernel(const FwdArgs a) {
+    constexpr int K = HAN_D / FP;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, q = lane & 15;
+    const int head = (4 * q) / FP;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
+    const float b2h = a.b2[head];
+    const bool drop_c = TRAIN && a.thr_coef < 16777216u;
+    for (int64_t ch = wave0; ch < a.n_chunks; ch += nwaves) {
+        const int64_t row = a.long_rows[a.chunk_long[ch]];
+        const int64_t s = a.chunk_start[ch], e = a.chunk_end[ch];
+        const float f1h = a.f1[row * K + head];
+        const uint32_t gi = (uint32_t)(row + a.row_offset);
+        RowState<TRAIN> st;
+        st.init();
+        for (int64_t base = s; base < e; base += 64) {
+            const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
+            const int mycol = a.colidx[base + (lane < cnt ? lane : cnt - 1)];
+            for (int it = 0; it * 4 < cnt; it += U) {
+                int j[U];
+                bool valid[U];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            pv[t] = st.acc[t] * inv + c4[t];
-            ov[t] = a.activation == HAN_ACT_ELU ? han_elu(pv[t]) : pv[t];
-        }
-        if (writer) {
-            *reinterpret_cast<float4_t *>(a.out + row * a.out_stride + 4 * q) = ov;
-            if (TRAIN) {
-                float4_t ap;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) ap[t] = st.accp[t] * inv;
-                *reinterpret_cast<float4_t *>(a.pre + row * HAN_D + 4 * q) = pv;
-                *reinterpret_cast<float4_t *>(a.aggp + row * HAN_D + 4 * q) = ap;
-                if ((4 * q) % FP == 0) {
-                    a.lse[row * K + head] = st.l > 0.f ? st.m + __logf(st.l) : HAN_NEG_BIG;
-                    a.tsum[row * K + head] = st.tl * inv;
+                for (int u = 0; u < U; ++u) {
+                    const int idx = (it + u) * 4 + g;
+                    valid[u] = idx < cnt;
+                    j[u] = __shfl(mycol, idx & 63, 64);
                 }
+                consume_edges<FP, TRAIN, U>(a, j, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
+            }
+        }
+        st.merge(16);
+        st.merge(32);
+        if (g == 0) {
+            float *w = a.split_ws + ch * kFwdChunkStride;
+            float4_t v;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = st.acc[t];
+            *reinterpret_cast<float4_t *>(w + 4 * q) = v;
+            if (TRAIN) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = st.accp[t];
+                *reinterpret_cast<float4_t *>(w + 64 + 4 * q) = v;
+            }
+            if ((4 * q) % FP == 0) {
+                w[128 + head] = st.m;
+                w[128 + K + head] = st.l;
+                if (TRAIN) w[128 + 2 * K + head] = st.tl;
             }
         }
     }
+}
+
+// Split rows, step 2: one 16-lane group per long row merges its chunks in order.
+template <int FP, bool TRAIN>
+__global__ __launch_bounds__(256) void node_attn_fwd_finish_kernel(const FwdArgs a) {
+    constexpr int K = HAN_D / FP;
+    const int q = threadIdx.x & 15;
+    const int head = (4 * q) / FP;
+    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (r >= a.n_long) return;
+    const float4_t c4 = *reinterpret_cast<const float4_t *>(a.c + 4 * q);
+    RowState<TRAIN> st;
+    st.init();
+    for (int64_t ch = a.long_ptr[r]; ch < a.long_ptr[r + 1]; ++ch) {
+        const float *w = a.split_ws + ch * kFwdChunkStride;
+        const float4_t v = *reinterpret_cast<const float4_t *>(w + 4 * q);
+        const float m_o = w[128 + head], l_o = w[128 + K + head];
+        const float M = fmaxf(st.m, m_o);
+        const float sa = __expf(st.m - M), sb = __expf(m_o - M);
+        st.l = st.l * sa + l_o * sb;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st.acc[t] = st.acc[t] * sa + v[t] * sb;
+        if (TRAIN) {
+            const float4_t vp = *reinterpret_cast<const float4_t *>(w + 64 + 4 * q);
+            st.tl = st.tl * sa + w[128 + 2 * K + head] * sb;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) st.accp[t] = st.accp[t] * sa + vp[t] * sb;
+        }
+        st.m = M;
+    }
+    write_row<FP, TRAIN>(a, a.long_rows[r], st, q, head, c4, true);
 }
 
 // ---------------------------------------------------------------------------
@@ -326,11 +431,88 @@ struct BwdColsArgs {
     uint32_t seed_lo, seed_hi, thr_coef;
     float inv_keep_coef, inv_keep_fts;
     int64_t src_offset, dst_offset;
+    int64_t split_deg;
+    int64_t n_long, n_chunks;
+    const int64_t *long_rows, *long_ptr, *chunk_start, *chunk_end;
+    const int32_t *chunk_long;
+    float *split_ws;
 };
+
+// per source row: the dropped projected row H~_j (layers.py:32) and its mask/keep factors
+struct SrcRow {
+    float4_t hd;
+    float mk[4];
+    float f2h;
+    uint32_t gj;
+};
+
+template <int FP>
+__device__ __forceinline__ SrcRow load_src(const BwdColsArgs &a, const int64_t src, const int q, const int head) {
+    constexpr int K = HAN_D / FP;
+    SrcRow r;
+    r.gj = (uint32_t)(src + a.src_offset);
+    r.f2h = a.f2[src * K + head];
+    r.hd = *reinterpret_cast<const float4_t *>(a.H + src * HAN_D + 4 * q);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) r.mk[t] = 1.f;
+    if (a.lsb_mask) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            r.mk[t] = (__float_as_uint(r.hd[t]) & 1u) ? a.inv_keep_fts : 0.f;
+            r.hd[t] *= r.mk[t];
+        }
+    }
+    return r;
+}
+
+// gather U destinations i of source j and accumulate  acc += alpha~ g_i,  df += dl_ij
+template <int FP, int U>
+__device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)[U], const bool (&valid)[U],
+                                            const SrcRow &sr, const int q, const int head, const bool drop_c,
+                                            float (&acc)[4], float &dfacc) {
+    constexpr int K = HAN_D / FP;
+    float4_t gv[U], st[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        gv[u] = *reinterpret_cast<const float4_t *>(a.g + (int64_t)i[u] * HAN_D + 4 * q);
+        st[u] = *reinterpret_cast<const float4_t *>(a.stats + ((int64_t)i[u] * K + head) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const float x = st[u][0] + sr.f2h;
+        const float sg = x > 0.f ? 1.f : a.slope;
+        float alpha = __expf(han_lrelu(x, a.slope) - st[u][1]);
+        alpha = valid[u] ? alpha : 0.f;
+        float am = 1.f;
+        if (drop_c) {
+            const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_COEF,
+                                        (uint32_t)((int64_t)i[u] + a.dst_offset),
+                                        sr.gj * (uint32_t)K + (uint32_t)head);
+            am = han_keep(h, a.thr_coef) ? a.inv_keep_coef : 0.f;
+        }
+        const float dot = head_sum<FP>(dot4(gv[u], sr.hd));
+        dfacc += alpha * sg * (am * dot - st[u][2]);
+        const float w = alpha * am;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] += w * gv[u][t];
+    }
+}
+
+template <int FP>
+__device__ __forceinline__ void write_src(const BwdColsArgs &a, const int64_t src, const SrcRow &sr,
+                                          const float (&acc)[4], const float dfacc, const int q, const int head,
+                                          const float4_t &a14, const float4_t &a24) {
+    constexpr int K = HAN_D / FP;
+    const float d1 = a.df1[src * K + head];
+    float4_t o;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t] = acc[t] * sr.mk[t] + d1 * a14[t] + dfacc * a24[t];
+    *reinterpret_cast<float4_t *>(a.dH + src * HAN_D + 4 * q) = o;
+    if ((4 * q) % FP == 0) a.df2[src * K + head] = dfacc;
+}
 
 template <int FP, int RPW, int U>
 __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsArgs a) {
-    constexpr int K = HAN_D / FP;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
     const int head = (4 * q) / FP;
@@ -346,19 +528,10 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
         const bool src_ok = src_raw < a.NS;
         const int64_t src = src_ok ? src_raw : a.NS - 1;
         const int64_t s = a.colptr[src];
-        const int64_t e = src_ok ? a.colptr[src + 1] : s;
-        const uint32_t gj = (uint32_t)(src + a.src_offset);
-        const float f2h = a.f2[src * K + head];
-        // the dropped projected row H~_j = H_j * mask / keep (layers.py:32)
-        float4_t hd = *reinterpret_cast<const float4_t *>(a.H + src * HAN_D + 4 * q);
-        float mk[4] = {1.f, 1.f, 1.f, 1.f};
-        if (a.lsb_mask) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                mk[t] = (__float_as_uint(hd[t]) & 1u) ? a.inv_keep_fts : 0.f;
-                hd[t] *= mk[t];
-            }
-        }
+        const int64_t e_raw = src_ok ? a.colptr[src + 1] : s;
+        const bool is_long = e_raw - s > a.split_deg;
+        const int64_t e = is_long ? s : e_raw;
+        const SrcRow sr = load_src<FP>(a, src, q, head);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         float dfacc = 0.f;
         const int64_t len = e - s;
@@ -375,37 +548,13 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
         for (int64_t it = 0; it < trips; it += U) {
             int i[U];
             bool valid[U];
-            float4_t gv[U], st[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t k = (RPW == 1) ? (it + u) * 4 + g : it + u;
                 valid[u] = k < len;
                 i[u] = len > 0 ? a.rowidx[valid[u] ? s + k : s] : 0;
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                gv[u] = *reinterpret_cast<const float4_t *>(a.g + (int64_t)i[u] * HAN_D + 4 * q);
-                st[u] = *reinterpret_cast<const float4_t *>(a.stats + ((int64_t)i[u] * K + head) * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float x = st[u][0] + f2h;
-                const float sg = x > 0.f ? 1.f : a.slope;
-                float alpha = __expf(han_lrelu(x, a.slope) - st[u][1]);
-                alpha = valid[u] ? alpha : 0.f;
-                float am = 1.f;
-                if (drop_c) {
-                    const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_COEF,
-                                                (uint32_t)((int64_t)i[u] + a.dst_offset),
-                                                gj * (uint32_t)K + (uint32_t)head);
-                    am = han_keep(h, a.thr_coef) ? a.inv_keep_coef : 0.f;
-                }
-                const float dot = head_sum<FP>(dot4(gv[u], hd));
-                dfacc += alpha * sg * (am * dot - st[u][2]);
-                const float w = alpha * am;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] += w * gv[u][t];
-            }
+            bwd_consume<FP, U>(a, i, valid, sr, q, head, drop_c, acc, dfacc);
         }
         if (RPW == 1) {
 #pragma unroll
@@ -415,16 +564,74 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
                 for (int t = 0; t < 4; ++t) acc[t] += __shfl_xor(acc[t], off, 64);
             }
         }
-        const bool writer = src_ok && (RPW == 4 || g == 0);
-        if (writer) {
-            const float d1 = a.df1[src * K + head];
-            float4_t o;
+        if (src_ok && !is_long && (RPW == 4 || g == 0)) write_src<FP>(a, src, sr, acc, dfacc, q, head, a14, a24);
+    }
+}
+
+// Split source rows: one wave per chunk -> partial sums; one 16-lane group per long row adds them.
+template <int FP, int U>
+__global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, q = lane & 15;
+    const int head = (4 * q) / FP;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const bool drop_c = a.thr_coef < 16777216u;
+    for (int64_t ch = wave0; ch < a.n_chunks; ch += nwaves) {
+        const int64_t src = a.long_rows[a.chunk_long[ch]];
+        const int64_t s = a.chunk_start[ch], len = a.chunk_end[ch] - s;
+        const SrcRow sr = load_src<FP>(a, src, q, head);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float dfacc = 0.f;
+        const int64_t trips = (len + 3) >> 2;
+        for (int64_t it = 0; it < trips; it += U) {
+            int i[U];
+            bool valid[U];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) o[t] = acc[t] * mk[t] + d1 * a14[t] + dfacc * a24[t];
-            *reinterpret_cast<float4_t *>(a.dH + src * HAN_D + 4 * q) = o;
-            if ((4 * q) % FP == 0) a.df2[src * K + head] = dfacc;
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = (it + u) * 4 + g;
+                valid[u] = k < len;
+                i[u] = a.rowidx[valid[u] ? s + k : s];
+            }
+            bwd_consume<FP, U>(a, i, valid, sr, q, head, drop_c, acc, dfacc);
+        }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            dfacc += __shfl_xor(dfacc, off, 64);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += __shfl_xor(acc[t], off, 64);
+        }
+        if (g == 0) {
+            float *w = a.split_ws + ch * kBwdChunkStride;
+            float4_t v;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = acc[t];
+            *reinterpret_cast<float4_t *>(w + 4 * q) = v;
+            if ((4 * q) % FP == 0) w[64 + head] = dfacc;
         }
     }
+}
+
+template <int FP>
+__global__ __launch_bounds__(256) void node_attn_bwd_finish_kernel(const BwdColsArgs a) {
+    const int q = threadIdx.x & 15;
+    const int head = (4 * q) / FP;
+    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (r >= a.n_long) return;
+    const float4_t a14 = *reinterpret_cast<const float4_t *>(a.a1 + 4 * q);
+    const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
+    const int64_t src = a.long_rows[r];
+    const SrcRow sr = load_src<FP>(a, src, q, head);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float dfacc = 0.f;
+    for (int64_t ch = a.long_ptr[r]; ch < a.long_ptr[r + 1]; ++ch) {
+        const float *w = a.split_ws + ch * kBwdChunkStride;
+        const float4_t v = *reinterpret_cast<const float4_t *>(w + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] += v[t];
+        dfacc += w[64 + head];
+    }
+    write_src<FP>(a, src, sr, acc, dfacc, q, head, a14, a24);
 }
 
 // ---------------------------------------------------------------------------
@@ -485,6 +692,13 @@ int attn_grid(int64_t units) { return han_grid_for(units, 4, 256 * 8 * 4); }
 // mean degree (E / N) below which a 16-lane group per row beats a wave per row
 constexpr double kLowDegree = 12.0;
 
+bool split_ok(const han_row_split_t *sp) {
+    if (!sp || sp->n_long == 0) return true;
+    return sp->n_long > 0 && sp->n_chunks >= sp->n_long && sp->split_deg > 0 && sp->long_rows && sp->long_ptr &&
+           sp->chunk_long && sp->chunk_start && sp->chunk_end && sp->workspace &&
+           sp->workspace_bytes >= (size_t)sp->n_chunks * kFwdChunkStride * sizeof(float);
+}
+
 }  // namespace
 
 #define HAN_DISPATCH_FP(FPV, ...)                                \
@@ -501,9 +715,10 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
                                  const float *c, float *out, int64_t out_stride, float *pre, float *lse,
                                  float *aggp, float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
                                  float coef_drop, float fts_drop, uint64_t seed, int64_t row_offset,
-                                 int activation, void *stream) {
+                                 int activation, const han_row_split_t *split, void *stream) {
     if (!rowptr || !colidx || !H || !f1 || !a2 || !b2 || !c || !out || N < 0 || E < 0 || out_stride < HAN_D)
         return HAN_E_BADARG;
+    if (!split_ok(split)) return HAN_E_BADARG;
     if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
     const bool train = pre || lse || aggp || tsum;
     if (train && !(pre && lse && aggp && tsum)) return HAN_E_BADARG;
@@ -519,6 +734,16 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
     a.inv_keep_fts = 1.f / (1.f - fts_drop);
     a.row_offset = row_offset; a.activation = activation;
+    const bool has_split = split && split->n_long > 0;
+    a.split_deg = has_split ? split->split_deg : INT64_MAX;
+    a.n_long = has_split ? split->n_long : 0;
+    a.n_chunks = has_split ? split->n_chunks : 0;
+    a.long_rows = has_split ? split->long_rows : nullptr;
+    a.long_ptr = has_split ? split->long_ptr : nullptr;
+    a.chunk_long = has_split ? split->chunk_long : nullptr;
+    a.chunk_start = has_split ? split->chunk_start : nullptr;
+    a.chunk_end = has_split ? split->chunk_end : nullptr;
+    a.split_ws = has_split ? (float *)split->workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool low = (double)E < kLowDegree * (double)N;
     HAN_DISPATCH_FP(FP, {
@@ -531,9 +756,24 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
             if (train) node_attn_fwd_kernel<FPC, true, 1, 4><<<grid, 256, 0, st>>>(a);
             else node_attn_fwd_kernel<FPC, false, 1, 4><<<grid, 256, 0, st>>>(a);
         }
+        if (has_split) {
+            const int cgrid = attn_grid(a.n_chunks);
+            const int fgrid = (int)((a.n_long + 15) / 16);
+            if (train) {
+                node_attn_fwd_chunk_kernel<FPC, true, 4><<<cgrid, 256, 0, st>>>(a);
+                node_attn_fwd_finish_kernel<FPC, true><<<fgrid, 256, 0, st>>>(a);
+            } else {
+                node_attn_fwd_chunk_kernel<FPC, false, 4><<<cgrid, 256, 0, st>>>(a);
+                node_attn_fwd_finish_kernel<FPC, false><<<fgrid, 256, 0, st>>>(a);
+            }
+        }
     })
     HAN_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" size_t han_row_split_workspace(int64_t n_chunks) {
+    return (size_t)(n_chunks > 0 ? n_chunks : 0) * kFwdChunkStride * sizeof(float);
 }
 
 extern "C" size_t han_node_attn_bwd_workspace(int64_t N, int K, int FP) {
@@ -568,9 +808,10 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
                                       const float *stats, const float *H, const float *f2, const float *df1, const float *a1, const float *a2,
                                       float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                                       float coef_drop, float fts_drop, uint64_t seed, int64_t src_offset,
-                                      int64_t dst_offset, void *stream) {
+                                      int64_t dst_offset, const han_row_split_t *split, void *stream) {
     if (!colptr || !rowidx || !g || !stats || !H || !f2 || !df1 || !a1 || !a2 || !dH || !df2 || NS < 0 || E < 0)
         return HAN_E_BADARG;
+    if (!split_ok(split)) return HAN_E_BADARG;
     if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
     if (NS == 0) return 0;
@@ -582,11 +823,25 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
     a.inv_keep_fts = 1.f / (1.f - fts_drop);
     a.src_offset = src_offset; a.dst_offset = dst_offset;
+    const bool has_split = split && split->n_long > 0;
+    a.split_deg = has_split ? split->split_deg : INT64_MAX;
+    a.n_long = has_split ? split->n_long : 0;
+    a.n_chunks = has_split ? split->n_chunks : 0;
+    a.long_rows = has_split ? split->long_rows : nullptr;
+    a.long_ptr = has_split ? split->long_ptr : nullptr;
+    a.chunk_long = has_split ? split->chunk_long : nullptr;
+    a.chunk_start = has_split ? split->chunk_start : nullptr;
+    a.chunk_end = has_split ? split->chunk_end : nullptr;
+    a.split_ws = has_split ? (float *)split->workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool low = (double)E < kLowDegree * (double)NS;
     HAN_DISPATCH_FP(FP, {
         if (low) node_attn_bwd_cols_kernel<FPC, 4, 2><<<attn_grid((NS + 3) / 4), 256, 0, st>>>(a);
         else node_attn_bwd_cols_kernel<FPC, 1, 4><<<attn_grid(NS), 256, 0, st>>>(a);
+        if (has_split) {
+            node_attn_bwd_chunk_kernel<FPC, 4><<<attn_grid(a.n_chunks), 256, 0, st>>>(a);
+            node_attn_bwd_finish_kernel<FPC><<<(int)((a.n_long + 15) / 16), 256, 0, st>>>(a);
+        }
     })
     HAN_CHECK_LAUNCH();
     return 0;

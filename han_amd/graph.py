@@ -42,6 +42,7 @@ class CSRGraph:
         self.n_cols = int(n_cols) if n_cols is not None else self.n_rows
         self.nnz = colidx.numel()
         self._t = None
+        self._split = {}
         if validate:
             self.validate()
 
@@ -70,6 +71,36 @@ class CSRGraph:
     def to(self, device) -> "CSRGraph":
         g = CSRGraph(self.rowptr.to(device), self.colidx.to(device), self.n_cols, validate=False)
         return g
+
+    # ---- row splitting for skewed degree distributions ---------------------------
+    def row_split(self, split_deg: int = 8192, chunk: int = 4096):
+        """Rows longer than `split_deg` cut into chunks of `chunk` edges (the
+        han_row_split_t description).  Returns None when no row is that long,
+        else a dict of device tensors; cached per (split_deg, chunk)."""
+        key = (int(split_deg), int(chunk))
+        if key not in self._split:
+            deg = self.degrees()
+            long_rows = torch.nonzero(deg > split_deg).flatten()
+            if long_rows.numel() == 0:
+                self._split[key] = None
+            else:
+                ldeg = deg[long_rows]
+                nch = (ldeg + chunk - 1) // chunk
+                long_ptr = torch.zeros(long_rows.numel() + 1, dtype=torch.int64, device=self.device)
+                torch.cumsum(nch, 0, out=long_ptr[1:])
+                n_chunks = int(long_ptr[-1])
+                chunk_long = torch.repeat_interleave(
+                    torch.arange(long_rows.numel(), device=self.device, dtype=torch.int32), nch)
+                within = torch.arange(n_chunks, device=self.device) - long_ptr[:-1][chunk_long.long()]
+                base = self.rowptr[long_rows][chunk_long.long()]
+                chunk_start = (base + within * chunk).contiguous()
+                chunk_end = torch.minimum(chunk_start + chunk,
+                                          self.rowptr[long_rows + 1][chunk_long.long()]).contiguous()
+                self._split[key] = dict(split_deg=int(split_deg), n_long=int(long_rows.numel()),
+                                        n_chunks=n_chunks, long_rows=long_rows.contiguous(),
+                                        long_ptr=long_ptr, chunk_long=chunk_long.contiguous(),
+                                        chunk_start=chunk_start, chunk_end=chunk_end)
+        return self._split[key]
 
     # ---- transposition (CSC) ------------------------------------------------
     def transpose(self) -> "CSRGraph":

@@ -6,6 +6,8 @@ kernel sees the pointers (the kernels assume validated input).
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -53,6 +55,25 @@ def _chk(t: torch.Tensor, name: str, shape=None, dtype=torch.float32, device=Non
                                         for a, s in zip(t.shape, shape)):
             raise ValueError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
     return t
+
+
+SPLIT_DEG = 8192       # rows longer than this are split into chunks of SPLIT_CHUNK edges
+SPLIT_CHUNK = 4096
+
+
+def _row_split_arg(graph: CSRGraph, tag: str):
+    """ctypes han_row_split_t for `graph` (None when no row needs splitting).
+    Returns (byref-able struct or None, keepalive tuple)."""
+    sp = graph.row_split(SPLIT_DEG, SPLIT_CHUNK)
+    if sp is None:
+        return None, None
+    lib = _lib.load()
+    ws = _ws(lib.han_row_split_workspace(sp["n_chunks"]), graph.device, "split" + tag)
+    st = _lib.HanRowSplit(sp["split_deg"], sp["n_long"], sp["n_chunks"], sp["long_rows"].data_ptr(),
+                          sp["long_ptr"].data_ptr(), sp["chunk_long"].data_ptr(),
+                          sp["chunk_start"].data_ptr(), sp["chunk_end"].data_ptr(), ws.data_ptr(),
+                          ws.numel())
+    return st, (sp, ws)
 
 
 def _check_heads(K: int, FP: int):
@@ -160,6 +181,7 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         tsum = torch.empty((N, K), dtype=torch.float32, device=dev)
         saved = (pre, lse, aggp, tsum)
         ptrs = [pre.data_ptr(), lse.data_ptr(), aggp.data_ptr(), tsum.data_ptr()]
+    split, _keep = _row_split_arg(graph, "f")
     timing = K2_TIMING
     if timing is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -168,7 +190,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         graph.rowptr.data_ptr(), graph.colidx.data_ptr(), H_tab.data_ptr(), f1.data_ptr(),
         a2.data_ptr(), b2.data_ptr(), c.data_ptr(), out.data_ptr(), out.stride(0) if N > 1 else D,
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
-        int(seed), int(row_offset), int(activation), _stream()), "han_node_attn_fwd")
+        int(seed), int(row_offset), int(activation),
+        ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_fwd")
     if timing is not None:
         ev1.record()
         timing.append(("train" if train else "eval", ev0, ev1, N, graph.nnz))
@@ -222,11 +245,13 @@ def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, 
     fts_drop = _check_drop(fts_drop, "fts_drop")
     dH = torch.empty((NS, D), dtype=torch.float32, device=dev)
     df2 = torch.empty((NS, K), dtype=torch.float32, device=dev)
+    split, _keep = _row_split_arg(graph_t, "b")
     _lib.check(lib.han_node_attn_bwd_cols(
         graph_t.rowptr.data_ptr(), graph_t.colidx.data_ptr(), g_tab.data_ptr(),
         stats_tab.data_ptr(), H.data_ptr(), f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
         NS, graph_t.nnz, K, FP, LEAKY_SLOPE, _check_drop(coef_drop, "coef_drop"), fts_drop,
-        int(seed), int(src_offset), int(dst_offset), _stream()), "han_node_attn_bwd_cols")
+        int(seed), int(src_offset), int(dst_offset),
+        ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_bwd_cols")
     return dH, df2
 
 

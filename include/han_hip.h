@@ -64,6 +64,22 @@ int han_project_bwd(const float *X, int64_t ldx, const float *dH, float *dW,
                     void *workspace, size_t workspace_bytes, int64_t N, int F, int K,
                     int FP, float in_drop, uint64_t seed, int64_t row_offset, void *stream);
 
+/* Row splitting for skewed graphs (optional; pass NULL for none).  Rows (sources, in
+ * the backward) with more than split_deg stored entries are skipped by the main
+ * launch; each is cut into chunks of consecutive edges [chunk_start, chunk_end),
+ * one wave per chunk produces a partial state in `workspace`, and a finishing
+ * launch merges a row's chunks in order (deterministic).  chunk_long[c] indexes
+ * long_rows; long_ptr (n_long+1) gives each long row's chunk range.            */
+typedef struct han_row_split {
+    int64_t split_deg, n_long, n_chunks;
+    const int64_t *long_rows, *long_ptr;
+    const int32_t *chunk_long;
+    const int64_t *chunk_start, *chunk_end;
+    void *workspace;
+    size_t workspace_bytes;       /* >= han_row_split_workspace(n_chunks) */
+} han_row_split_t;
+size_t han_row_split_workspace(int64_t n_chunks);
+
 /* ---- K2: node-level attention ---------------------------------------------
  * utils/layers.py:26-35,46 (dense mask form) == :95-118,127 (sparse form) over
  * the stored neighbours only:
@@ -82,7 +98,7 @@ int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float 
                       float *pre, float *lse, float *aggp, float *tsum, int64_t N,
                       int64_t E, int K, int FP, float slope, float coef_drop,
                       float fts_drop, uint64_t seed, int64_t row_offset, int activation,
-                      void *stream);
+                      const han_row_split_t *split, void *stream);
 
 /* Backward, step 1 (row-local): from dOut (N,D; row stride dout_stride) and
  * the saved pre/aggp/tsum/f1/lse compute
@@ -114,7 +130,8 @@ int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const f
                            const float *df1, const float *a1, const float *a2,
                            float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                            float coef_drop, float fts_drop, uint64_t seed,
-                           int64_t src_offset, int64_t dst_offset, void *stream);
+                           int64_t src_offset, int64_t dst_offset,
+                           const han_row_split_t *split, void *stream);
 
 /* Backward, step 3: gradients of the score parameters
  *   da1[k,f] = sum_n df1[n,k] H[n,k,f]   da2 likewise with df2

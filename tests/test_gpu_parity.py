@@ -496,3 +496,31 @@ def test_training_with_dropout_reduces_loss(dev):
             first = float(vl)
     assert float(vl) < 0.97 * first
     assert np.isfinite(float(tl))
+
+
+# ------------------------------------------------------------------- skewed graphs
+@pytest.mark.parametrize("drop", [0.0, 0.6])
+def test_row_split_for_long_rows_matches_oracle(dev, monkeypatch, drop):
+    """Rows longer than SPLIT_DEG go through the chunk + finish kernels (forward
+    and backward gather): same loss and gradients as the oracle, and as the
+    unsplit kernels."""
+    from han_amd import ops, rng as hrng
+    prob = make_problem(77, 300, 20, 2, 3, [0.02, 0.5])     # meta-path 1: ~150 neighbours, hub: 300
+    model, bp = build_model(prob, dev)
+    hrng.manual_seed(123)
+    base_loss, base_grads, base_lg, _ = _gpu_loss_and_grads(model, prob, dev, drop, drop)
+    monkeypatch.setattr(ops, "SPLIT_DEG", 16)
+    monkeypatch.setattr(ops, "SPLIT_CHUNK", 24)
+    hrng.manual_seed(123)
+    loss, grads, lg, _ = _gpu_loss_and_grads(model, prob, dev, drop, drop)
+    x, graphs = gpu_inputs(prob, dev)
+    sp = graphs[1].row_split(16, 24)
+    assert sp is not None and sp["n_long"] > 250 and sp["n_chunks"] > 2 * sp["n_long"]
+    assert np.abs(lg - base_lg).max() < 2e-5 and abs(loss - base_loss) < 2e-5
+    for k in ht.PARAM_ORDER:
+        assert rel_err(grads[k], base_grads[k]) < 2e-4, k
+    if drop == 0.0:
+        loss_ref, gref, lg_ref = _oracle_grads(prob, bp)
+        assert np.abs(lg - lg_ref).max() < TOL
+        for k in ht.PARAM_ORDER:
+            assert rel_err(grads[k], gref[k]) < GTOL, k
