@@ -104,7 +104,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # HAN_FORCE_COLLECTIVES=1 rehearses the RCCL path on a 1-rank group (single-GPU box)
+    use_dist = world > 1 or (os.environ.get("HAN_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -116,7 +118,7 @@ def main():
     rng.manual_seed(2024)
     wl = synth.make_workload(args.workload, device=dev, n_override=args.nodes or None)
     n, p = wl["n"], wl["p"]
-    part = NodePartition(n, rank, world) if world > 1 else None
+    part = NodePartition(n, rank, world) if use_dist else None
     gen = torch.Generator().manual_seed(0)
     model = HeteGAT_multi().build(p, wl["f"], wl["c"], (8,), (8, 1), 128, device=dev, generator=gen)
 
@@ -132,7 +134,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,7 +149,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timing, ops.K2_TIMING = ops.K2_TIMING, None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -196,7 +198,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: N={n} nodes, P={p} meta-paths, "
-                                   f"E={sum(g.nnz for g in trainer.graphs) if world == 1 else 'sharded'} "
+                                   f"E={sum(g.nnz for g in trainer.graphs) if not use_dist else 'sharded'} "
                                    f"edges, F={wl['f']}, K=8 heads x F'=8, A=128, C={wl['c']}",
                        "parallelism": f"node-partition x{world}" if world > 1 else "single GPU",
                        "dropout": "0.6/0.6 (train step)", "optimizer": "TF-form Adam lr 0.005, L2 0.001"},
@@ -209,7 +211,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, n, min(args.cpu_sample, n))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -6,7 +6,8 @@ blocks of ``shard = ceil(N / world)`` rows, so a node's global id is also its
 row in any all-gathered table of ``world * shard`` rows -- ``colidx`` needs no
 remapping.  Exchange steps of one training step:
 
-  forward   all-gather of the projected rows [H~ | f2] per meta-path
+  forward   all-gather of the projected rows H per meta-path (the dropout keep
+            bits travel inside the rows; f2 is recomputed by the consumer)
   backward  all-gather of [g | stats] per meta-path (the transposed-graph pass
             gathers from every destination), then ONE all-reduce of the flat
             parameter-gradient buffer.
@@ -17,6 +18,8 @@ random graph every remote row is needed by someone, so the halo exchange
 degenerates to an all-gather; that is what is implemented.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -41,6 +44,9 @@ class NodePartition:
         self.row_end = min(self.row_start + self.shard, self.n_global)
         self.n_local = self.row_end - self.row_start
         self.n_table = self.shard * self.world     # rows of an all-gathered table
+        # HAN_FORCE_COLLECTIVES=1 runs the collectives even on a 1-rank group (used to
+        # exercise the RCCL calls on a single-GPU box)
+        self.active = self.world > 1 or os.environ.get("HAN_FORCE_COLLECTIVES") == "1"
 
     # ---- graph sharding -------------------------------------------------------
     def shard_graph(self, g: CSRGraph) -> tuple[CSRGraph, CSRGraph]:
@@ -64,8 +70,15 @@ class NodePartition:
     def all_gather_rows(self, local: torch.Tensor) -> torch.Tensor:
         """local (n_local, ...) -> table (world*shard, ...); rows past n_global
         (padding of the last shard) hold zeros and are never indexed."""
-        if self.world == 1:
-            return local
+        return self.all_gather_rows_async(local).wait()
+
+    def all_gather_rows_async(self, local: torch.Tensor) -> "GatheredTable":
+        """Start the all-gather and return a handle; `.wait()` yields the table.
+        Under RCCL the collective runs on the communicator's stream (after the
+        producer kernels already queued on the current stream) and overlaps with
+        whatever is launched before `.wait()`; under gloo it completes here."""
+        if not self.active:
+            return GatheredTable(local, None)
         tail = tuple(local.shape[1:])
         if local.shape[0] != self.shard:
             padded = local.new_zeros((self.shard,) + tail)
@@ -74,16 +87,17 @@ class NodePartition:
             padded = local.contiguous()
         table = local.new_empty((self.n_table,) + tail)
         if self._backend() == "nccl":
-            dist.all_gather_into_tensor(table, padded, group=self.group)
-        else:   # gloo (CPU rehearsal / single-GPU multi-process tests): stage through host
-            src = padded.cpu()
-            parts = [torch.empty_like(src) for _ in range(self.world)]
-            dist.all_gather(parts, src, group=self.group)
-            table.copy_(torch.cat(parts, 0))
-        return table
+            work = dist.all_gather_into_tensor(table, padded, group=self.group, async_op=True)
+            return GatheredTable(table, work, keep=padded)
+        # gloo (CPU rehearsal / single-GPU multi-process tests): stage through host
+        src = padded.cpu()
+        parts = [torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(parts, src, group=self.group)
+        table.copy_(torch.cat(parts, 0))
+        return GatheredTable(table, None)
 
     def all_reduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if not self.active:
             return flat
         if self._backend() == "nccl" or not flat.is_cuda:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
@@ -92,6 +106,19 @@ class NodePartition:
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             flat.copy_(host)
         return flat
+
+
+class GatheredTable:
+    """Handle of an (possibly in-flight) all-gathered table."""
+
+    def __init__(self, table, work, keep=None):
+        self.table, self.work, self.keep = table, work, keep
+
+    def wait(self) -> torch.Tensor:
+        if self.work is not None:
+            self.work.wait()          # the current stream waits for the collective
+            self.work, self.keep = None, None
+        return self.table
 
 
 def _row_block(g: CSRGraph, r0: int, r1: int, n_cols: int) -> CSRGraph:

@@ -63,16 +63,25 @@ class NodeLevelAttention(torch.autograd.Function):
         M = torch.empty((N, P, D), dtype=torch.float32, device=W.device)
         row_offset = part.row_start if part is not None else 0
         saved = []
+        multi = part is not None and part.active
+        # all projections first, each table's all-gather started as soon as it exists:
+        # the exchange of meta-path p+1.. overlaps the node attention of meta-path p
+        proj = []
         for p in range(P):
             seed = int(cfg["seeds"][p])
             H, f1, f2 = ops.project_fwd(xs[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
                                         fts_drop=in_drop, seed=seed, row_offset=row_offset)
-            H_tab = part.all_gather_rows(H) if (part is not None and part.world > 1) else H
+            proj.append((H, f1, f2, part.all_gather_rows_async(H) if multi else None))
+        for p in range(P):
+            H, f1, f2, handle = proj[p]
+            H_tab = handle.wait() if multi else H
             _, sv = ops.node_attn_fwd(graphs[p], H_tab, f1, a2[p], b2[p], c[p], out=M[:, p, :],
-                                      train=train, coef_drop=coef_drop, fts_drop=in_drop, seed=seed,
-                                      row_offset=row_offset, activation=cfg["act"])
+                                      train=train, coef_drop=coef_drop, fts_drop=in_drop,
+                                      seed=int(cfg["seeds"][p]), row_offset=row_offset,
+                                      activation=cfg["act"])
             if train:
                 saved.append((H, f1, f2) + sv)
+        del proj
         ctx.cfg, ctx.xs, ctx.graphs = cfg, xs, graphs
         ctx.saved_per_p = saved
         ctx.in_drop, ctx.coef_drop = in_drop, coef_drop
@@ -95,21 +104,28 @@ class NodeLevelAttention(torch.autograd.Function):
         da1, da2 = torch.empty_like(a1), torch.empty_like(a2)
         db1, db2 = torch.empty_like(b1), torch.empty_like(b2)
         dc = torch.empty_like(c)
+        multi = part is not None and part.active
+        rows = []
+        for p in range(P):      # row-local halves first; their tables go out while we continue
+            H, f1, f2, pre, lse, aggp, tsum = ctx.saved_per_p[p]
+            g, stats, df1, dcp = ops.node_attn_bwd_rows(dM[:, p, :], pre, aggp, tsum, f1, lse, c[p],
+                                                        activation=cfg["act"], K=K, FP=FP)
+            dc[p] = dcp
+            if multi:
+                rows.append((part.all_gather_rows_async(g), part.all_gather_rows_async(stats), df1))
+            else:
+                rows.append((g, stats, df1))
         for p in range(P):
             H, f1, f2, pre, lse, aggp, tsum = ctx.saved_per_p[p]
             seed = int(cfg["seeds"][p])
-            g, stats, df1, dcp = ops.node_attn_bwd_rows(dM[:, p, :], pre, aggp, tsum, f1, lse, c[p],
-                                                        activation=cfg["act"], K=K, FP=FP)
-            if part is not None and part.world > 1:
-                g_tab = part.all_gather_rows(g)
-                stats_tab = part.all_gather_rows(stats)
-            else:
-                g_tab, stats_tab = g, stats
+            g_h, st_h, df1 = rows[p]
+            g_tab, stats_tab = (g_h.wait(), st_h.wait()) if multi else (g_h, st_h)
             dH, df2 = ops.node_attn_bwd_cols(graphs_t[p], g_tab, stats_tab, H, f2, df1, a1[p], a2[p],
                                              coef_drop=ctx.coef_drop, fts_drop=ctx.in_drop, seed=seed,
                                              src_offset=row_offset, dst_offset=0)
+            rows[p] = None
             d1, d2, e1, e2 = ops.score_param_bwd(H, df1, df2, K=K, FP=FP)
-            da1[p], da2[p], db1[p], db2[p], dc[p] = d1, d2, e1, e2, dcp
+            da1[p], da2[p], db1[p], db2[p] = d1, d2, e1, e2
             dW[p] = ops.project_bwd(xs[p], dH, K, FP, in_drop=ctx.in_drop, seed=seed,
                                     row_offset=row_offset)
         ctx.saved_per_p = None

@@ -31,7 +31,7 @@ class HANTrainer:
         if not model._built:
             raise RuntimeError("build the model first (model.build(...))")
         self.model = model
-        self.part = part if (part is not None and part.world > 1) else None
+        self.part = part if (part is not None and part.active) else None
         model.partition = self.part
         dev = model.flat.device
         self.xs = [x.contiguous() for x in xs]

@@ -38,8 +38,14 @@ def run(rank, world, device, epochs, drop, out_path, port, use_cpu_backend):
     if use_cpu_backend:
         from tests import cpu_backend
         cpu_backend.install()
-    if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("HAN_TEST_BACKEND", "gloo")
+    forced = os.environ.get("HAN_FORCE_COLLECTIVES") == "1"
+    if world > 1 or forced:
+        if backend == "nccl":
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     from han_amd import rng as hrng
     from han_amd.dist import NodePartition
     from han_amd.gat import HeteGAT_multi
@@ -49,7 +55,7 @@ def run(rank, world, device, epochs, drop, out_path, port, use_cpu_backend):
     hrng.manual_seed(77)
     gen = torch.Generator().manual_seed(3)
     model = HeteGAT_multi().build(p, f, c, device=dev, generator=gen)
-    part = NodePartition(n, rank, world) if world > 1 else None
+    part = NodePartition(n, rank, world) if (world > 1 or forced) else None
     loc = (lambda t: part.local_rows(t).contiguous()) if part is not None else (lambda t: t)
     tr = HANTrainer(model, [loc(x)] * p, graphs, loc(labels), loc(tm), loc(vm), attn_drop=drop,
                     ffd_drop=drop, part=part)
@@ -58,7 +64,7 @@ def run(rank, world, device, epochs, drop, out_path, port, use_cpu_backend):
         hist.append(tr.reduce_metrics(*tr.epoch()))
     if rank == 0:
         np.savez(out_path, flat=model.flat.detach().cpu().numpy(), hist=np.array(hist))
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

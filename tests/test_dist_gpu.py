@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(world, epochs, drop, out, port):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _launch(world, epochs, drop, out, port, extra_env=None):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r),
                                str(world), "cuda:0", str(epochs), str(drop), out, str(port), "0"],
                               env=env, cwd=ROOT) for r in range(world)]
@@ -32,3 +32,15 @@ def test_two_ranks_match_single_process(dev, tmp_path, drop):
     # identical algorithm, different summation order in the cross-rank reductions
     assert np.abs(a["flat"] - b["flat"]).max() < 2e-5
     assert np.abs(a["hist"] - b["hist"]).max() < 2e-5
+
+
+def test_rccl_collectives_on_a_one_rank_group(dev, tmp_path):
+    """The RCCL code path (backend nccl: all_gather_into_tensor async + wait,
+    all_reduce of the flat gradients, barrier) on a 1-rank communicator -- the
+    only way to execute those calls on a single-GPU box."""
+    one, forced = str(tmp_path / "one.npz"), str(tmp_path / "forced.npz")
+    _launch(1, 2, 0.6, one, 29621)
+    _launch(1, 2, 0.6, forced, 29623, {"HAN_FORCE_COLLECTIVES": "1", "HAN_TEST_BACKEND": "nccl"})
+    a, b = np.load(one), np.load(forced)
+    assert np.abs(a["flat"] - b["flat"]).max() < 1e-6
+    assert np.abs(a["hist"] - b["hist"]).max() < 1e-6
