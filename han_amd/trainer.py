@@ -118,6 +118,22 @@ class HANTrainer:
         self.curr_step += 1
         return self.curr_step == self.patience
 
+    def save_checkpoint(self, path):
+        """saver.save(sess, checkpt_file) (ex_acm3025.py:229) -- plus the optimiser
+        state, which the reference does not keep."""
+        torch.save({"flat": self.model.flat.detach().cpu(), "opt": {
+            "t": self.opt.t, "m": self.opt.m.cpu(), "v": self.opt.v.cpu()},
+            "shape": (self.model.P, self.model.F, self.model.K, self.model.FP, self.model.A,
+                      self.model.C, self.model.HC)}, path)
+
+    def load_checkpoint(self, path):
+        ck = torch.load(path, weights_only=True)
+        m = self.model
+        if tuple(ck["shape"]) != (m.P, m.F, m.K, m.FP, m.A, m.C, m.HC):
+            raise ValueError("checkpoint was written for a different model shape")
+        m.flat.copy_(ck["flat"])
+        self.opt.load_state_dict(ck["opt"])
+
     def restore_best(self):
         """saver.restore(sess, checkpt_file) (ex_acm3025.py:247)."""
         if self.best_state is not None:

@@ -222,3 +222,28 @@ def test_base_gattn_loss_functions():
     assert abs(a - ho.masked_softmax_cross_entropy(logits, labels, mask)) < 1e-12
     b = float(BaseGAttN.masked_accuracy(torch.tensor(logits), torch.tensor(labels), torch.tensor(mask)))
     assert abs(b - ho.masked_accuracy(logits, labels, mask)) < 1e-12
+
+
+def test_evaluate_and_checkpoint(cpu_ops, tmp_path):
+    from han_amd import evaluate
+    from han_amd.trainer import HANTrainer
+    rng = np.random.default_rng(0)
+    y = rng.integers(0, 3, 300)
+    x = np.eye(3)[y] * 3 + rng.standard_normal((300, 3)) * 0.3      # separable embeddings
+    knn = evaluate.my_KNN(x, np.eye(3)[y], time=2, seed=0, verbose=False)
+    assert set(knn) == {0.2, 0.4, 0.6, 0.8} and all(v[0] > 0.95 and v[1] > 0.95 for v in knn.values())
+    nmi, ari = evaluate.my_Kmeans(x, y, k=3, time=2, seed=0, verbose=False)
+    assert nmi > 0.9 and ari > 0.9
+    prob = make_problem(41, 30, 6, 1, 3, [0.2])
+    model, _ = _cpu_model(prob)
+    xt = torch.tensor(prob["x"][0], dtype=torch.float32)
+    tr = HANTrainer(model, [xt], _cpu_graphs(prob), torch.tensor(prob["labels"], dtype=torch.int32),
+                    torch.tensor(prob["mask"].astype(np.uint8)), attn_drop=0.0, ffd_drop=0.0)
+    tr.epoch()
+    path = str(tmp_path / "ck.pt")
+    tr.save_checkpoint(path)
+    snap, t = model.flat.clone(), tr.opt.t
+    tr.epoch()
+    assert not torch.equal(snap, model.flat)
+    tr.load_checkpoint(path)
+    assert torch.equal(snap, model.flat) and tr.opt.t == t
