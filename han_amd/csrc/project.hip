@@ -39,86 +39,139 @@ struct ProjFwdArgs {
 template <int FP>
 struct HeadsPerTile { static constexpr int value = FP >= 16 ? 1 : 16 / FP; };
 
-template <int FP, bool DROP>
+// MT = 16-row MFMA tiles per wave (block = 64*MT rows); VEC = 16-byte X loads
+// (needs F % 4 == 0, ldx % 4 == 0 and a 16-byte aligned X).  With dropout every
+// head a tile covers gets its own accumulator: the A fragment is masked per head
+// and the columns of the other heads are simply not read back.
+template <int FP, bool DROP, int MT, bool VEC>
 __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
     constexpr int K = HAN_D / FP;
     constexpr int KP = (K + 1) / 2;   // head pairs: one 32-bit hash = two 16-bit draws
-    constexpr int HPT = HeadsPerTile<FP>::value;
-    __shared__ float Xs[BM * XS_LD];
+    constexpr int HPT = DROP ? HeadsPerTile<FP>::value : 1;
+    constexpr int BMR = 64 * MT;      // rows per block
+    constexpr int XL = (BMR * BK) / 256;   // X elements per thread per tile
+    __shared__ float Xs[BMR * XS_LD];
     __shared__ float Ws[BK * WS_LD];
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int64_t row0 = (int64_t)blockIdx.x * BMR;
 
-    f32x4 acc[4];
+    f32x4 acc[MT][4][HPT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int hh = 0; hh < HPT; ++hh) acc[m][t][hh] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float xr[8], wr[8];
+    float xr[XL];
+    float4_t wr4[2];
     auto load_tile = [&](int k0) {
+        if (VEC) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < XL / 4; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx >> 3, c4 = (idx & 7) * 4;
+                const int64_t row = row0 + r;
+                float4_t v = {0.f, 0.f, 0.f, 0.f};
+                if (row < a.N && k0 + c4 < a.F) v = *reinterpret_cast<const float4_t *>(a.X + row * a.ldx + k0 + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xr[4 * i + e] = v[e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XL; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx >> 5, cc = idx & 31;
+                const int64_t row = row0 + r;
+                xr[i] = (row < a.N && k0 + cc < a.F) ? a.X[row * a.ldx + k0 + cc] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
-            const int r = idx >> 5, cc = idx & 31;
-            const int64_t row = row0 + r;
-            const int k = k0 + cc;
-            xr[i] = (row < a.N && k < a.F) ? a.X[row * a.ldx + k] : 0.f;
-            const int wr_r = idx >> 6, wr_c = idx & 63;
-            const int kw = k0 + wr_r;
-            wr[i] = kw < a.F ? a.W[(int64_t)kw * HAN_D + wr_c] : 0.f;
+            const int kw = k0 + (idx >> 4);
+            wr4[i] = kw < a.F ? *reinterpret_cast<const float4_t *>(a.W + (int64_t)kw * HAN_D + (idx & 15) * 4)
+                              : (float4_t){0.f, 0.f, 0.f, 0.f};
         }
     };
     load_tile(0);
-    const uint32_t nglob = (uint32_t)(row0 + 16 * w + l15 + a.row_offset);
     for (int k0 = 0; k0 < a.F; k0 += BK) {
         __syncthreads();   // previous tile's fragment reads are done
+        if (VEC) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < XL / 4; ++i) {
+                const int idx = tid + 256 * i;
+                float *dst = Xs + (idx >> 3) * XS_LD + (idx & 7) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[e] = xr[4 * i + e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XL; ++i) {
+                const int idx = tid + 256 * i;
+                Xs[(idx >> 5) * XS_LD + (idx & 31)] = xr[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
-            Xs[(idx >> 5) * XS_LD + (idx & 31)] = xr[i];
-            Ws[(idx >> 6) * WS_LD + (idx & 63)] = wr[i];
+            *reinterpret_cast<float4_t *>(Ws + (idx >> 4) * WS_LD + (idx & 15) * 4) = wr4[i];
         }
         __syncthreads();
         if (k0 + BK < a.F) load_tile(k0 + BK);   // in flight under the MFMAs
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
-            const float av = Xs[(16 * w + l15) * XS_LD + kk + l4];
-            uint32_t kglob = (uint32_t)(k0 + kk + l4);
+            float bv[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float bv = Ws[(kk + l4) * WS_LD + 16 * t + l15];
-                if (!DROP) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
-                } else {
+            for (int t = 0; t < 4; ++t) bv[t] = Ws[(kk + l4) * WS_LD + 16 * t + l15];
+            const uint32_t kglob = (uint32_t)(k0 + kk + l4);
 #pragma unroll
-                    for (int hh = 0; hh < HPT; ++hh) {
-                        const int head = (16 * t) / FP + hh;
-                        // one hash serves the two heads of a pair (identical calls are CSE'd)
-                        const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob,
-                                                    kglob * (uint32_t)KP + (uint32_t)(head >> 1));
-                        const float am = han_keep16(h, head & 1, a.thr_in) ? av : 0.f;
-                        const float bm = (HPT == 1 || (l15 / FP) == hh) ? bv : 0.f;
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, acc[t], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) {
+                const int lr = 16 * (w * MT + m) + l15;
+                const float av = Xs[lr * XS_LD + kk + l4];
+                const uint32_t nglob = (uint32_t)(row0 + lr + a.row_offset);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (!DROP) {
+                        acc[m][t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[m][t][0], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int hh = 0; hh < HPT; ++hh) {
+                            const int head = (16 * t) / FP + hh;
+                            // one hash serves the two heads of a pair (identical calls are CSE'd)
+                            const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob,
+                                                        kglob * (uint32_t)KP + (uint32_t)(head >> 1));
+                            const float am = han_keep16(h, head & 1, a.thr_in) ? av : 0.f;
+                            acc[m][t][hh] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bv[t], acc[m][t][hh], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
     }
     // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const int myhh = HPT > 1 ? l15 / FP : 0;   // which head accumulator holds this lane's column
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = row0 + 16 * w + l4 * 4 + r;
-            float v = DROP ? acc[t][r] * a.inv_keep_in : acc[t][r];
-            if (a.thr_fts < 16777216u) {
-                // projected-row dropout (layers.py:31-32): the keep bit rides in mantissa bit 0
-                const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_FTS,
-                                            (uint32_t)(row + a.row_offset), (uint32_t)(16 * t + l15));
-                v = __uint_as_float((__float_as_uint(v) & ~1u) | (han_keep(h, a.thr_fts) ? 1u : 0u));
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 16 * (w * MT + m) + l4 * 4 + r;
+                float v = acc[m][t][0][r];
+#pragma unroll
+                for (int hh = 1; hh < HPT; ++hh) v = (myhh == hh) ? acc[m][t][hh][r] : v;
+                if (DROP) v *= a.inv_keep_in;
+                if (a.thr_fts < 16777216u) {
+                    // projected-row dropout (layers.py:31-32): the keep bit rides in mantissa bit 0
+                    const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_FTS,
+                                                (uint32_t)(row + a.row_offset), (uint32_t)(16 * t + l15));
+                    v = __uint_as_float((__float_as_uint(v) & ~1u) | (han_keep(h, a.thr_fts) ? 1u : 0u));
+                }
+                if (row < a.N) a.H[row * HAN_D + 16 * t + l15] = v;
             }
-            if (row < a.N) a.H[row * HAN_D + 16 * t + l15] = v;
         }
     }
 }
@@ -300,10 +353,17 @@ extern "C" int han_project_fwd(const float *X, int64_t ldx, const float *W, cons
     a.thr_fts = fts_drop > 0.f ? han_keep_threshold(1.f - fts_drop) : 16777216u;
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
-    const int grid = (int)((N + BM - 1) / BM);
+    const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
+    constexpr int MT = 2;
+    const int grid = (int)((N + 64 * MT - 1) / (64 * MT));
     HAN_DISPATCH_FP(FP, {
-        if (in_drop > 0.f) project_fwd_kernel<FPC, true><<<grid, 256, 0, st>>>(a);
-        else project_fwd_kernel<FPC, false><<<grid, 256, 0, st>>>(a);
+        if (in_drop > 0.f) {
+            if (vec) project_fwd_kernel<FPC, true, MT, true><<<grid, 256, 0, st>>>(a);
+            else project_fwd_kernel<FPC, true, MT, false><<<grid, 256, 0, st>>>(a);
+        } else {
+            if (vec) project_fwd_kernel<FPC, false, MT, true><<<grid, 256, 0, st>>>(a);
+            else project_fwd_kernel<FPC, false, MT, false><<<grid, 256, 0, st>>>(a);
+        }
     })
     HAN_CHECK_LAUNCH();
     ScoreArgs s;

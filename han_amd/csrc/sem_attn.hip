@@ -35,9 +35,10 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float fast_tanh(float x) {
-    // 1 - 2/(1+e^{2x}); absolute error ~1e-7, saturates cleanly at +-1
+    // 1 - 2/(1+e^{2x}) with v_exp_f32 + v_rcp_f32 (a plain or "fast" division expands to
+    // a ~10-instruction div_scale/div_fmas sequence); absolute error ~2e-7, saturates at +-1
     const float e = __expf(2.f * x);
-    return 1.f - __fdividef(2.f, 1.f + e);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
 }
 
 constexpr int ROWS = 64;   // rows per block iteration (4 waves x 16)
@@ -116,6 +117,116 @@ __global__ __launch_bounds__(256) void sem_attn_fwd_kernel(const float *__restri
         }
         // no second barrier: the next iteration writes the other score buffer, and
         // the barrier inside it orders this iteration's reads before the reuse after.
+    }
+}
+
+// Forward for P in {1,2,4} (P divides 4): the P rows of a node sit in ONE 16-lane
+// group of the accumulator layout (rows 4*l4 .. 4*l4+3), so the per-node softmax
+// and the weighted sum finish inside the group -- no LDS exchange, no barrier; each
+// wave streams its own 16-row tiles.
+template <int CA, int P, bool WREG>
+__global__ __launch_bounds__(256) void sem_attn_fwd_wave_kernel(const float *__restrict__ M, const float *Wg,
+                                                                const float *bw, const float *uw, float *Z,
+                                                                float *beta, int64_t N) {
+    constexpr int A = 64 * CA;
+    constexpr int TA = A / 16;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // Womega lives in registers for the whole kernel: B fragment of k-step ks, column
+    // tile t is W[4ks + l4][16t + l15]  (16*TA VGPRs; no LDS traffic in the MFMA loop)
+    constexpr int WLD = A + 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float wf[WREG ? 16 : 1][TA];
+    if (WREG) {
+#pragma unroll
+        for (int ks = 0; ks < (WREG ? 16 : 1); ++ks)
+#pragma unroll
+            for (int t = 0; t < TA; ++t) wf[ks][t] = Wg[(4 * ks + l4) * A + 16 * t + l15];
+    } else {
+        for (int i = threadIdx.x; i < 64 * A; i += 256) smem[(i / A) * WLD + (i % A)] = Wg[i];
+        __syncthreads();
+    }
+    float bcol[TA], ucol[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        bcol[t] = bw[16 * t + l15];
+        ucol[t] = uw[16 * t + l15];
+    }
+    const int64_t R = N * P;
+    const int64_t ntiles = (R + 15) / 16;
+    const int64_t tstride = (int64_t)gridDim.x * 4;
+    float afrag[16];       // A fragments of the current tile, loaded one tile ahead
+    {
+        const int64_t t0 = (int64_t)blockIdx.x * 4 + w;
+        const int64_t ra = t0 * 16 + l15 < R ? t0 * 16 + l15 : R - 1;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) afrag[ks] = M[ra * 64 + l4 + 4 * ks];
+    }
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += tstride) {
+        const int64_t r0 = tile * 16;
+        f32x4 acc[TA];
+#pragma unroll
+        for (int t = 0; t < TA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float anext[16];
+        {
+            const int64_t rn = (tile + tstride) * 16 + l15;
+            const float *mnext = M + (rn < R ? rn : R - 1) * 64 + l4;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) anext[ks] = mnext[4 * ks];   // in flight under the MFMAs
+        }
+        // the 4 rows of this lane group as whole rows (lane = 4 features), for the weighted
+        // sum after the softmax: issued now so that their latency hides under the MFMAs
+        float4_t mz[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t row = r0 + 4 * l4 + rr;
+            mz[rr] = *reinterpret_cast<const float4_t *>(M + (row < R ? row : R - 1) * 64 + 4 * l15);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                const float bfrag = WREG ? wf[WREG ? ks : 0][t] : smem[(4 * ks + l4) * WLD + 16 * t + l15];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], bfrag, acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) afrag[ks] = anext[ks];
+        float sc[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < TA; ++t) s += fast_tanh(acc[t][reg] + bcol[t]) * ucol[t];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+            sc[reg] = s;     // every lane of the group holds the score of row 4*l4 + reg
+        }
+#pragma unroll
+        for (int k = 0; k < 4 / P; ++k) {       // the 4/P nodes of this lane group
+            const int64_t row = r0 + 4 * l4 + k * P;
+            if (row < R) {
+                float mx = sc[k * P];
+#pragma unroll
+                for (int p = 1; p < P; ++p) mx = fmaxf(mx, sc[k * P + p]);
+                float e[P], den = 0.f;
+#pragma unroll
+                for (int p = 0; p < P; ++p) { e[p] = __expf(sc[k * P + p] - mx); den += e[p]; }
+                const float inv = 1.f / den;
+                float4_t z = {0.f, 0.f, 0.f, 0.f};
+                float mine = 0.f;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const float bp = e[p] * inv;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) z[c] += bp * mz[k * P + p][c];
+                    mine = (l15 == p) ? bp : mine;
+                }
+                const int64_t node = row / P;
+                *reinterpret_cast<float4_t *>(Z + node * 64 + 4 * l15) = z;
+                if (l15 < P) beta[node * P + l15] = mine;
+            }
+        }
     }
 }
 
@@ -292,6 +403,179 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_kernel(const float *__restri
     for (int i = threadIdx.x; i < 64 * A + 2 * A; i += 256) out[i] = red[i];
 }
 
+// Backward for P in {1,2,4}: as in the forward, the P rows of a node share one
+// 16-lane group of the accumulator layout, so d beta / d s are formed inside the
+// group (lane = 4 features of a row) and the whole tile flow G1 -> dpre -> G3 -> G2
+// is wave-local: no block barrier in the main loop.
+template <int CA, int P>
+__global__ __launch_bounds__(256) void sem_attn_bwd_wave_kernel(const float *__restrict__ M, const float *Wg,
+                                                                const float *bw, const float *uw,
+                                                                const float *beta, const float *dZ, float *dM,
+                                                                float *slab, int64_t N) {
+    constexpr int A = 64 * CA;
+    constexpr int TA = A / 16;
+    constexpr int WLD1 = A + 16;
+    constexpr int WLD2 = A + 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *W1 = smem;                         // [64][WLD1]
+    float *W2 = W1 + 64 * WLD1;               // [64][WLD2]
+    float *dp = W2 + 64 * WLD2;               // [4 waves][16][WLD2]
+    for (int i = threadIdx.x; i < 64 * A; i += 256) {
+        const float v = Wg[i];
+        W1[(i / A) * WLD1 + (i % A)] = v;
+        W2[(i / A) * WLD2 + (i % A)] = v;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    float bcol[TA], ucol[TA], du[TA], db[TA];
+    f32x4 dW[4][TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        bcol[t] = bw[16 * t + l15];
+        ucol[t] = uw[16 * t + l15];
+        du[t] = 0.f;
+        db[t] = 0.f;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) dW[ft][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float *mydp = dp + w * 16 * WLD2;
+    __syncthreads();
+    const int64_t R = N * P;
+    const int64_t ntiles = (R + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = tile * 16;
+        const int64_t g0 = r0 + 4 * l4;           // first row of this lane group
+        // ---- d beta, d s inside the lane group (lane = features 4*l15 .. 4*l15+3)
+        float ds[4], bt[4];
+        {
+            float dbt[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int64_t row = g0 + rr;
+                const bool ok = row < R;
+                const int64_t rc = ok ? row : R - 1;
+                const float4_t mv = *reinterpret_cast<const float4_t *>(M + rc * 64 + 4 * l15);
+                const float4_t dz = *reinterpret_cast<const float4_t *>(dZ + (rc / P) * 64 + 4 * l15);
+                float d = mv[0] * dz[0] + mv[1] * dz[1] + mv[2] * dz[2] + mv[3] * dz[3];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) d += __shfl_xor(d, o, 64);
+                dbt[rr] = d;
+                bt[rr] = ok ? beta[rc] : 0.f;        // beta is (N,P) flat == row index
+            }
+#pragma unroll
+            for (int k = 0; k < 4 / P; ++k) {
+                float S = 0.f;
+#pragma unroll
+                for (int p2 = 0; p2 < P; ++p2) S += bt[k * P + p2] * dbt[k * P + p2];
+#pragma unroll
+                for (int p2 = 0; p2 < P; ++p2) ds[k * P + p2] = bt[k * P + p2] * (dbt[k * P + p2] - S);
+            }
+        }
+        // ---- G1: pre = M_tile . Womega
+        f32x4 acc[TA];
+#pragma unroll
+        for (int t = 0; t < TA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            const int64_t ra = r0 + l15 < R ? r0 + l15 : R - 1;
+            const float *mrow = M + ra * 64 + l4;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const float a = mrow[4 * ks];
+                const float *wr = W1 + (4 * ks + l4) * WLD1 + l15;
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wr[16 * t], acc[t], 0, 0, 0);
+            }
+        }
+        // ---- dpre in the accumulator layout (row r = 4*l4 + reg, col a = 16t + l15)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+#pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                const float v = fast_tanh(acc[t][reg] + bcol[t]);
+                const float d = ds[reg] * ucol[t] * (1.f - v * v);
+                du[t] += ds[reg] * v;
+                db[t] += d;
+                acc[t][reg] = d;
+                mydp[(4 * l4 + reg) * WLD2 + 16 * t + l15] = d;
+            }
+        }
+        // ---- G3: dW += M_tile^T . dpre   (k-step `reg` holds rows 4g + reg, g = lane group)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t rg = g0 + reg < R ? g0 + reg : R - 1;     // dpre of a padding row is 0
+            const float *mrow = M + rg * 64 + l15;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const float a = mrow[16 * ft];
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+                    dW[ft][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, acc[t][reg], dW[ft][t], 0, 0, 0);
+            }
+        }
+        // ---- G2: dMx = dpre . Womega^T   (A operand from the wave's LDS tile)
+        f32x4 acc2[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) acc2[ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int ks = 0; ks < A / 4; ++ks) {
+            const float a = mydp[l15 * WLD2 + 4 * ks + l4];
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const float b = W2[(16 * ft + l15) * WLD2 + 4 * ks + l4];
+                acc2[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc2[ft], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t row = g0 + reg;
+            if (row < R) {
+                const int64_t n = row / P;
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) {
+                    const int f = 16 * ft + l15;
+                    dM[row * 64 + f] = acc2[ft][reg] + bt[reg] * dZ[n * 64 + f];
+                }
+            }
+        }
+    }
+    // ---- parameter gradients: lane groups -> waves (LDS) -> slab row
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            du[t] += __shfl_xor(du[t], o, 64);
+            db[t] += __shfl_xor(db[t], o, 64);
+        }
+    }
+    __syncthreads();
+    float *red = smem;   // [64*A] dW | [A] db | [A] du  (fits inside W1)
+    for (int ww = 0; ww < 4; ++ww) {
+        if (w == ww) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int idx = (16 * ft + 4 * l4 + reg) * A + 16 * t + l15;
+                        red[idx] = (ww == 0 ? 0.f : red[idx]) + dW[ft][t][reg];
+                    }
+            if (l4 == 0) {
+#pragma unroll
+                for (int t = 0; t < TA; ++t) {
+                    const int idx = 64 * A + 16 * t + l15;
+                    red[idx] = (ww == 0 ? 0.f : red[idx]) + db[t];
+                    red[idx + A] = (ww == 0 ? 0.f : red[idx + A]) + du[t];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *out = slab + (int64_t)blockIdx.x * (64 * A + 2 * A);
+    for (int i = threadIdx.x; i < 64 * A + 2 * A; i += 256) out[i] = red[i];
+}
+
 constexpr int kSemBwdBlocks = 256;   // one 4-wave block per CU (104 KB of LDS at A = 128)
 
 template <int CA>
@@ -311,6 +595,16 @@ int launch_fwd(const float *M, const float *w, const float *b, const float *u, f
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+    if (P == 1 || P == 2 || P == 4) {
+        constexpr bool WREG = false;
+        const size_t wlds = WREG ? 0 : (size_t)64 * (64 * CA + 16) * sizeof(float);
+        const int grid = han_grid_for(N * P, 64, 256 * (WREG ? 2 : 4));
+        if (P == 1) sem_attn_fwd_wave_kernel<CA, 1, WREG><<<grid, 256, wlds, st>>>(M, w, b, u, Z, beta, N);
+        else if (P == 2) sem_attn_fwd_wave_kernel<CA, 2, WREG><<<grid, 256, wlds, st>>>(M, w, b, u, Z, beta, N);
+        else sem_attn_fwd_wave_kernel<CA, 4, WREG><<<grid, 256, wlds, st>>>(M, w, b, u, Z, beta, N);
+        HAN_CHECK_LAUNCH();
+        return 0;
+    }
     const int NB = ROWS / P;
     const int grid = han_grid_for(N, NB, 256 * 3);
     sem_attn_fwd_kernel<CA><<<grid, 256, lds, st>>>(M, w, b, u, Z, beta, N, P);
@@ -325,6 +619,30 @@ int launch_bwd(const float *M, const float *w, const float *b, const float *u, c
     hipError_t e = hipFuncSetAttribute((const void *)sem_attn_bwd_kernel<CA>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
+    if (P == 1 || P == 2 || P == 4) {
+        const int grid = han_grid_for(N > 0 ? N * P : 1, 64, kSemBwdBlocks);
+        *grid_out = grid;
+        hipError_t e2 = hipSuccess;
+        if (P == 1) {
+            e2 = hipFuncSetAttribute((const void *)sem_attn_bwd_wave_kernel<CA, 1>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e2 == hipSuccess)
+                sem_attn_bwd_wave_kernel<CA, 1><<<grid, 256, lds, st>>>(M, w, b, u, beta, dZ, dM, slab, N);
+        } else if (P == 2) {
+            e2 = hipFuncSetAttribute((const void *)sem_attn_bwd_wave_kernel<CA, 2>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e2 == hipSuccess)
+                sem_attn_bwd_wave_kernel<CA, 2><<<grid, 256, lds, st>>>(M, w, b, u, beta, dZ, dM, slab, N);
+        } else {
+            e2 = hipFuncSetAttribute((const void *)sem_attn_bwd_wave_kernel<CA, 4>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e2 == hipSuccess)
+                sem_attn_bwd_wave_kernel<CA, 4><<<grid, 256, lds, st>>>(M, w, b, u, beta, dZ, dM, slab, N);
+        }
+        if (e2 != hipSuccess) return (int)e2;
+        HAN_CHECK_LAUNCH();
+        return 0;
+    }
     const int NB = ROWS / P;
     const int grid = han_grid_for(N > 0 ? N : 1, NB, kSemBwdBlocks);
     *grid_out = grid;

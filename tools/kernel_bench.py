@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Stand-alone timings of K1 / K3 kernels at the SYN-1M shape (N = 1M, P = 4,
+F = 256): one JSON line per kernel (median of `reps`, HIP events on the launch
+stream).  Used while tuning; `bench.py` is the headline measurement."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from han_amd import ops  # noqa: E402
+
+
+def timeit(fn, reps=7):
+    for _ in range(2):
+        fn()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def main():
+    which = sys.argv[1:] or ["k1", "k3"]
+    dev = torch.device("cuda:0")
+    n, p, f = 1_000_000, 4, 256
+    gen = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: torch.randn(s, device=dev, generator=gen)
+    if "k3" in which:
+        M = rnd(n, p, 64)
+        w, b, u = rnd(64, 128) * 0.1, rnd(128) * 0.1, rnd(128) * 0.1
+        dZ = rnd(n, 64)
+        Z, beta = ops.sem_attn_fwd(M, w, b, u)
+        t = timeit(lambda: ops.sem_attn_fwd(M, w, b, u))
+        fl = 2.0 * n * p * 64 * 128
+        print(json.dumps({"kernel": "sem_attn_fwd", "ms": round(t, 4), "TFLOPs": round(fl / t / 1e9, 1)}))
+        t = timeit(lambda: ops.sem_attn_bwd(M, w, b, u, beta, dZ))
+        print(json.dumps({"kernel": "sem_attn_bwd", "ms": round(t, 4), "TFLOPs": round(3 * fl / t / 1e9, 1)}))
+        del M, dZ, Z, beta
+    if "k1" in which:
+        X = rnd(n, f)
+        W = rnd(f, 64) * 0.1
+        a1, a2, b1, b2 = rnd(8, 8), rnd(8, 8), rnd(8), rnd(8)
+        dH = rnd(n, 64)
+        fl = 2.0 * n * f * 64
+        for drop in (0.0, 0.6):
+            t = timeit(lambda: ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=drop, fts_drop=drop, seed=5))
+            print(json.dumps({"kernel": f"project_fwd drop={drop}", "ms": round(t, 4),
+                              "TFLOPs": round(fl / t / 1e9, 1), "X_GBs": round(n * f * 4 / t / 1e6, 1)}))
+            t = timeit(lambda: ops.project_bwd(X, dH, 8, 8, in_drop=drop, seed=5))
+            print(json.dumps({"kernel": f"project_bwd drop={drop}", "ms": round(t, 4),
+                              "TFLOPs": round(fl / t / 1e9, 1)}))
+
+
+if __name__ == "__main__":
+    main()
