@@ -16,43 +16,54 @@
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------
-// Counter-based dropout RNG.  One 32-bit hash per Bernoulli draw, keyed by
-// (seed, stream, a, b) so that forward and backward -- and any node partition --
-// regenerate the same mask from global ids.  tests/rng_ref.py restates it in
-// NumPy so that the oracle can be fed the identical masks.
-//   stream 0: input-feature dropout  a = global row,  b = f*ceil(K/2) + k/2; TWO 16-bit
-//             draws per hash: head k uses bits [16*(k&1), 16*(k&1)+16)   (layers.py:19)
-//   stream 1: attention dropout      a = global dst i, b = j*K + k  (layers.py:30)
-//   stream 2: projected-row dropout  a = global row j, b = d        (layers.py:32)
+// Counter-based dropout RNG: two rounds of the 32x32->64 multiply-fold ("mum", as in
+// wyhash32) keyed by (seed, stream) over the counter (a, b).  One call costs four
+// integer multiplies and yields 64 bits = FOUR 16-bit Bernoulli draws (keep iff
+// field < keep_prob * 2^16); forward, backward and any node partition regenerate the
+// same mask from global ids.  tests/rng_ref.py restates it in NumPy so that the
+// oracle can be fed the identical masks.  (Measured alternatives: a murmur-style
+// 32-bit hash with two draws per call, and an add/rotate/xor Threefry-2x32 -- both
+// slower in the K1/K2 training kernels.)
+//   stream 0  input-feature dropout (layers.py:19)   a = global row, b = f*ceil(K/4) + k/4,  field k%4
+//   stream 1  attention dropout     (layers.py:30)   a = global dst i, b = j*ceil(K/4) + k/4, field k%4
+//   stream 2  projected-row dropout (layers.py:32)   a = global row j, b = d/4,               field d%4
 // ---------------------------------------------------------------------------
 #define HAN_STREAM_SEQ 0u
 #define HAN_STREAM_COEF 1u
 #define HAN_STREAM_FTS 2u
 
-__host__ __device__ __forceinline__ uint32_t han_hash(uint32_t seed_lo, uint32_t seed_hi,
-                                                      uint32_t stream, uint32_t a, uint32_t b) {
-    uint32_t h = (a * 0x9E3779B1u) ^ (seed_lo + stream * 0x7F4A7C15u);
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13;
-    h ^= b * 0xC2B2AE35u + seed_hi;
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return h;
+struct HanRand64 {
+    uint32_t x, y;
+    // 16-bit field f in [0,4)
+    __host__ __device__ __forceinline__ uint32_t field(int f) const {
+        return (((f & 2) ? y : x) >> (16 * (f & 1))) & 0xFFFFu;
+    }
+};
+
+__host__ __device__ __forceinline__ void han_mum(uint32_t &A, uint32_t &B) {
+    const uint64_t c = (uint64_t)(A ^ 0x53C5CA59u) * (uint64_t)(B ^ 0x74743C1Bu);
+    A = (uint32_t)c;
+    B = (uint32_t)(c >> 32);
 }
 
-// keep iff the top 24 bits are below keep_prob * 2^24
+__host__ __device__ __forceinline__ HanRand64 han_rand64(uint32_t seed_lo, uint32_t seed_hi, uint32_t stream,
+                                                         uint32_t a, uint32_t b) {
+    uint32_t A = a ^ seed_lo, B = b ^ (seed_hi + stream * 0x9E3779B9u);
+    han_mum(A, B);
+    A ^= seed_hi;
+    B ^= seed_lo;
+    han_mum(A, B);
+    HanRand64 r;
+    r.x = A ^ B;          // fold the halves once more so every output bit sees both
+    r.y = B ^ (A >> 15) ^ (A << 17);
+    return r;
+}
+
+// keep iff the 16-bit field is below keep_prob * 2^16 (65536 = keep everything)
 __host__ __device__ __forceinline__ uint32_t han_keep_threshold(float keep_prob) {
-    return (uint32_t)(keep_prob * 16777216.0f);
-}
-__host__ __device__ __forceinline__ bool han_keep(uint32_t h, uint32_t thr) {
-    return (h >> 8) < thr;
-}
-
-// 16-bit draws of stream 0: keep iff the 16-bit field is below keep_prob * 2^16
-__host__ __device__ __forceinline__ uint32_t han_keep_threshold16(float keep_prob) {
     return (uint32_t)(keep_prob * 65536.0f);
 }
-__host__ __device__ __forceinline__ bool han_keep16(uint32_t h, int half, uint32_t thr16) {
-    return ((h >> (16 * half)) & 0xFFFFu) < thr16;
-}
+#define HAN_KEEP_ALL 65536u
 
 __device__ __forceinline__ float han_lrelu(float x, float slope) { return fmaxf(x, slope * x); }
 

@@ -111,7 +111,7 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
                                               const float f1h, const uint32_t gi, const int q, const int head,
                                               const float4_t &a24, const float b2h, const bool drop_c,
                                               RowState<TRAIN> &st) {
-    constexpr int K = HAN_D / FP;
+    constexpr int KQ = (HAN_D / FP + 3) / 4;
     float4_t hv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -141,9 +141,9 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
         float pd = p;
         if (TRAIN) {
             if (drop_c) {   // attention dropout, layers.py:29-30
-                const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
-                                            (uint32_t)j[u] * (uint32_t)K + (uint32_t)head);
-                pd = han_keep(h, a.thr_coef) ? p * a.inv_keep_coef : 0.f;
+                const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
+                                                (uint32_t)j[u] * (uint32_t)KQ + (uint32_t)(head >> 2));
+                pd = rn.field(head & 3) < a.thr_coef ? p * a.inv_keep_coef : 0.f;
             }
             // projected-row dropout, layers.py:31-32 (after the score was taken)
             if (a.lsb_mask) {
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
     const float4_t c4 = *reinterpret_cast<const float4_t *>(a.c + 4 * q);
     const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
     const float b2h = a.b2[head];
-    const bool drop_c = TRAIN && a.thr_coef < 16777216u;
+    const bool drop_c = TRAIN && a.thr_coef < HAN_KEEP_ALL;
     const int64_t nunits = (a.N + RPW - 1) / RPW;   // wave-sized work units
 
     for (int64_t unit = wave0; unit < nunits; unit += nwaves) {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_chunk_kernel(const FwdArgs 
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
     const float b2h = a.b2[head];
-    const bool drop_c = TRAIN && a.thr_coef < 16777216u;
+    const bool drop_c = TRAIN && a.thr_coef < HAN_KEEP_ALL;
     for (int64_t ch = wave0; ch < a.n_chunks; ch += nwaves) {
         const int64_t row = a.long_rows[a.chunk_long[ch]];
         const int64_t s = a.chunk_start[ch], e = a.chunk_end[ch];
@@ -471,6 +471,7 @@ __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)
                                             const SrcRow &sr, const int q, const int head, const bool drop_c,
                                             float (&acc)[4], float &dfacc) {
     constexpr int K = HAN_D / FP;
+    constexpr int KQ = (K + 3) / 4;
     float4_t gv[U], st[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -485,10 +486,10 @@ __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)
         alpha = valid[u] ? alpha : 0.f;
         float am = 1.f;
         if (drop_c) {
-            const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_COEF,
-                                        (uint32_t)((int64_t)i[u] + a.dst_offset),
-                                        sr.gj * (uint32_t)K + (uint32_t)head);
-            am = han_keep(h, a.thr_coef) ? a.inv_keep_coef : 0.f;
+            const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF,
+                                            (uint32_t)((int64_t)i[u] + a.dst_offset),
+                                            sr.gj * (uint32_t)KQ + (uint32_t)(head >> 2));
+            am = rn.field(head & 3) < a.thr_coef ? a.inv_keep_coef : 0.f;
         }
         const float dot = head_sum<FP>(dot4(gv[u], sr.hd));
         dfacc += alpha * sg * (am * dot - st[u][2]);
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
     const int head = (4 * q) / FP;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const bool drop_c = a.thr_coef < 16777216u;
+    const bool drop_c = a.thr_coef < HAN_KEEP_ALL;
     const float4_t a14 = *reinterpret_cast<const float4_t *>(a.a1 + 4 * q);
     const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
     const int64_t nunits = (a.NS + RPW - 1) / RPW;
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsA
     const int head = (4 * q) / FP;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const bool drop_c = a.thr_coef < 16777216u;
+    const bool drop_c = a.thr_coef < HAN_KEEP_ALL;
     for (int64_t ch = wave0; ch < a.n_chunks; ch += nwaves) {
         const int64_t src = a.long_rows[a.chunk_long[ch]];
         const int64_t s = a.chunk_start[ch], len = a.chunk_end[ch] - s;
@@ -730,7 +731,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     a.out = out; a.out_stride = out_stride; a.pre = pre; a.lse = lse; a.aggp = aggp; a.tsum = tsum;
     a.N = N; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-    a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : 16777216u;
+    a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
     a.inv_keep_fts = 1.f / (1.f - fts_drop);
     a.row_offset = row_offset; a.activation = activation;
@@ -819,7 +820,7 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
     a.colptr = colptr; a.rowidx = rowidx; a.g = g; a.stats = stats; a.H = H; a.lsb_mask = fts_drop > 0.f; a.f2 = f2;
     a.df1 = df1; a.a1 = a1; a.a2 = a2; a.dH = dH; a.df2 = df2; a.NS = NS; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-    a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : 16777216u;
+    a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
     a.inv_keep_fts = 1.f / (1.f - fts_drop);
     a.src_offset = src_offset; a.dst_offset = dst_offset;

@@ -30,7 +30,7 @@ struct ProjFwdArgs {
     float *H;
     int64_t N;
     int F;
-    uint32_t seed_lo, seed_hi, thr_in, thr_fts;   // thr_fts < 2^24: stamp keep bits into H
+    uint32_t seed_lo, seed_hi, thr_in, thr_fts;   // thr_fts < 2^16: stamp keep bits into H
     float inv_keep_in;
     int64_t row_offset;
 };
@@ -46,7 +46,7 @@ struct HeadsPerTile { static constexpr int value = FP >= 16 ? 1 : 16 / FP; };
 template <int FP, bool DROP, int MT, bool VEC>
 __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
     constexpr int K = HAN_D / FP;
-    constexpr int KP = (K + 1) / 2;   // head pairs: one 32-bit hash = two 16-bit draws
+    constexpr int KQ = (K + 3) / 4;   // one RNG call = four 16-bit draws = four heads
     constexpr int HPT = DROP ? HeadsPerTile<FP>::value : 1;
     constexpr int BMR = 64 * MT;      // rows per block
     constexpr int XL = (BMR * BK) / 256;   // X elements per thread per tile
@@ -140,10 +140,10 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
 #pragma unroll
                         for (int hh = 0; hh < HPT; ++hh) {
                             const int head = (16 * t) / FP + hh;
-                            // one hash serves the two heads of a pair (identical calls are CSE'd)
-                            const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob,
-                                                        kglob * (uint32_t)KP + (uint32_t)(head >> 1));
-                            const float am = han_keep16(h, head & 1, a.thr_in) ? av : 0.f;
+                            // one call serves four heads (identical calls are CSE'd)
+                            const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob,
+                                                            kglob * (uint32_t)KQ + (uint32_t)(head >> 2));
+                            const float am = rn.field(head & 3) < a.thr_in ? av : 0.f;
                             acc[m][t][hh] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bv[t], acc[m][t][hh], 0, 0, 0);
                         }
                     }
@@ -164,11 +164,12 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
 #pragma unroll
                 for (int hh = 1; hh < HPT; ++hh) v = (myhh == hh) ? acc[m][t][hh][r] : v;
                 if (DROP) v *= a.inv_keep_in;
-                if (a.thr_fts < 16777216u) {
+                if (a.thr_fts < HAN_KEEP_ALL) {
                     // projected-row dropout (layers.py:31-32): the keep bit rides in mantissa bit 0
-                    const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_FTS,
-                                                (uint32_t)(row + a.row_offset), (uint32_t)(16 * t + l15));
-                    v = __uint_as_float((__float_as_uint(v) & ~1u) | (han_keep(h, a.thr_fts) ? 1u : 0u));
+                    const int d = 16 * t + l15;
+                    const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_FTS,
+                                                    (uint32_t)(row + a.row_offset), (uint32_t)(d >> 2));
+                    v = __uint_as_float((__float_as_uint(v) & ~1u) | (rn.field(d & 3) < a.thr_fts ? 1u : 0u));
                 }
                 if (row < a.N) a.H[row * HAN_D + 16 * t + l15] = v;
             }
@@ -235,7 +236,7 @@ struct ProjBwdArgs {
 template <int FP, bool DROP>
 __global__ __launch_bounds__(256) void project_bwd_kernel(const ProjBwdArgs a) {
     constexpr int K = HAN_D / FP;
-    constexpr int KP = (K + 1) / 2;   // head pairs: one 32-bit hash = two 16-bit draws
+    constexpr int KQ = (K + 3) / 4;   // one RNG call = four 16-bit draws = four heads
     constexpr int HPT = HeadsPerTile<FP>::value;
     __shared__ float Xs[BN * TS_LD];
     __shared__ float Gs[BN * TS_LD];
@@ -289,9 +290,9 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const ProjBwdArgs a) {
 #pragma unroll
                     for (int hh = 0; hh < HPT; ++hh) {
                         const int head = (16 * t) / FP + hh;
-                        const uint32_t h = han_hash(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob,
-                                                    fglob * (uint32_t)KP + (uint32_t)(head >> 1));
-                        const float am = han_keep16(h, head & 1, a.thr_in) ? av : 0.f;
+                        const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob,
+                                                        fglob * (uint32_t)KQ + (uint32_t)(head >> 2));
+                        const float am = rn.field(head & 3) < a.thr_in ? av : 0.f;
                         const float bm = (HPT == 1 || (l15 / FP) == hh) ? bv : 0.f;
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, acc[t], 0, 0, 0);
                     }
@@ -349,8 +350,8 @@ extern "C" int han_project_fwd(const float *X, int64_t ldx, const float *W, cons
     ProjFwdArgs a;
     a.X = X; a.ldx = ldx; a.W = W; a.H = H; a.N = N; a.F = F;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-    a.thr_in = in_drop > 0.f ? han_keep_threshold16(1.f - in_drop) : 65536u;
-    a.thr_fts = fts_drop > 0.f ? han_keep_threshold(1.f - fts_drop) : 16777216u;
+    a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : HAN_KEEP_ALL;
+    a.thr_fts = fts_drop > 0.f ? han_keep_threshold(1.f - fts_drop) : HAN_KEEP_ALL;
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
     const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
@@ -396,7 +397,7 @@ extern "C" int han_project_bwd(const float *X, int64_t ldx, const float *dH, flo
     a.X = X; a.ldx = ldx; a.dH = dH; a.slab = (float *)workspace; a.N = N; a.F = F;
     a.rows_per_chunk = rpc;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-    a.thr_in = in_drop > 0.f ? han_keep_threshold16(1.f - in_drop) : 65536u;
+    a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : HAN_KEEP_ALL;
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
     dim3 grid(ftiles, (unsigned)nch);

@@ -137,12 +137,8 @@ def node_attn_bwd_cols(graph_t, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=
     am = torch.ones_like(alpha)
     if coef_drop > 0:
         keep = rng_ref.keep_prob32(coef_drop)
-        KQ = K
-        h = rng_ref.han_hash(seed, rng_ref.STREAM_COEF, (dst.numpy() + dst_offset)[:, None],
-                             (src.numpy() + src_offset)[:, None].astype(np.uint64) * KQ
-                             + np.arange(K)[None, :])
-        thr = np.uint64(int(np.float32(keep) * np.float32(16777216.0)))
-        am = torch.tensor(((h >> np.uint64(8)) < thr).astype(np.float64)) / keep
+        am = torch.tensor(rng_ref.coef_draws(seed, dst.numpy() + dst_offset, src.numpy() + src_offset,
+                                             K, coef_drop)) / keep
     h64 = _f64(H)
     mk = torch.ones_like(h64)
     if fts_drop > 0:

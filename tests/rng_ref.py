@@ -1,6 +1,7 @@
 """NumPy restatement of the kernels' counter-based dropout RNG
-(han_amd/csrc/han_common.h: han_hash / han_keep) so that the oracle can be fed
-exactly the masks the HIP kernels draw."""
+(han_amd/csrc/han_common.h: han_rand64 = two 32x32->64 multiply-fold rounds, four
+16-bit draws per call) so that the oracle can be fed exactly the masks the HIP
+kernels draw."""
 import numpy as np
 
 STREAM_SEQ, STREAM_COEF, STREAM_FTS = 0, 1, 2
@@ -11,16 +12,30 @@ def _u32(x):
     return np.asarray(x, dtype=np.uint64) & _M
 
 
-def han_hash(seed, stream, a, b):
+def _mum(A, B):
+    c = (A ^ np.uint64(0x53C5CA59)) * (B ^ np.uint64(0x74743C1B))      # < 2^64, exact in uint64
+    return c & _M, c >> np.uint64(32)
+
+
+def han_rand64(seed, stream, a, b):
+    """Returns (x, y), two uint32 words per counter (a, b)."""
     seed = int(seed)
-    lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
-    a, b = _u32(a), _u32(b)
-    h = _u32(a * np.uint64(0x9E3779B1)) ^ _u32(lo + np.uint64(stream) * np.uint64(0x7F4A7C15))
-    h = h ^ (h >> np.uint64(16)); h = _u32(h * np.uint64(0x85EBCA6B)); h = h ^ (h >> np.uint64(13))
-    h = h ^ _u32(_u32(b * np.uint64(0xC2B2AE35)) + hi)
-    h = h ^ (h >> np.uint64(16)); h = _u32(h * np.uint64(0x85EBCA6B)); h = h ^ (h >> np.uint64(13))
-    h = _u32(h * np.uint64(0xC2B2AE35)); h = h ^ (h >> np.uint64(16))
-    return h
+    lo = np.uint64(seed & 0xFFFFFFFF)
+    hi = np.uint64((seed >> 32) & 0xFFFFFFFF)
+    k1 = np.uint64((int(hi) + stream * 0x9E3779B9) & 0xFFFFFFFF)
+    A, B = np.broadcast_arrays(_u32(a) ^ lo, _u32(b) ^ k1)
+    A, B = _mum(A, B)
+    A, B = _mum(A ^ hi, B ^ lo)
+    x = A ^ B
+    y = B ^ (A >> np.uint64(15)) ^ _u32(A << np.uint64(17))
+    return x, y
+
+
+def field(x, y, f):
+    """16-bit field f in [0,4) of the 64-bit output (f may be an array)."""
+    f = np.asarray(f)
+    w = np.where((f & 2) != 0, y, x)
+    return (w >> (np.uint64(16) * (f & 1).astype(np.uint64))) & np.uint64(0xFFFF)
 
 
 def keep_prob32(drop):
@@ -28,41 +43,38 @@ def keep_prob32(drop):
     return float(np.float32(1.0) - np.float32(drop))
 
 
-def keep(seed, stream, a, b, drop):
-    thr = np.uint64(int(np.float32(keep_prob32(drop)) * np.float32(16777216.0)))
-    return ((han_hash(seed, stream, a, b) >> np.uint64(8)) < thr)
+def _thr(drop):
+    return np.uint64(int(np.float32(keep_prob32(drop)) * np.float32(65536.0)))
 
 
 def seq_mask(seed, n, f, K, drop, row_offset=0):
-    """(K,N,F) -- layers.py:19.  One hash per (row, f, head pair): key
-    (row, f*ceil(K/2) + k//2); head k uses the 16-bit field k&1."""
-    KP = (K + 1) // 2
+    """(K,N,F) -- layers.py:19: counter (row, f*ceil(K/4) + k//4), field k%4."""
+    KQ = (K + 3) // 4
     rows = np.arange(n)[None, :, None] + row_offset
     fs = np.arange(f)[None, None, :]
     ks = np.arange(K)[:, None, None]
-    h = han_hash(seed, STREAM_SEQ, rows, fs * KP + ks // 2)
-    field = (h >> (np.uint64(16) * (ks % 2).astype(np.uint64))) & np.uint64(0xFFFF)
-    thr16 = np.uint64(int(np.float32(keep_prob32(drop)) * np.float32(65536.0)))
-    return (field < thr16).astype(np.float64)
+    x, y = han_rand64(seed, STREAM_SEQ, rows, fs * KQ + ks // 4)
+    return (field(x, y, ks % 4) < _thr(drop)).astype(np.float64)
+
+
+def coef_draws(seed, dst, src, K, drop):
+    """(E,K) keep draws of the attention dropout for edges dst_i <- src_j (global ids)."""
+    KQ = (K + 3) // 4
+    ks = np.arange(K)[None, :]
+    x, y = han_rand64(seed, STREAM_COEF, np.asarray(dst)[:, None],
+                      np.asarray(src)[:, None].astype(np.uint64) * KQ + ks // 4)
+    return (field(x, y, ks % 4) < _thr(drop)).astype(np.float64)
 
 
 def coef_mask_csr(seed, rowptr, colidx, K, drop, row_offset=0):
-    """(E,K) -- layers.py:30, key (i, j*K + k)."""
+    """(E,K) -- layers.py:30: counter (i, j*ceil(K/4) + k//4), field k%4."""
     rows = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr)) + row_offset
-    ks = np.arange(K)[None, :]
-    return keep(seed, STREAM_COEF, rows[:, None], colidx[:, None].astype(np.uint64) * K + ks,
-                drop).astype(np.float64)
-
-
-def coef_mask_dense(seed, n, K, drop):
-    """(K,N,N)."""
-    i = np.arange(n)[None, :, None]
-    j = np.arange(n)[None, None, :]
-    ks = np.arange(K)[:, None, None]
-    return keep(seed, STREAM_COEF, i, j * K + ks, drop).astype(np.float64)
+    return coef_draws(seed, rows, colidx, K, drop)
 
 
 def fts_mask(seed, n, d, drop, row_offset=0):
-    """(N,D) -- layers.py:32, key (row, d)."""
+    """(N,D) -- layers.py:32: counter (row, d//4), field d%4."""
     rows = np.arange(n)[:, None] + row_offset
-    return keep(seed, STREAM_FTS, rows, np.arange(d)[None, :], drop).astype(np.float64)
+    ds = np.arange(d)[None, :]
+    x, y = han_rand64(seed, STREAM_FTS, rows, ds // 4)
+    return (field(x, y, ds % 4) < _thr(drop)).astype(np.float64)
