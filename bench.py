@@ -32,8 +32,10 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s sp
 
 
 def k2_algorithmic_bytes(n_rows, nnz, K=8, D=64, s=4, train=False):
+    """the gathered row is s bytes per element (4 fp32 / 2 bf16); the
+    output row is always written in fp32."""
     per_edge = 4 + D * s + K * 4
-    per_row = D * s + K * 4 + 8
+    per_row = D * 4 + K * 4 + 8
     if train:                       # + pre, aggp rows and lse, tsum
         per_row += 2 * D * s + 2 * K * 4
     return nnz * per_edge + n_rows * per_row
@@ -95,6 +97,9 @@ def main():
     ap.add_argument("--nodes", type=int, default=0, help="override N (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=5000)
+    ap.add_argument("--table-dtype", choices=("f32", "bf16"), default="f32",
+                    help="storage of X and of the H/g gather tables (bf16 = the 10M-node config's "
+                         "'bf16 feats'); accumulation is fp32 either way")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,7 +125,11 @@ def main():
     n, p = wl["n"], wl["p"]
     part = NodePartition(n, rank, world) if use_dist else None
     gen = torch.Generator().manual_seed(0)
-    model = HeteGAT_multi().build(p, wl["f"], wl["c"], (8,), (8, 1), 128, device=dev, generator=gen)
+    tdt = torch.bfloat16 if args.table_dtype == "bf16" else torch.float32
+    model = HeteGAT_multi().build(p, wl["f"], wl["c"], (8,), (8, 1), 128, device=dev, generator=gen,
+                                  table_dtype=tdt)
+    if tdt == torch.bfloat16:
+        wl["x"] = wl["x"].to(torch.bfloat16)
 
     def loc(t):
         return part.local_rows(t).contiguous() if part is not None else t
@@ -166,14 +175,16 @@ def main():
     if ms["eval"]:
         nr, nnz = shape["eval"]
         avg_ms = sum(ms["eval"]) / len(ms["eval"])
-        alg = k2_algorithmic_bytes(nr, nnz)
+        esz = 2 if args.table_dtype == "bf16" else 4
+        alg = k2_algorithmic_bytes(nr, nnz, s=esz)
         achieved = alg / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "k2_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload and tj.get("n_gpus", 1) == world:
+                if tj.get("workload") == args.workload and tj.get("n_gpus", 1) == world \
+                        and args.table_dtype == "f32":
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -185,7 +196,7 @@ def main():
         if ms["train"]:
             nr, nnz = shape["train"]
             tavg = sum(ms["train"]) / len(ms["train"])
-            talg = k2_algorithmic_bytes(nr, nnz, train=True)
+            talg = k2_algorithmic_bytes(nr, nnz, s=esz, train=True)
             extra["k2_train_fwd"] = {"avg_launch_ms": round(tavg, 4),
                                      "achieved_GBs": round(talg / (tavg * 1e-3) / 1e9, 1)}
 
@@ -196,7 +207,9 @@ def main():
             "value": round(args.steps / dt, 4), "unit": "epochs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.table_dtype == "f32" else "bf16 storage / f32 accumulate",
+            "data": "synthetic",
             "config": {"workload": f"{args.workload}: N={n} nodes, P={p} meta-paths, "
                                    f"E={sum(g.nnz for g in trainer.graphs) if not use_dist else 'sharded'} "
                                    f"edges, F={wl['f']}, K=8 heads x F'=8, A=128, C={wl['c']}",

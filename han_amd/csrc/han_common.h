@@ -65,6 +65,49 @@ __host__ __device__ __forceinline__ uint32_t han_keep_threshold(float keep_prob)
 }
 #define HAN_KEEP_ALL 65536u
 
+// ---------------------------------------------------------------------------
+// Table rows in fp32 (256 B) or bf16 (128 B): lane q of a 16-lane group owns the 4
+// features 4q..4q+3 -> one 16-B or 8-B load.  bf16 is widened by a 16-bit shift
+// (exact), rounded to nearest-even on store.  The dropout keep bit is the LOWEST
+// mantissa bit of the stored element, i.e. bit 0 (fp32) or bit 16 of the widened
+// float (bf16).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t han_f32_to_bf16_bits(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <bool BF>
+__device__ __forceinline__ float4_t han_load_row4(const void *tab, int64_t row, int q) {
+    if (BF) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(tab) + row * 64 + 4 * q);
+        float4_t v;
+        v[0] = __uint_as_float(w.x << 16);
+        v[1] = __uint_as_float(w.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(w.y << 16);
+        v[3] = __uint_as_float(w.y & 0xFFFF0000u);
+        return v;
+    }
+    return *reinterpret_cast<const float4_t *>(reinterpret_cast<const float *>(tab) + row * 64 + 4 * q);
+}
+
+template <bool BF>
+__device__ __forceinline__ void han_store_row4(void *tab, int64_t row, int q, const float4_t &v) {
+    if (BF) {
+        uint2 w;
+        w.x = han_f32_to_bf16_bits(v[0]) | (han_f32_to_bf16_bits(v[1]) << 16);
+        w.y = han_f32_to_bf16_bits(v[2]) | (han_f32_to_bf16_bits(v[3]) << 16);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(tab) + row * 64 + 4 * q) = w;
+    } else {
+        *reinterpret_cast<float4_t *>(reinterpret_cast<float *>(tab) + row * 64 + 4 * q) = v;
+    }
+}
+
+template <bool BF>
+__device__ __forceinline__ uint32_t han_keep_bit(float v) {
+    return (__float_as_uint(v) >> (BF ? 16 : 0)) & 1u;
+}
+
 __device__ __forceinline__ float han_lrelu(float x, float slope) { return fmaxf(x, slope * x); }
 
 __device__ __forceinline__ float han_elu(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }

@@ -51,8 +51,8 @@ __device__ __forceinline__ float dot4(const float4_t &x, const float4_t &y) {
 struct FwdArgs {
     const int64_t *rowptr;
     const int32_t *colidx;
-    const float *H;
-    int lsb_mask;   // training with fts dropout: bit 0 of every H element is its keep bit
+    const void *H;  // fp32 (256-B rows) or bf16 (128-B rows) table
+    int lsb_mask;   // training with fts dropout: the lowest mantissa bit of every H element is its keep bit
     const float *f1;
     const float *a2;
     const float *b2;
@@ -106,7 +106,7 @@ struct RowState {
 };
 
 // Gather U neighbour rows and fold them into the running softmax state.
-template <int FP, bool TRAIN, int U>
+template <int FP, bool TRAIN, int U, bool BF>
 __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U], const bool (&valid)[U],
                                               const float f1h, const uint32_t gi, const int q, const int head,
                                               const float4_t &a24, const float b2h, const bool drop_c,
@@ -114,8 +114,7 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
     constexpr int KQ = (HAN_D / FP + 3) / 4;
     float4_t hv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-        hv[u] = *reinterpret_cast<const float4_t *>(a.H + (int64_t)j[u] * HAN_D + 4 * q);
+    for (int u = 0; u < U; ++u) hv[u] = han_load_row4<BF>(a.H, (int64_t)j[u], q);
     float ev[U], sg[U];
     float mc = st.m;
 #pragma unroll
@@ -149,7 +148,7 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
             if (a.lsb_mask) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    hv[u][t] = (__float_as_uint(hv[u][t]) & 1u) ? hv[u][t] * a.inv_keep_fts : 0.f;
+                    hv[u][t] = han_keep_bit<BF>(hv[u][t]) ? hv[u][t] * a.inv_keep_fts : 0.f;
             }
         }
 #pragma unroll
@@ -195,7 +194,7 @@ __device__ __forceinline__ void write_row(const FwdArgs &a, const int64_t row, c
 // One wave per destination row (RPW = 1) or one 16-lane group per row (RPW = 4,
 // for low-degree graphs).  TRAIN also produces pre / lse / aggp / tsum and
 // applies the two dropouts.
-template <int FP, bool TRAIN, int RPW, int U>
+template <int FP, bool TRAIN, int RPW, int U, bool BF>
 __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
     constexpr int K = HAN_D / FP;
     const int lane = threadIdx.x & 63;
@@ -235,7 +234,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
                         valid[u] = idx < cnt;
                         j[u] = __shfl(mycol, idx & 63, 64);
                     }
-                    consume_edges<FP, TRAIN, U>(a, j, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
+                    consume_edges<FP, TRAIN, U, BF>(a, j, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
                 }
             }
             st.merge(16);
@@ -258,7 +257,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
                     valid[u] = it + u < len;
                     j[u] = (len > 0) ? a.colidx[valid[u] ? s + it + u : s] : 0;
                 }
-                consume_edges<FP, TRAIN, U>(a, j, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
+                consume_edges<FP, TRAIN, U, BF>(a, j, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
             }
         }
 
@@ -267,7 +266,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
 }
 
 // Split rows, step 1: one wave per chunk of a long row -> un-normalised partial state.
-template <int FP, bool TRAIN, int U>
+template <int FP, bool TRAIN, int U, bool BF>
 __global__ __launch_bounds__(256) void node_attn_fwd_chunk_kernel(const FwdArgs a) {
     constexpr int K = HAN_D / FP;
     const int lane = threadIdx.x & 63;
@@ -297,7 +296,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_chunk_kernel(const FwdArgs 
                     valid[u] = idx < cnt;
                     j[u] = __shfl(mycol, idx & 63, 64);
                 }
-                consume_edges<FP, TRAIN, U>(a, j, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
+                consume_edges<FP, TRAIN, U, BF>(a, j, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
             }
         }
         st.merge(16);
@@ -360,13 +359,14 @@ struct BwdRowsArgs {
     const float *dOut;
     int64_t dout_stride;
     const float *pre, *aggp, *tsum, *f1, *lse, *c;
-    float *g, *stats, *df1;
+    void *g;       // fp32 or bf16 table
+    float *stats, *df1;
     float *slab;   // [gridDim.x][64] partial sums of g (for dc)
     int64_t N;
     int activation;
 };
 
-template <int FP>
+template <int FP, bool BF>
 __global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsArgs a) {
     constexpr int K = HAN_D / FP;
     const int q = threadIdx.x & 15;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsAr
         }
         sp = head_sum<FP>(sp);
         dp = head_sum<FP>(dp);
-        *reinterpret_cast<float4_t *>(a.g + row * HAN_D + 4 * q) = g4;
+        han_store_row4<BF>(a.g, row, q, g4);
         if ((4 * q) % FP == 0) {
             const float ts = a.tsum[row * K + head];
             a.df1[row * K + head] = dp - sp * ts;
@@ -423,7 +423,8 @@ __global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsAr
 struct BwdColsArgs {
     const int64_t *colptr;
     const int32_t *rowidx;
-    const float *g, *stats, *H, *f2, *df1, *a1, *a2;
+    const void *g, *H;   // fp32 or bf16 tables
+    const float *stats, *f2, *df1, *a1, *a2;
     int lsb_mask;
     float *dH, *df2;
     int64_t NS;
@@ -446,19 +447,19 @@ struct SrcRow {
     uint32_t gj;
 };
 
-template <int FP>
+template <int FP, bool BF>
 __device__ __forceinline__ SrcRow load_src(const BwdColsArgs &a, const int64_t src, const int q, const int head) {
     constexpr int K = HAN_D / FP;
     SrcRow r;
     r.gj = (uint32_t)(src + a.src_offset);
     r.f2h = a.f2[src * K + head];
-    r.hd = *reinterpret_cast<const float4_t *>(a.H + src * HAN_D + 4 * q);
+    r.hd = han_load_row4<BF>(a.H, src, q);
 #pragma unroll
     for (int t = 0; t < 4; ++t) r.mk[t] = 1.f;
     if (a.lsb_mask) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            r.mk[t] = (__float_as_uint(r.hd[t]) & 1u) ? a.inv_keep_fts : 0.f;
+            r.mk[t] = han_keep_bit<BF>(r.hd[t]) ? a.inv_keep_fts : 0.f;
             r.hd[t] *= r.mk[t];
         }
     }
@@ -466,7 +467,7 @@ __device__ __forceinline__ SrcRow load_src(const BwdColsArgs &a, const int64_t s
 }
 
 // gather U destinations i of source j and accumulate  acc += alpha~ g_i,  df += dl_ij
-template <int FP, int U>
+template <int FP, int U, bool BF>
 __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)[U], const bool (&valid)[U],
                                             const SrcRow &sr, const int q, const int head, const bool drop_c,
                                             float (&acc)[4], float &dfacc) {
@@ -475,7 +476,7 @@ __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)
     float4_t gv[U], st[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        gv[u] = *reinterpret_cast<const float4_t *>(a.g + (int64_t)i[u] * HAN_D + 4 * q);
+        gv[u] = han_load_row4<BF>(a.g, (int64_t)i[u], q);
         st[u] = *reinterpret_cast<const float4_t *>(a.stats + ((int64_t)i[u] * K + head) * 4);
     }
 #pragma unroll
@@ -512,7 +513,7 @@ __device__ __forceinline__ void write_src(const BwdColsArgs &a, const int64_t sr
     if ((4 * q) % FP == 0) a.df2[src * K + head] = dfacc;
 }
 
-template <int FP, int RPW, int U>
+template <int FP, int RPW, int U, bool BF>
 __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsArgs a) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
         const int64_t e_raw = src_ok ? a.colptr[src + 1] : s;
         const bool is_long = e_raw - s > a.split_deg;
         const int64_t e = is_long ? s : e_raw;
-        const SrcRow sr = load_src<FP>(a, src, q, head);
+        const SrcRow sr = load_src<FP, BF>(a, src, q, head);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         float dfacc = 0.f;
         const int64_t len = e - s;
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
                 valid[u] = k < len;
                 i[u] = len > 0 ? a.rowidx[valid[u] ? s + k : s] : 0;
             }
-            bwd_consume<FP, U>(a, i, valid, sr, q, head, drop_c, acc, dfacc);
+            bwd_consume<FP, U, BF>(a, i, valid, sr, q, head, drop_c, acc, dfacc);
         }
         if (RPW == 1) {
 #pragma unroll
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
 }
 
 // Split source rows: one wave per chunk -> partial sums; one 16-lane group per long row adds them.
-template <int FP, int U>
+template <int FP, int U, bool BF>
 __global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsArgs a) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsA
     for (int64_t ch = wave0; ch < a.n_chunks; ch += nwaves) {
         const int64_t src = a.long_rows[a.chunk_long[ch]];
         const int64_t s = a.chunk_start[ch], len = a.chunk_end[ch] - s;
-        const SrcRow sr = load_src<FP>(a, src, q, head);
+        const SrcRow sr = load_src<FP, BF>(a, src, q, head);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         float dfacc = 0.f;
         const int64_t trips = (len + 3) >> 2;
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsA
                 valid[u] = k < len;
                 i[u] = a.rowidx[valid[u] ? s + k : s];
             }
-            bwd_consume<FP, U>(a, i, valid, sr, q, head, drop_c, acc, dfacc);
+            bwd_consume<FP, U, BF>(a, i, valid, sr, q, head, drop_c, acc, dfacc);
         }
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsA
     }
 }
 
-template <int FP>
+template <int FP, bool BF>
 __global__ __launch_bounds__(256) void node_attn_bwd_finish_kernel(const BwdColsArgs a) {
     const int q = threadIdx.x & 15;
     const int head = (4 * q) / FP;
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_finish_kernel(const BwdCols
     const float4_t a14 = *reinterpret_cast<const float4_t *>(a.a1 + 4 * q);
     const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
     const int64_t src = a.long_rows[r];
-    const SrcRow sr = load_src<FP>(a, src, q, head);
+    const SrcRow sr = load_src<FP, BF>(a, src, q, head);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     float dfacc = 0.f;
     for (int64_t ch = a.long_ptr[r]; ch < a.long_ptr[r + 1]; ++ch) {
@@ -639,8 +640,8 @@ __global__ __launch_bounds__(256) void node_attn_bwd_finish_kernel(const BwdCols
 // backward step 3: score-parameter gradients (da1, da2, db1, db2)
 // slab row layout: [0,64) da1, [64,128) da2, [128,128+K) db1, [128+K,128+2K) db2
 // ---------------------------------------------------------------------------
-template <int FP>
-__global__ __launch_bounds__(256) void score_param_bwd_kernel(const float *H, const float *df1,
+template <int FP, bool BF>
+__global__ __launch_bounds__(256) void score_param_bwd_kernel(const void *H, const float *df1,
                                                               const float *df2, float *slab, int64_t N) {
     constexpr int K = HAN_D / FP;
     constexpr int WIDTH = 128 + 2 * K;
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(256) void score_param_bwd_kernel(const float *H, co
     float d1[4] = {0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
     float s1 = 0.f, s2 = 0.f;
     for (int64_t row = grp0; row < N; row += ngrp) {
-        const float4_t h4 = *reinterpret_cast<const float4_t *>(H + row * HAN_D + 4 * q);
+        const float4_t h4 = han_load_row4<BF>(H, row, q);
         const float x1 = df1[row * K + head], x2 = df2[row * K + head];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -711,7 +712,48 @@ bool split_ok(const han_row_split_t *sp) {
         default: { constexpr int FPC = 64; __VA_ARGS__; } break; \
     }
 
-extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float *H,
+// bf16 tables are built for the reference head shape only (8 heads x 8)
+#define HAN_BF16_OK(FPV) ((FPV) == 8)
+
+template <int FPC, bool BF>
+static void launch_fwd(const FwdArgs &a, bool train, bool low, bool has_split, hipStream_t st) {
+    if (low) {
+        const int grid = attn_grid((a.N + 3) / 4);
+        if (train) node_attn_fwd_kernel<FPC, true, 4, 2, BF><<<grid, 256, 0, st>>>(a);
+        else node_attn_fwd_kernel<FPC, false, 4, 2, BF><<<grid, 256, 0, st>>>(a);
+    } else {
+        const int grid = attn_grid(a.N);
+        if (train) node_attn_fwd_kernel<FPC, true, 1, 4, BF><<<grid, 256, 0, st>>>(a);
+        else node_attn_fwd_kernel<FPC, false, 1, 4, BF><<<grid, 256, 0, st>>>(a);
+    }
+    if (has_split) {
+        const int cgrid = attn_grid(a.n_chunks);
+        const int fgrid = (int)((a.n_long + 15) / 16);
+        if (train) {
+            node_attn_fwd_chunk_kernel<FPC, true, 4, BF><<<cgrid, 256, 0, st>>>(a);
+            node_attn_fwd_finish_kernel<FPC, true><<<fgrid, 256, 0, st>>>(a);
+        } else {
+            node_attn_fwd_chunk_kernel<FPC, false, 4, BF><<<cgrid, 256, 0, st>>>(a);
+            node_attn_fwd_finish_kernel<FPC, false><<<fgrid, 256, 0, st>>>(a);
+        }
+    }
+}
+
+template <int FPC, bool BF>
+static void launch_bwd_cols(const BwdColsArgs &a, bool low, bool has_split, hipStream_t st) {
+    if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
+    else node_attn_bwd_cols_kernel<FPC, 1, 4, BF><<<attn_grid(a.NS), 256, 0, st>>>(a);
+    if (has_split) {
+        node_attn_bwd_chunk_kernel<FPC, 4, BF><<<attn_grid(a.n_chunks), 256, 0, st>>>(a);
+        node_attn_bwd_finish_kernel<FPC, BF><<<(int)((a.n_long + 15) / 16), 256, 0, st>>>(a);
+    }
+}
+
+static bool dtype_ok(int dt, int FP) {
+    return dt == HAN_DTYPE_F32 || (dt == HAN_DTYPE_BF16 && HAN_BF16_OK(FP));
+}
+
+extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const void *H, int table_dtype,
                                  const float *f1, const float *a2, const float *b2,
                                  const float *c, float *out, int64_t out_stride, float *pre, float *lse,
                                  float *aggp, float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
@@ -720,7 +762,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     if (!rowptr || !colidx || !H || !f1 || !a2 || !b2 || !c || !out || N < 0 || E < 0 || out_stride < HAN_D)
         return HAN_E_BADARG;
     if (!split_ok(split)) return HAN_E_BADARG;
-    if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
+    if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
     const bool train = pre || lse || aggp || tsum;
     if (train && !(pre && lse && aggp && tsum)) return HAN_E_BADARG;
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
@@ -747,28 +789,11 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     a.split_ws = has_split ? (float *)split->workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool low = (double)E < kLowDegree * (double)N;
-    HAN_DISPATCH_FP(FP, {
-        if (low) {
-            const int grid = attn_grid((N + 3) / 4);
-            if (train) node_attn_fwd_kernel<FPC, true, 4, 2><<<grid, 256, 0, st>>>(a);
-            else node_attn_fwd_kernel<FPC, false, 4, 2><<<grid, 256, 0, st>>>(a);
-        } else {
-            const int grid = attn_grid(N);
-            if (train) node_attn_fwd_kernel<FPC, true, 1, 4><<<grid, 256, 0, st>>>(a);
-            else node_attn_fwd_kernel<FPC, false, 1, 4><<<grid, 256, 0, st>>>(a);
-        }
-        if (has_split) {
-            const int cgrid = attn_grid(a.n_chunks);
-            const int fgrid = (int)((a.n_long + 15) / 16);
-            if (train) {
-                node_attn_fwd_chunk_kernel<FPC, true, 4><<<cgrid, 256, 0, st>>>(a);
-                node_attn_fwd_finish_kernel<FPC, true><<<fgrid, 256, 0, st>>>(a);
-            } else {
-                node_attn_fwd_chunk_kernel<FPC, false, 4><<<cgrid, 256, 0, st>>>(a);
-                node_attn_fwd_finish_kernel<FPC, false><<<fgrid, 256, 0, st>>>(a);
-            }
-        }
-    })
+    if (table_dtype == HAN_DTYPE_BF16) {
+        launch_fwd<8, true>(a, train, low, has_split, st);
+    } else {
+        HAN_DISPATCH_FP(FP, { launch_fwd<FPC, false>(a, train, low, has_split, st); })
+    }
     HAN_CHECK_LAUNCH();
     return 0;
 }
@@ -784,13 +809,14 @@ extern "C" size_t han_node_attn_bwd_workspace(int64_t N, int K, int FP) {
 
 extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *pre,
                                       const float *aggp, const float *tsum, const float *f1,
-                                      const float *lse, const float *c, float *g, float *stats,
-                                      float *df1, float *dc, void *workspace, size_t workspace_bytes,
-                                      int64_t N, int K, int FP, int activation, void *stream) {
+                                      const float *lse, const float *c, void *g, int table_dtype,
+                                      float *stats, float *df1, float *dc, void *workspace,
+                                      size_t workspace_bytes, int64_t N, int K, int FP, int activation,
+                                      void *stream) {
     if (!dOut || !pre || !aggp || !tsum || !f1 || !lse || !c || !g || !stats || !df1 || !dc || !workspace ||
         N < 0 || dout_stride < HAN_D)
         return HAN_E_BADARG;
-    if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
+    if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
     if (workspace_bytes < han_node_attn_bwd_workspace(N, K, FP)) return HAN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     BwdRowsArgs a;
@@ -798,22 +824,27 @@ extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, co
     a.f1 = f1; a.lse = lse; a.c = c; a.g = g; a.stats = stats; a.df1 = df1;
     a.slab = (float *)workspace; a.N = N; a.activation = activation;
     const int grid = han_grid_for(N, 16, kReduceBlocks);
-    HAN_DISPATCH_FP(FP, { node_attn_bwd_rows_kernel<FPC><<<grid, 256, 0, st>>>(a); })
+    if (table_dtype == HAN_DTYPE_BF16) {
+        node_attn_bwd_rows_kernel<8, true><<<grid, 256, 0, st>>>(a);
+    } else {
+        HAN_DISPATCH_FP(FP, { node_attn_bwd_rows_kernel<FPC, false><<<grid, 256, 0, st>>>(a); })
+    }
     HAN_CHECK_LAUNCH();
     hipError_t e = han_reduce_slabs((const float *)workspace, grid, 64, 64, han_reduce_to(dc, 64), st);
     if (e != hipSuccess) return (int)e;
     return 0;
 }
 
-extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const float *g,
-                                      const float *stats, const float *H, const float *f2, const float *df1, const float *a1, const float *a2,
+extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const void *g,
+                                      const float *stats, const void *H, int table_dtype, const float *f2,
+                                      const float *df1, const float *a1, const float *a2,
                                       float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                                       float coef_drop, float fts_drop, uint64_t seed, int64_t src_offset,
                                       int64_t dst_offset, const han_row_split_t *split, void *stream) {
     if (!colptr || !rowidx || !g || !stats || !H || !f2 || !df1 || !a1 || !a2 || !dH || !df2 || NS < 0 || E < 0)
         return HAN_E_BADARG;
     if (!split_ok(split)) return HAN_E_BADARG;
-    if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
+    if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
     if (NS == 0) return 0;
     BwdColsArgs a;
@@ -836,14 +867,11 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
     a.split_ws = has_split ? (float *)split->workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool low = (double)E < kLowDegree * (double)NS;
-    HAN_DISPATCH_FP(FP, {
-        if (low) node_attn_bwd_cols_kernel<FPC, 4, 2><<<attn_grid((NS + 3) / 4), 256, 0, st>>>(a);
-        else node_attn_bwd_cols_kernel<FPC, 1, 4><<<attn_grid(NS), 256, 0, st>>>(a);
-        if (has_split) {
-            node_attn_bwd_chunk_kernel<FPC, 4><<<attn_grid(a.n_chunks), 256, 0, st>>>(a);
-            node_attn_bwd_finish_kernel<FPC><<<(int)((a.n_long + 15) / 16), 256, 0, st>>>(a);
-        }
-    })
+    if (table_dtype == HAN_DTYPE_BF16) {
+        launch_bwd_cols<8, true>(a, low, has_split, st);
+    } else {
+        HAN_DISPATCH_FP(FP, { launch_bwd_cols<FPC, false>(a, low, has_split, st); })
+    }
     HAN_CHECK_LAUNCH();
     return 0;
 }
@@ -853,17 +881,21 @@ extern "C" size_t han_score_param_bwd_workspace(int64_t N, int K, int FP) {
     return (size_t)kReduceBlocks * (size_t)(128 + 2 * K) * sizeof(float);
 }
 
-extern "C" int han_score_param_bwd(const float *H, const float *df1, const float *df2, float *da1,
-                                   float *da2, float *db1, float *db2, void *workspace,
+extern "C" int han_score_param_bwd(const void *H, int table_dtype, const float *df1, const float *df2,
+                                   float *da1, float *da2, float *db1, float *db2, void *workspace,
                                    size_t workspace_bytes, int64_t N, int K, int FP, void *stream) {
     if (!H || !df1 || !df2 || !da1 || !da2 || !db1 || !db2 || !workspace || N < 0) return HAN_E_BADARG;
-    if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
+    if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
     if (workspace_bytes < han_score_param_bwd_workspace(N, K, FP)) return HAN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int grid = han_grid_for(N, 16, kReduceBlocks);
-    HAN_DISPATCH_FP(FP, {
-        score_param_bwd_kernel<FPC><<<grid, 256, 0, st>>>(H, df1, df2, (float *)workspace, N);
-    })
+    if (table_dtype == HAN_DTYPE_BF16) {
+        score_param_bwd_kernel<8, true><<<grid, 256, 0, st>>>(H, df1, df2, (float *)workspace, N);
+    } else {
+        HAN_DISPATCH_FP(FP, {
+            score_param_bwd_kernel<FPC, false><<<grid, 256, 0, st>>>(H, df1, df2, (float *)workspace, N);
+        })
+    }
     HAN_CHECK_LAUNCH();
     HanReduceOut o = han_reduce_to(da1, 128 + 2 * K);
     o.ptr[1] = da2; o.ptr[2] = db1; o.ptr[3] = db2;

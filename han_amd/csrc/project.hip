@@ -24,16 +24,34 @@ constexpr int XS_LD = 34;   // LDS leading dims chosen conflict-free for the MFM
 constexpr int WS_LD = 80;
 
 struct ProjFwdArgs {
-    const float *X;
+    const void *X;      // fp32 or bf16 (x_bf16), row stride ldx ELEMENTS
     int64_t ldx;
     const float *W;
-    float *H;
+    void *H;            // fp32 or bf16 (h_bf16), 64 elements per row
+    int x_bf16, h_bf16;
     int64_t N;
     int F;
     uint32_t seed_lo, seed_hi, thr_in, thr_fts;   // thr_fts < 2^16: stamp keep bits into H
     float inv_keep_in;
     int64_t row_offset;
 };
+
+__device__ __forceinline__ float load_x1(const void *X, int bf, int64_t idx) {
+    if (bf) return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(X)[idx] << 16);
+    return reinterpret_cast<const float *>(X)[idx];
+}
+__device__ __forceinline__ float4_t load_x4(const void *X, int bf, int64_t idx) {   // idx % 4 == 0, aligned
+    if (bf) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(X) + idx);
+        float4_t v;
+        v[0] = __uint_as_float(w.x << 16);
+        v[1] = __uint_as_float(w.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(w.y << 16);
+        v[3] = __uint_as_float(w.y & 0xFFFF0000u);
+        return v;
+    }
+    return *reinterpret_cast<const float4_t *>(reinterpret_cast<const float *>(X) + idx);
+}
 
 // heads covered by one 16-column MFMA tile
 template <int FP>
@@ -75,7 +93,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
                 const int r = idx >> 3, c4 = (idx & 7) * 4;
                 const int64_t row = row0 + r;
                 float4_t v = {0.f, 0.f, 0.f, 0.f};
-                if (row < a.N && k0 + c4 < a.F) v = *reinterpret_cast<const float4_t *>(a.X + row * a.ldx + k0 + c4);
+                if (row < a.N && k0 + c4 < a.F) v = load_x4(a.X, a.x_bf16, row * a.ldx + k0 + c4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xr[4 * i + e] = v[e];
             }
@@ -85,7 +103,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
                 const int idx = tid + 256 * i;
                 const int r = idx >> 5, cc = idx & 31;
                 const int64_t row = row0 + r;
-                xr[i] = (row < a.N && k0 + cc < a.F) ? a.X[row * a.ldx + k0 + cc] : 0.f;
+                xr[i] = (row < a.N && k0 + cc < a.F) ? load_x1(a.X, a.x_bf16, row * a.ldx + k0 + cc) : 0.f;
             }
         }
 #pragma unroll
@@ -164,14 +182,26 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
 #pragma unroll
                 for (int hh = 1; hh < HPT; ++hh) v = (myhh == hh) ? acc[m][t][hh][r] : v;
                 if (DROP) v *= a.inv_keep_in;
+                uint32_t keepbit = 0, stamp = 0;
                 if (a.thr_fts < HAN_KEEP_ALL) {
-                    // projected-row dropout (layers.py:31-32): the keep bit rides in mantissa bit 0
+                    // projected-row dropout (layers.py:31-32): the keep bit rides in the lowest
+                    // mantissa bit of the STORED element (fp32 bit 0 / bf16 bit 0)
                     const int d = 16 * t + l15;
                     const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_FTS,
                                                     (uint32_t)(row + a.row_offset), (uint32_t)(d >> 2));
-                    v = __uint_as_float((__float_as_uint(v) & ~1u) | (rn.field(d & 3) < a.thr_fts ? 1u : 0u));
+                    keepbit = rn.field(d & 3) < a.thr_fts ? 1u : 0u;
+                    stamp = 1;
                 }
-                if (row < a.N) a.H[row * HAN_D + 16 * t + l15] = v;
+                if (row < a.N) {
+                    if (a.h_bf16) {
+                        uint32_t b = han_f32_to_bf16_bits(v);
+                        if (stamp) b = (b & ~1u) | keepbit;
+                        reinterpret_cast<uint16_t *>(a.H)[row * HAN_D + 16 * t + l15] = (uint16_t)b;
+                    } else {
+                        if (stamp) v = __uint_as_float((__float_as_uint(v) & ~1u) | keepbit);
+                        reinterpret_cast<float *>(a.H)[row * HAN_D + 16 * t + l15] = v;
+                    }
+                }
             }
         }
     }
@@ -180,12 +210,13 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
 // Row-local epilogue: f1 = H_k.a1 + b1, f2 = H_k.a2 + b2 (layers.py:23-24), taken from
 // the rows exactly as stored (i.e. including the keep bits stamped in training).
 struct ScoreArgs {
-    const float *H, *a1, *a2, *b1, *b2;
+    const void *H;
+    const float *a1, *a2, *b1, *b2;
     float *f1, *f2;
     int64_t N;
 };
 
-template <int FP>
+template <int FP, bool BF>
 __global__ __launch_bounds__(256) void project_scores_kernel(const ScoreArgs a) {
     constexpr int K = HAN_D / FP;
     const int q = threadIdx.x & 15;
@@ -196,7 +227,7 @@ __global__ __launch_bounds__(256) void project_scores_kernel(const ScoreArgs a) 
     const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
     const float b1 = a.b1[head], b2 = a.b2[head];
     for (int64_t row = grp0; row < a.N; row += ngrp) {
-        const float4_t h4 = *reinterpret_cast<const float4_t *>(a.H + row * HAN_D + 4 * q);
+        const float4_t h4 = han_load_row4<BF>(a.H, row, q);
         float s1 = h4[0] * a14[0] + h4[1] * a14[1] + h4[2] * a14[2] + h4[3] * a14[3];
         float s2 = h4[0] * a24[0] + h4[1] * a24[1] + h4[2] * a24[2] + h4[3] * a24[3];
 #pragma unroll
@@ -221,7 +252,8 @@ constexpr int BN = 32;       // reduction step (rows of X / dH)
 constexpr int TS_LD = 80;
 
 struct ProjBwdArgs {
-    const float *X;
+    const void *X;
+    int x_bf16;
     int64_t ldx;
     const float *dH;
     float *slab;   // [nchunks][F][64]
@@ -260,7 +292,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const ProjBwdArgs a) {
             const int r = idx >> 6, cc = idx & 63;
             const int64_t row = n0 + r;
             const int f = f0 + cc;
-            xr[i] = (row < n_end && f < a.F) ? a.X[row * a.ldx + f] : 0.f;
+            xr[i] = (row < n_end && f < a.F) ? load_x1(a.X, a.x_bf16, row * a.ldx + f) : 0.f;
             gr[i] = row < n_end ? a.dH[row * HAN_D + cc] : 0.f;
         }
     };
@@ -337,24 +369,28 @@ void bwd_geometry(int64_t N, int F, int *ftiles, int64_t *rows_per_chunk, int64_
         default: { constexpr int FPC = 64; __VA_ARGS__; } break;  \
     }
 
-extern "C" int han_project_fwd(const float *X, int64_t ldx, const float *W, const float *a1,
-                               const float *a2, const float *b1, const float *b2, float *H,
+extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const float *W, const float *a1,
+                               const float *a2, const float *b1, const float *b2, void *H, int table_dtype,
                                float *f1, float *f2, int64_t N, int F, int K, int FP, float in_drop,
                                float fts_drop, uint64_t seed, int64_t row_offset, void *stream) {
     if (!X || !W || !a1 || !a2 || !b1 || !b2 || !H || !f1 || !f2 || N < 0 || F <= 0 || ldx < F)
         return HAN_E_BADARG;
     if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
+    if ((x_dtype != HAN_DTYPE_F32 && x_dtype != HAN_DTYPE_BF16) ||
+        (table_dtype != HAN_DTYPE_F32 && !(table_dtype == HAN_DTYPE_BF16 && FP == 8)))
+        return HAN_E_UNSUPPORTED;
     if (in_drop < 0.f || in_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     ProjFwdArgs a;
     a.X = X; a.ldx = ldx; a.W = W; a.H = H; a.N = N; a.F = F;
+    a.x_bf16 = x_dtype == HAN_DTYPE_BF16; a.h_bf16 = table_dtype == HAN_DTYPE_BF16;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : HAN_KEEP_ALL;
     a.thr_fts = fts_drop > 0.f ? han_keep_threshold(1.f - fts_drop) : HAN_KEEP_ALL;
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
-    const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
+    const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & (a.x_bf16 ? 7 : 15)) == 0);
     constexpr int MT = 2;
     const int grid = (int)((N + 64 * MT - 1) / (64 * MT));
     HAN_DISPATCH_FP(FP, {
@@ -371,7 +407,11 @@ extern "C" int han_project_fwd(const float *X, int64_t ldx, const float *W, cons
     s.H = H; s.a1 = a1; s.a2 = a2; s.b1 = b1; s.b2 = b2; s.f1 = f1; s.f2 = f2;
     s.N = N;
     const int sgrid = han_grid_for(N, 16, 256 * 8);
-    HAN_DISPATCH_FP(FP, { project_scores_kernel<FPC><<<sgrid, 256, 0, st>>>(s); })
+    if (a.h_bf16) {
+        project_scores_kernel<8, true><<<sgrid, 256, 0, st>>>(s);
+    } else {
+        HAN_DISPATCH_FP(FP, { project_scores_kernel<FPC, false><<<sgrid, 256, 0, st>>>(s); })
+    }
     HAN_CHECK_LAUNCH();
     return 0;
 }
@@ -383,18 +423,19 @@ extern "C" size_t han_project_bwd_workspace(int64_t N, int F, int K, int FP) {
     return (size_t)nch * (size_t)F * HAN_D * sizeof(float);
 }
 
-extern "C" int han_project_bwd(const float *X, int64_t ldx, const float *dH, float *dW, void *workspace,
+extern "C" int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const float *dH, float *dW, void *workspace,
                                size_t workspace_bytes, int64_t N, int F, int K, int FP, float in_drop,
                                uint64_t seed, int64_t row_offset, void *stream) {
     if (!X || !dH || !dW || !workspace || N < 0 || F <= 0 || ldx < F) return HAN_E_BADARG;
     if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
+    if (x_dtype != HAN_DTYPE_F32 && x_dtype != HAN_DTYPE_BF16) return HAN_E_UNSUPPORTED;
     if (in_drop < 0.f || in_drop >= 1.f) return HAN_E_BADARG;
     if (workspace_bytes < han_project_bwd_workspace(N, F, K, FP)) return HAN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     int ftiles; int64_t rpc, nch;
     bwd_geometry(N, F, &ftiles, &rpc, &nch);
     ProjBwdArgs a;
-    a.X = X; a.ldx = ldx; a.dH = dH; a.slab = (float *)workspace; a.N = N; a.F = F;
+    a.X = X; a.x_bf16 = x_dtype == HAN_DTYPE_BF16; a.ldx = ldx; a.dH = dH; a.slab = (float *)workspace; a.N = N; a.F = F;
     a.rows_per_chunk = rpc;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : HAN_KEEP_ALL;

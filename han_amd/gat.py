@@ -71,7 +71,8 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
 
     # ------------------------------------------------------------------ params
     def build(self, n_metapaths, ft_size, nb_classes, hid_units=(8,), n_heads=(8, 1),
-              mp_att_size=128, device=None, generator: torch.Generator | None = None):
+              mp_att_size=128, device=None, generator: torch.Generator | None = None,
+              table_dtype=torch.float32):
         """Create the variables the reference's first inference() call creates
         (SURVEY.md 8a): glorot-uniform conv1d/dense kernels, zero biases,
         N(0, 0.1^2) semantic-attention variables."""
@@ -87,6 +88,9 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         dev = torch.device(device) if device is not None else (self._device or torch.device("cuda:0"))
         self.P, self.F, self.K, self.FP = int(n_metapaths), int(ft_size), K, FP
         self.A, self.C, self.HC = int(mp_att_size), int(nb_classes), HC
+        if table_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("table_dtype must be torch.float32 or torch.bfloat16")
+        self.table_dtype = table_dtype       # storage of the projected rows / backward tables
         shapes = _param_shapes(self.P, self.F, K, FP, self.A, self.C, HC)
         total = sum(math.prod(s) for _, s in shapes)
         flat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -153,7 +157,8 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
     def node_level(self, xs, graphs, attn_drop, ffd_drop, train, act_code, graphs_t=None):
         cfg = {"train": train, "in_drop": float(ffd_drop), "coef_drop": float(attn_drop),
                "seeds": tuple(rng.next_seed() for _ in graphs) if train else (0,) * len(graphs),
-               "act": act_code, "part": self.partition, "graphs_t": graphs_t}
+               "act": act_code, "part": self.partition, "graphs_t": graphs_t,
+               "table_dtype": self.table_dtype}
         return layers.NodeLevelAttention.apply(self.W, self.a1, self.b1, self.a2, self.b2, self.c,
                                                tuple(xs), tuple(graphs), cfg)
 

@@ -48,6 +48,7 @@ class NodeLevelAttention(torch.autograd.Function):
       graphs  tuple of P CSRGraph (rows = local destinations)
       cfg     dict: train (bool), in_drop, coef_drop, seeds (tuple of P ints),
               act (kernel activation code), part (NodePartition or None),
+              table_dtype (torch.float32 | torch.bfloat16: storage of the H / g tables),
               graphs_t (tuple of P transposed graphs for the backward, or None)
     """
 
@@ -70,7 +71,8 @@ class NodeLevelAttention(torch.autograd.Function):
         for p in range(P):
             seed = int(cfg["seeds"][p])
             H, f1, f2 = ops.project_fwd(xs[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
-                                        fts_drop=in_drop, seed=seed, row_offset=row_offset)
+                                        fts_drop=in_drop, seed=seed, row_offset=row_offset,
+                                        table_dtype=cfg.get("table_dtype", torch.float32))
             proj.append((H, f1, f2, part.all_gather_rows_async(H) if multi else None))
         for p in range(P):
             H, f1, f2, handle = proj[p]
@@ -109,7 +111,8 @@ class NodeLevelAttention(torch.autograd.Function):
         for p in range(P):      # row-local halves first; their tables go out while we continue
             H, f1, f2, pre, lse, aggp, tsum = ctx.saved_per_p[p]
             g, stats, df1, dcp = ops.node_attn_bwd_rows(dM[:, p, :], pre, aggp, tsum, f1, lse, c[p],
-                                                        activation=cfg["act"], K=K, FP=FP)
+                                                        activation=cfg["act"], K=K, FP=FP,
+                                                        table_dtype=H.dtype)
             dc[p] = dcp
             if multi:
                 rows.append((part.all_gather_rows_async(g), part.all_gather_rows_async(stats), df1))

@@ -57,6 +57,15 @@ def _chk(t: torch.Tensor, name: str, shape=None, dtype=torch.float32, device=Non
     return t
 
 
+DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}      # HAN_DTYPE_F32 / HAN_DTYPE_BF16
+
+
+def _dtype_code(t: torch.Tensor, name: str) -> int:
+    if t.dtype not in DTYPE_CODE:
+        raise ValueError(f"{name}: dtype {t.dtype}, expected float32 or bfloat16")
+    return DTYPE_CODE[t.dtype]
+
+
 SPLIT_DEG = 8192       # rows longer than this are split into chunks of SPLIT_CHUNK edges
 SPLIT_CHUNK = 4096
 
@@ -91,20 +100,27 @@ def _check_drop(p: float, name: str):
 
 
 # --------------------------------------------------------------------------- K1
-def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_offset=0):
+def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_offset=0,
+                table_dtype=torch.float32):
     """utils/layers.py:18-24,31-32 for the K heads of one meta-path.
-    X (N,F) [row stride >= F]; W (F,D); a1,a2 (K,F'); b1,b2 (K,).
+    X (N,F) fp32 or bf16 [row stride >= F]; W (F,D); a1,a2 (K,F'); b1,b2 (K,).
+    H is stored in `table_dtype` (float32 or bfloat16; f1/f2 come from the stored rows).
     Returns H (N,D), f1 (N,K), f2 (N,K).  With fts_drop > 0 the keep bit of the
     projected-row dropout rides in mantissa bit 0 of every H element."""
     lib = _lib.load()
     if X.dim() != 2:
         raise ValueError(f"X: expected (N,F), got {tuple(X.shape)}")
-    _chk(X, "X", contiguous=False)
+    _chk(X, "X", contiguous=False, dtype=X.dtype)
+    xcode = _dtype_code(X, "X")
     if X.stride(1) != 1:
         raise ValueError("X: rows must be contiguous")
     N, F = X.shape
     dev = X.device
     K, FP = a1.shape
+    if table_dtype not in DTYPE_CODE:
+        raise ValueError(f"table_dtype {table_dtype}: expected float32 or bfloat16")
+    if table_dtype == torch.bfloat16 and (K, FP) != (8, 8):
+        raise NotImplementedError("bf16 tables are built for 8 heads x 8 features")
     _check_heads(K, FP)
     _chk(W, "W", (F, D), device=dev)
     _chk(a1, "a1", (K, FP), device=dev)
@@ -113,12 +129,12 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
     _chk(b2, "b2", (K,), device=dev)
     in_drop = _check_drop(in_drop, "in_drop")
     fts_drop = _check_drop(fts_drop, "fts_drop")
-    H = torch.empty((N, D), dtype=torch.float32, device=dev)
+    H = torch.empty((N, D), dtype=table_dtype, device=dev)
     f1 = torch.empty((N, K), dtype=torch.float32, device=dev)
     f2 = torch.empty((N, K), dtype=torch.float32, device=dev)
     _lib.check(lib.han_project_fwd(
-        X.data_ptr(), X.stride(0) if N > 1 else max(F, X.stride(0)), W.data_ptr(), a1.data_ptr(),
-        a2.data_ptr(), b1.data_ptr(), b2.data_ptr(), H.data_ptr(),
+        X.data_ptr(), xcode, X.stride(0) if N > 1 else max(F, X.stride(0)), W.data_ptr(), a1.data_ptr(),
+        a2.data_ptr(), b1.data_ptr(), b2.data_ptr(), H.data_ptr(), DTYPE_CODE[table_dtype],
         f1.data_ptr(), f2.data_ptr(), N, F, K, FP,
         in_drop, fts_drop, int(seed), int(row_offset), _stream()), "han_project_fwd")
     return H, f1, f2
@@ -127,7 +143,8 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
 def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0):
     """dW (F,D) = dropout_k(X)^T dH."""
     lib = _lib.load()
-    _chk(X, "X", contiguous=False)
+    _chk(X, "X", contiguous=False, dtype=X.dtype)
+    xcode = _dtype_code(X, "X")
     N, F = X.shape
     _chk(dH, "dH", (N, D), device=X.device)
     _check_heads(K, FP)
@@ -135,7 +152,7 @@ def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0):
     nbytes = lib.han_project_bwd_workspace(N, F, K, FP)
     ws = _ws(nbytes, X.device, "proj")
     _lib.check(lib.han_project_bwd(
-        X.data_ptr(), X.stride(0) if N > 1 else max(F, X.stride(0)), dH.data_ptr(), dW.data_ptr(),
+        X.data_ptr(), xcode, X.stride(0) if N > 1 else max(F, X.stride(0)), dH.data_ptr(), dW.data_ptr(),
         ws.data_ptr(), ws.numel(), N, F, K, FP, _check_drop(in_drop, "in_drop"), int(seed),
         int(row_offset), _stream()), "han_project_bwd")
     return dW
@@ -155,7 +172,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
     _check_heads(K, FP)
     N = graph.n_rows
     dev = H_tab.device
-    _chk(H_tab, "H", (graph.n_cols, D))
+    _chk(H_tab, "H", (graph.n_cols, D), dtype=H_tab.dtype)
+    tcode = _dtype_code(H_tab, "H")
     _chk(f1, "f1", (N, K), device=dev)
     _chk(a2, "a2", (K, FP), device=dev)
     _chk(b2, "b2", (K,), device=dev)
@@ -187,7 +205,7 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     _lib.check(lib.han_node_attn_fwd(
-        graph.rowptr.data_ptr(), graph.colidx.data_ptr(), H_tab.data_ptr(), f1.data_ptr(),
+        graph.rowptr.data_ptr(), graph.colidx.data_ptr(), H_tab.data_ptr(), tcode, f1.data_ptr(),
         a2.data_ptr(), b2.data_ptr(), c.data_ptr(), out.data_ptr(), out.stride(0) if N > 1 else D,
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
         int(seed), int(row_offset), int(activation),
@@ -198,7 +216,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
     return out, saved
 
 
-def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=8, FP=8):
+def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=8, FP=8,
+                       table_dtype=torch.float32):
     """Row-local half of the K2 backward.  dOut (N,D) view (unit inner stride).
     Returns g (N,D), stats (N,K,4), df1 (N,K), dc (D,)."""
     lib = _lib.load()
@@ -211,7 +230,7 @@ def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=
     for t, n, s in ((pre, "pre", (N, D)), (aggp, "aggp", (N, D)), (tsum, "tsum", (N, K)),
                     (f1, "f1", (N, K)), (lse, "lse", (N, K)), (c, "c", (D,))):
         _chk(t, n, s, device=dev)
-    g = torch.empty((N, D), dtype=torch.float32, device=dev)
+    g = torch.empty((N, D), dtype=table_dtype, device=dev)
     stats = torch.empty((N, K, 4), dtype=torch.float32, device=dev)
     df1 = torch.empty((N, K), dtype=torch.float32, device=dev)
     dc = torch.empty((D,), dtype=torch.float32, device=dev)
@@ -219,7 +238,7 @@ def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=
     _lib.check(lib.han_node_attn_bwd_rows(
         dOut.data_ptr(), dOut.stride(0) if N > 1 else D, pre.data_ptr(), aggp.data_ptr(),
         tsum.data_ptr(), f1.data_ptr(), lse.data_ptr(), c.data_ptr(), g.data_ptr(),
-        stats.data_ptr(), df1.data_ptr(), dc.data_ptr(), ws.data_ptr(), ws.numel(), N, K, FP,
+        DTYPE_CODE[table_dtype], stats.data_ptr(), df1.data_ptr(), dc.data_ptr(), ws.data_ptr(), ws.numel(), N, K, FP,
         int(activation), _stream()), "han_node_attn_bwd_rows")
     return g, stats, df1, dc
 
@@ -235,9 +254,10 @@ def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, 
     _check_heads(K, FP)
     NS = graph_t.n_rows
     dev = H.device
-    _chk(g_tab, "g", (graph_t.n_cols, D), device=dev)
+    _chk(H, "H", (NS, D), dtype=H.dtype)
+    tcode = _dtype_code(H, "H")
+    _chk(g_tab, "g", (graph_t.n_cols, D), device=dev, dtype=H.dtype)
     _chk(stats_tab, "stats", (graph_t.n_cols, K, 4), device=dev)
-    _chk(H, "H", (NS, D))
     _chk(f2, "f2", (NS, K), device=dev)
     _chk(df1, "df1", (NS, K), device=dev)
     _chk(a1, "a1", (K, FP), device=dev)
@@ -248,7 +268,7 @@ def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, 
     split, _keep = _row_split_arg(graph_t, "b")
     _lib.check(lib.han_node_attn_bwd_cols(
         graph_t.rowptr.data_ptr(), graph_t.colidx.data_ptr(), g_tab.data_ptr(),
-        stats_tab.data_ptr(), H.data_ptr(), f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
+        stats_tab.data_ptr(), H.data_ptr(), tcode, f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
         NS, graph_t.nnz, K, FP, LEAKY_SLOPE, _check_drop(coef_drop, "coef_drop"), fts_drop,
         int(seed), int(src_offset), int(dst_offset),
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_bwd_cols")
@@ -261,7 +281,8 @@ def score_param_bwd(H, df1, df2, K=8, FP=8):
     _check_heads(K, FP)
     N = H.shape[0]
     dev = H.device
-    _chk(H, "H", (N, D))
+    _chk(H, "H", (N, D), dtype=H.dtype)
+    tcode = _dtype_code(H, "H")
     _chk(df1, "df1", (N, K), device=dev)
     _chk(df2, "df2", (N, K), device=dev)
     da1 = torch.empty((K, FP), dtype=torch.float32, device=dev)
@@ -270,7 +291,7 @@ def score_param_bwd(H, df1, df2, K=8, FP=8):
     db2 = torch.empty((K,), dtype=torch.float32, device=dev)
     ws = _ws(lib.han_score_param_bwd_workspace(N, K, FP), dev, "score")
     _lib.check(lib.han_score_param_bwd(
-        H.data_ptr(), df1.data_ptr(), df2.data_ptr(), da1.data_ptr(), da2.data_ptr(),
+        H.data_ptr(), tcode, df1.data_ptr(), df2.data_ptr(), da1.data_ptr(), da2.data_ptr(),
         db1.data_ptr(), db2.data_ptr(), ws.data_ptr(), ws.numel(), N, K, FP, _stream()),
         "han_score_param_bwd")
     return da1, da2, db1, db2

@@ -36,6 +36,11 @@ extern "C" {
 #define HAN_ACT_IDENTITY 0
 #define HAN_ACT_ELU      1
 
+/* storage type of X and of the gather tables H / g ("bf16 feats" of the 10M-node
+ * config): everything is accumulated in fp32; bf16 tables need K == FP == 8      */
+#define HAN_DTYPE_F32  0
+#define HAN_DTYPE_BF16 1
+
 int han_abi_version(void);
 const char *han_error_string(int code);
 
@@ -49,18 +54,19 @@ const char *han_error_string(int code);
  * fts_drop > 0 the keep bit of H[n][d] is stamped into mantissa bit 0 of that
  * float (a 1-ulp perturbation seen consistently by f1/f2, K2 and the backward),
  * so that K2 applies the mask while it gathers at no extra memory traffic.
- * X (N,F) ldx>=F; W (F,D); a1,a2 (K,FP); b1,b2 (K); H (N,D); f1,f2 (N,K).
+ * X (N,F) ldx>=F (elements; x_dtype fp32 or bf16); W (F,D); a1,a2 (K,FP); b1,b2 (K);
+ * H (N,D) in table_dtype (f1/f2 are taken from the rows as stored); f1,f2 (N,K).
  * in_drop == 0 -> no input dropout.  row_offset = global id of row 0 (RNG key). */
-int han_project_fwd(const float *X, int64_t ldx, const float *W, const float *a1,
-                    const float *a2, const float *b1, const float *b2, float *H,
-                    float *f1, float *f2, int64_t N, int F, int K, int FP,
+int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const float *W, const float *a1,
+                    const float *a2, const float *b1, const float *b2, void *H,
+                    int table_dtype, float *f1, float *f2, int64_t N, int F, int K, int FP,
                     float in_drop, float fts_drop, uint64_t seed, int64_t row_offset,
                     void *stream);
 
 /* dW = Xk^T dH (per head dropout masks regenerated from the seed).
  * workspace: han_project_bwd_workspace() bytes, any contents.              */
 size_t han_project_bwd_workspace(int64_t N, int F, int K, int FP);
-int han_project_bwd(const float *X, int64_t ldx, const float *dH, float *dW,
+int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const float *dH, float *dW,
                     void *workspace, size_t workspace_bytes, int64_t N, int F, int K,
                     int FP, float in_drop, uint64_t seed, int64_t row_offset, void *stream);
 
@@ -93,8 +99,8 @@ size_t han_row_split_workspace(int64_t n_chunks);
  * models/gat.py:46,58-60).  Training extras (all or none may be NULL): pre (N,D)
  * pre-activation, lse (N,K) log-sum-exp of the scores, aggp (N,D) and tsum (N,K)
  * -- the LeakyReLU'-weighted aggregates that make df1 row-local in the backward. */
-int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float *H,
-                      const float *f1, const float *a2, const float *b2, const float *c, float *out, int64_t out_stride,
+int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const void *H,
+                      int table_dtype, const float *f1, const float *a2, const float *b2, const float *c, float *out, int64_t out_stride,
                       float *pre, float *lse, float *aggp, float *tsum, int64_t N,
                       int64_t E, int K, int FP, float slope, float coef_drop,
                       float fts_drop, uint64_t seed, int64_t row_offset, int activation,
@@ -111,9 +117,10 @@ int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float 
 size_t han_node_attn_bwd_workspace(int64_t N, int K, int FP);
 int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *pre,
                            const float *aggp, const float *tsum, const float *f1,
-                           const float *lse, const float *c, float *g, float *stats,
-                           float *df1, float *dc, void *workspace, size_t workspace_bytes,
-                           int64_t N, int K, int FP, int activation, void *stream);
+                           const float *lse, const float *c, void *g, int table_dtype,
+                           float *stats, float *df1, float *dc, void *workspace,
+                           size_t workspace_bytes, int64_t N, int K, int FP, int activation,
+                           void *stream);
 
 /* Backward, step 2 (gather over the TRANSPOSED graph, no float atomics):
  * colptr (NS+1) / rowidx (E) list, for each source row j owned by this call,
@@ -125,8 +132,8 @@ int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *
  * dH (NS,D), df2 (NS,K) outputs.
  * src_offset / the ids in rowidx + dst_offset are the global ids used as RNG
  * keys (must match the forward).                                            */
-int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const float *g,
-                           const float *stats, const float *H, const float *f2,
+int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const void *g,
+                           const float *stats, const void *H, int table_dtype, const float *f2,
                            const float *df1, const float *a1, const float *a2,
                            float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                            float coef_drop, float fts_drop, uint64_t seed,
@@ -137,8 +144,8 @@ int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const f
  *   da1[k,f] = sum_n df1[n,k] H[n,k,f]   da2 likewise with df2
  *   db1[k] = sum_n df1[n,k]              db2[k] = sum_n df2[n,k]            */
 size_t han_score_param_bwd_workspace(int64_t N, int K, int FP);
-int han_score_param_bwd(const float *H, const float *df1, const float *df2, float *da1,
-                        float *da2, float *db1, float *db2, void *workspace,
+int han_score_param_bwd(const void *H, int table_dtype, const float *df1, const float *df2,
+                        float *da1, float *da2, float *db1, float *db2, void *workspace,
                         size_t workspace_bytes, int64_t N, int K, int FP, void *stream);
 
 /* ---- K3: semantic-level (meta-path) attention ------------------------------

@@ -27,7 +27,9 @@ def _rows_of(graph):
     return torch.repeat_interleave(torch.arange(graph.n_rows), graph.degrees())
 
 
-def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_offset=0):
+def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_offset=0,
+                table_dtype=torch.float32):
+    assert table_dtype == torch.float32, "the CPU stand-in covers fp32 tables only"
     N, F = X.shape
     K, FP = a1.shape
     x, w = _f64(X), _f64(W)
@@ -111,7 +113,8 @@ def node_attn_fwd(graph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=
     return out, saved
 
 
-def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=1, K=8, FP=8):
+def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=1, K=8, FP=8,
+                       table_dtype=torch.float32):
     N = pre.shape[0]
     p = _f64(pre)
     da = torch.where(p <= 0, torch.exp(p), torch.ones_like(p)) if activation == 1 else torch.ones_like(p)

@@ -606,3 +606,63 @@ def test_syn1m_size_independent_properties(dev):
     dH, df2 = ops.node_attn_bwd_cols(g.transpose(), gg, stats, H1, zero8, df1, z, z)
     assert abs(float(dH.double().sum()) - float(gg.double().sum())) < 1e-3 * float(gg.double().abs().sum()) ** 0.5 + 1.0
     assert float((dc.double() - gg.double().sum(0)).abs().max()) < 5e-2
+
+
+# ------------------------------------------------------------------------ bf16 tables
+def test_node_attn_bf16_table_exact_against_rounded_inputs(dev):
+    """bf16 storage, fp32 accumulate: fed the bf16-rounded rows, the oracle must be
+    matched to fp32 accuracy (the only error is the storage rounding of H itself)."""
+    from han_amd import ops
+    rng = np.random.default_rng(12)
+    n = 400
+    bias, rp, ci, H, f1, a2, b2, c, g = _k2_inputs(rng, n, 0.1, dev)
+    Hb = _t(H, dev).to(torch.bfloat16)
+    Hr = Hb.to(torch.float32).cpu().numpy().astype(np.float64)          # what the kernel reads
+    ref, pre_ref, lse_ref = _k2_oracle(bias, Hr, f1, _f2(Hr, a2, b2), c)
+    out, saved = ops.node_attn_fwd(g, Hb, _t(f1, dev), _t(a2, dev), _t(b2, dev), _t(c, dev), train=True)
+    assert np.abs(out.cpu().numpy() - ref).max() < TOL
+    assert np.abs(saved[0].cpu().numpy() - pre_ref).max() < TOL
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.6])
+def test_bf16_mode_forward_backward(dev, drop):
+    """configs[4] storage: X and the H / g tables in bf16.  Forward within bf16
+    rounding of the fp64 oracle; gradients within 3e-2 relative (bf16 g table)."""
+    from han_amd import rng as hrng
+    from han_amd.gat import HeteGAT_multi
+    from tests.helpers import load_params
+    prob = make_problem(91, 200, 32, 2, 3, [0.03, 0.3])
+    xb = torch.tensor(prob["x"][0], dtype=torch.float32).to(torch.bfloat16)
+    prob["x"] = xb.to(torch.float32).numpy().astype(np.float64)[None]     # the oracle sees the same bf16 features
+    bp = ht.to_batched(prob["params"])
+    model = HeteGAT_multi().build(2, 32, 3, device=dev, table_dtype=torch.bfloat16)
+    load_params(model, bp)
+    masks, keep = None, 1.0
+    hrng.manual_seed(31)
+    if drop > 0:
+        seeds = [hrng.next_seed() for _ in range(2)]
+        hrng.manual_seed(31)
+        keep = rng_ref.keep_prob32(drop)
+        masks = []
+        for q in range(2):
+            rp, ci = ho.bias_to_csr(prob["biases"][q])
+            masks.append({"seq": torch.tensor(rng_ref.seq_mask(seeds[q], 200, 32, 8, drop)),
+                          "coef": torch.tensor(rng_ref.coef_mask_csr(seeds[q], rp, ci, 8, drop)),
+                          "fts": torch.tensor(rng_ref.fts_mask(seeds[q], 200, 64, drop))})
+    loss_ref, gref, lg_ref = _oracle_grads(prob, bp, masks=masks, keep=keep, dense=False)
+    from han_amd import layers, ops
+    _, graphs = gpu_inputs(prob, dev)
+    labels = _t(prob["labels"], dev, torch.int32)
+    mask = _t(prob["mask"].astype(np.uint8), dev, torch.uint8)
+    model.zero_grad_flat()
+    xg = xb.to(dev)
+    M = model.node_level([xg, xg], graphs, drop, drop, True, ops.ACT_ELU)
+    Z, _ = layers.SemanticAttention.apply(M, model.w_omega, model.b_omega, model.u_omega)
+    loss, acc, logits = layers.ClassifierLoss.apply(Z, model.Wc, model.bc, labels, mask,
+                                                    1.0 / int(prob["mask"].sum()))
+    loss.backward()
+    # bf16 storage: ~0.4 % per stored element; compare relative to the largest magnitude
+    assert rel_err(logits.cpu().numpy(), lg_ref) < 4e-2
+    assert abs(float(loss) - loss_ref) < 4e-2 * max(1.0, abs(loss_ref))
+    for k in ht.PARAM_ORDER:
+        assert rel_err(getattr(model, k).grad.cpu().numpy(), gref[k]) < 6e-2, k
