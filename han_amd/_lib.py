@@ -37,6 +37,7 @@ SIGNATURES = {
     "han_project_bwd_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
     "han_project_bwd": (c_int, [P, c_int, I64, P, P, P, c_size_t, I64, c_int, c_int, c_int, c_float,
                                 c_uint64, I64, P]),
+    "han_project_bwd_input": (c_int, [P, P, P, I64, I64, c_int, c_int, c_int, c_float, c_uint64, I64, P]),
     "han_row_split_workspace": (c_size_t, [I64]),
     "han_node_attn_fwd": (c_int, [P, P, P, c_int, P, P, P, P, P, I64, P, P, P, P, I64, I64, c_int,
                                   c_int, c_float, c_float, c_float, c_uint64, I64, c_int, P, P]),

@@ -343,6 +343,78 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const ProjBwdArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// backward w.r.t. the INPUT (layers >= 1 of a multi-layer stack, models/gat.py:48-57):
+//   dX[n,f] = sum_k  m_k[n,f]/keep * sum_f'  dH[n, k*FP+f'] * W[f, k*FP+f']
+// One wave per 16 rows; per head a (16 x FP).(FP x 16) MFMA product, masked by that
+// head's input-dropout draw and accumulated.  dX rows may be strided (a slice of the
+// previous layer's dM).
+// ---------------------------------------------------------------------------
+struct ProjBwdInArgs {
+    const float *dH, *W;
+    float *dX;
+    int64_t ldo;
+    int64_t N;
+    int F;
+    uint32_t seed_lo, seed_hi, thr_in;
+    float inv_keep_in;
+    int64_t row_offset;
+};
+
+template <int FP, bool DROP>
+__global__ __launch_bounds__(256) void project_bwd_input_kernel(const ProjBwdInArgs a) {
+    constexpr int K = HAN_D / FP;
+    constexpr int KQ = (K + 3) / 4;
+    constexpr int KS = (FP + 3) / 4;          // MFMA k-steps per head (FP = 4 -> 1, 8 -> 2, ...)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t ntiles = (a.N + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = tile * 16;
+        const int64_t ra = r0 + l15 < a.N ? r0 + l15 : a.N - 1;
+        // A fragments: dH[row = l15][k*FP + 4s + l4]
+        float af[K][KS];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+                const int col = 4 * s2 + l4;
+                af[k][s2] = col < FP ? a.dH[ra * HAN_D + k * FP + col] : 0.f;
+            }
+        for (int f0 = 0; f0 < a.F; f0 += 16) {
+            const int f = f0 + l15;
+            const int fc = f < a.F ? f : a.F - 1;
+            f32x4 out = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                f32x4 acc = DROP ? (f32x4){0.f, 0.f, 0.f, 0.f} : out;
+#pragma unroll
+                for (int s2 = 0; s2 < KS; ++s2) {
+                    const int col = 4 * s2 + l4;
+                    const float b = col < FP ? a.W[(int64_t)fc * HAN_D + k * FP + col] : 0.f;   // B[kk][j=f]
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k][s2], b, acc, 0, 0, 0);
+                }
+                if (DROP) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const uint32_t nglob = (uint32_t)(r0 + 4 * l4 + reg + a.row_offset);
+                        const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob,
+                                                        (uint32_t)f * (uint32_t)KQ + (uint32_t)(k >> 2));
+                        out[reg] += rn.field(k & 3) < a.thr_in ? acc[reg] : 0.f;
+                    }
+                } else {
+                    out = acc;
+                }
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t row = r0 + 4 * l4 + reg;
+                if (row < a.N && f < a.F) a.dX[row * a.ldo + f] = DROP ? out[reg] * a.inv_keep_in : out[reg];
+            }
+        }
+    }
+}
+
 bool fp_ok(int K, int FP) {
     return K * FP == HAN_D && (FP == 4 || FP == 8 || FP == 16 || FP == 32 || FP == 64);
 }
@@ -450,5 +522,28 @@ extern "C" int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const fl
     const int width = F * HAN_D;
     hipError_t e = han_reduce_slabs((const float *)workspace, (int)nch, width, width, han_reduce_to(dW, width), st);
     if (e != hipSuccess) return (int)e;
+    return 0;
+}
+
+extern "C" int han_project_bwd_input(const float *dH, const float *W, float *dX, int64_t ldo, int64_t N,
+                                     int F, int K, int FP, float in_drop, uint64_t seed, int64_t row_offset,
+                                     void *stream) {
+    if (!dH || !W || !dX || N < 0 || F <= 0 || ldo < F) return HAN_E_BADARG;
+    if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
+    if (in_drop < 0.f || in_drop >= 1.f) return HAN_E_BADARG;
+    if (N == 0) return 0;
+    ProjBwdInArgs a;
+    a.dH = dH; a.W = W; a.dX = dX; a.ldo = ldo; a.N = N; a.F = F;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : HAN_KEEP_ALL;
+    a.inv_keep_in = 1.f / (1.f - in_drop);
+    a.row_offset = row_offset;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = han_grid_for((N + 15) / 16, 4, 256 * 8);
+    HAN_DISPATCH_FP(FP, {
+        if (in_drop > 0.f) project_bwd_input_kernel<FPC, true><<<grid, 256, 0, st>>>(a);
+        else project_bwd_input_kernel<FPC, false><<<grid, 256, 0, st>>>(a);
+    })
+    HAN_CHECK_LAUNCH();
     return 0;
 }

@@ -39,11 +39,17 @@ class _ClassOrInstance:
         return functools.partial(self.fn, obj)
 
 
-# name -> shape builder; order == flat layout == gradient all-reduce layout
-def _param_shapes(P, F, K, FP, A, C, HC):
-    return [("W", (P, F, D)), ("a1", (P, K, FP)), ("b1", (P, K)), ("a2", (P, K, FP)),
-            ("b2", (P, K)), ("c", (P, D)), ("w_omega", (D, A)), ("b_omega", (A,)),
-            ("u_omega", (A,)), ("Wc", (HC, D, C)), ("bc", (HC, C))]
+# name -> shape builder; order == flat layout == gradient all-reduce layout.
+# `extra` = [(K_i, FP_i)] for the node-attention layers i >= 1 (models/gat.py:48-57):
+# their variables are named W_i, a1_i, ... and sit right after layer 0's.
+def _param_shapes(P, F, K, FP, A, C, HC, extra=()):
+    shapes = [("W", (P, F, D)), ("a1", (P, K, FP)), ("b1", (P, K)), ("a2", (P, K, FP)),
+              ("b2", (P, K)), ("c", (P, D))]
+    for i, (Ki, FPi) in enumerate(extra, start=1):
+        shapes += [(f"W_{i}", (P, D, D)), (f"a1_{i}", (P, Ki, FPi)), (f"b1_{i}", (P, Ki)),
+                   (f"a2_{i}", (P, Ki, FPi)), (f"b2_{i}", (P, Ki)), (f"c_{i}", (P, D))]
+    return shapes + [("w_omega", (D, A)), ("b_omega", (A,)), ("u_omega", (A,)),
+                     ("Wc", (HC, D, C)), ("bc", (HC, C))]
 
 
 class HeteGAT_multi(BaseGAttN, torch.nn.Module):
@@ -76,11 +82,14 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         """Create the variables the reference's first inference() call creates
         (SURVEY.md 8a): glorot-uniform conv1d/dense kernels, zero biases,
         N(0, 0.1^2) semantic-attention variables."""
-        if len(hid_units) != 1:
-            raise NotImplementedError("multi-layer node attention (len(hid_units) > 1, "
-                                      "models/gat.py:48-57) is not built yet")
+        if len(n_heads) != len(hid_units) + 1:
+            raise ValueError("n_heads needs one entry per hidden layer plus the output entry "
+                             "(ex_acm3025.py:27)")
         K, FP, HC = int(n_heads[0]), int(hid_units[0]), int(n_heads[-1])
         ops._check_heads(K, FP)
+        self.extra = [(int(n_heads[i]), int(hid_units[i])) for i in range(1, len(hid_units))]
+        for Ki, FPi in self.extra:            # every layer's concatenated width is 64 in this build
+            ops._check_heads(Ki, FPi)
         if mp_att_size not in (64, 128):
             raise NotImplementedError("mp_att_size must be 64 or 128 in this build")
         if not (1 <= nb_classes <= 16):
@@ -91,7 +100,7 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         if table_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("table_dtype must be torch.float32 or torch.bfloat16")
         self.table_dtype = table_dtype       # storage of the projected rows / backward tables
-        shapes = _param_shapes(self.P, self.F, K, FP, self.A, self.C, HC)
+        shapes = _param_shapes(self.P, self.F, K, FP, self.A, self.C, HC, self.extra)
         total = sum(math.prod(s) for _, s in shapes)
         flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.register_buffer("flat", flat, persistent=False)        # storage owner
@@ -116,6 +125,10 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         uni(self.W, math.sqrt(6.0 / (self.F + FP)))          # conv1d kernel (1,F,F')
         uni(self.a1, math.sqrt(6.0 / (FP + 1)))              # conv1d kernel (1,F',1)
         uni(self.a2, math.sqrt(6.0 / (FP + 1)))
+        for i, (Ki, FPi) in enumerate(self.extra, start=1):
+            uni(getattr(self, f"W_{i}"), math.sqrt(6.0 / (D + FPi)))
+            uni(getattr(self, f"a1_{i}"), math.sqrt(6.0 / (FPi + 1)))
+            uni(getattr(self, f"a2_{i}"), math.sqrt(6.0 / (FPi + 1)))
         nrm(self.w_omega, 0.1)                               # utils/layers.py:145-147
         nrm(self.b_omega, 0.1)
         nrm(self.u_omega, 0.1)
@@ -124,8 +137,10 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         return self
 
     def trainable(self):
-        return [self._views[n] for n, _ in _param_shapes(self.P, self.F, self.K, self.FP,
-                                                         self.A, self.C, self.HC)]
+        return [self._views[n] for n, _ in self.param_shapes()]
+
+    def param_shapes(self):
+        return _param_shapes(self.P, self.F, self.K, self.FP, self.A, self.C, self.HC, self.extra)
 
     def zero_grad_flat(self):
         """Zero the flat gradient buffer and (re)bind every .grad to its slice."""
@@ -134,7 +149,7 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
 
     def _rebind_grads(self):
         off = 0
-        for name, shp in _param_shapes(self.P, self.F, self.K, self.FP, self.A, self.C, self.HC):
+        for name, shp in self.param_shapes():
             n = math.prod(shp)
             self._views[name].grad = self.flat_grad[off:off + n].view(shp)
             off += n
@@ -155,12 +170,19 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         return out
 
     def node_level(self, xs, graphs, attn_drop, ffd_drop, train, act_code, graphs_t=None):
-        cfg = {"train": train, "in_drop": float(ffd_drop), "coef_drop": float(attn_drop),
-               "seeds": tuple(rng.next_seed() for _ in graphs) if train else (0,) * len(graphs),
-               "act": act_code, "part": self.partition, "graphs_t": graphs_t,
-               "table_dtype": self.table_dtype}
-        return layers.NodeLevelAttention.apply(self.W, self.a1, self.b1, self.a2, self.b2, self.c,
-                                               tuple(xs), tuple(graphs), cfg)
+        """models/gat.py:39-60: every node-attention layer of every meta-path -> M (N,P,64)."""
+        def cfg():
+            return {"train": train, "in_drop": float(ffd_drop), "coef_drop": float(attn_drop),
+                    "seeds": tuple(rng.next_seed() for _ in graphs) if train else (0,) * len(graphs),
+                    "act": act_code, "part": self.partition, "graphs_t": graphs_t,
+                    "table_dtype": self.table_dtype}
+        M = layers.NodeLevelAttention.apply(None, self.W, self.a1, self.b1, self.a2, self.b2, self.c,
+                                            tuple(xs), tuple(graphs), cfg())
+        for i in range(1, len(self.extra) + 1):                                 # gat.py:48-57
+            g = lambda n: getattr(self, f"{n}_{i}")
+            M = layers.NodeLevelAttention.apply(M, g("W"), g("a1"), g("b1"), g("a2"), g("b2"), g("c"),
+                                                None, tuple(graphs), cfg())
+        return M
 
     @_ClassOrInstance
     def inference(self, inputs_list, nb_classes, nb_nodes, training, attn_drop, ffd_drop,
@@ -206,4 +228,5 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         if not self._built:
             raise RuntimeError("call build(...) or inference(...) first")
         return self.inference(inputs_list, self.C, None, None, attn_drop, ffd_drop, bias_mat_list,
-                              [self.FP], [self.K, self.HC], mp_att_size=self.A)
+                              [self.FP] + [e[1] for e in self.extra],
+                              [self.K] + [e[0] for e in self.extra] + [self.HC], mp_att_size=self.A)

@@ -43,8 +43,12 @@ def _act_code(activation):
 class NodeLevelAttention(torch.autograd.Function):
     """K1 + K2 for every meta-path: (X_p, graph_p) -> M (N, P, D).
 
-    forward(W (P,F,D), a1 (P,K,F'), b1 (P,K), a2, b2, c (P,D), xs, graphs, cfg)
-      xs      tuple of P feature tensors (N,F) (no gradient: they are inputs)
+    forward(Xin, W (P,F,D), a1 (P,K,F'), b1 (P,K), a2, b2, c (P,D), xs, graphs, cfg)
+      Xin     None for the first layer; for layers >= 1 (models/gat.py:48-57) the
+              previous layer's output (N,P,F): meta-path p reads Xin[:, p, :] and the
+              backward returns dXin
+      xs      tuple of P feature tensors (N,F) (no gradient: they are inputs);
+              ignored when Xin is given
       graphs  tuple of P CSRGraph (rows = local destinations)
       cfg     dict: train (bool), in_drop, coef_drop, seeds (tuple of P ints),
               act (kernel activation code), part (NodePartition or None),
@@ -53,8 +57,11 @@ class NodeLevelAttention(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, W, a1, b1, a2, b2, c, xs, graphs, cfg):
+    def forward(ctx, Xin, W, a1, b1, a2, b2, c, xs, graphs, cfg):
         P = len(graphs)
+        if Xin is not None:
+            Xin = Xin.contiguous()
+            xs = tuple(Xin[:, p, :] for p in range(P))
         K, FP = a1.shape[1], a1.shape[2]
         part: NodePartition | None = cfg.get("part")
         train = bool(cfg["train"])
@@ -85,6 +92,7 @@ class NodeLevelAttention(torch.autograd.Function):
                 saved.append((H, f1, f2) + sv)
         del proj
         ctx.cfg, ctx.xs, ctx.graphs = cfg, xs, graphs
+        ctx.xin_shape = tuple(Xin.shape) if Xin is not None else None
         ctx.saved_per_p = saved
         ctx.in_drop, ctx.coef_drop = in_drop, coef_drop
         ctx.save_for_backward(W, a1, b1, a2, b2, c)
@@ -103,6 +111,9 @@ class NodeLevelAttention(torch.autograd.Function):
         graphs_t = cfg.get("graphs_t") or tuple(g.transpose() for g in graphs)
         row_offset = part.row_start if part is not None else 0
         dW = torch.empty_like(W)
+        dXin = None
+        if ctx.xin_shape is not None and ctx.needs_input_grad[0]:
+            dXin = torch.empty(ctx.xin_shape, dtype=torch.float32, device=W.device)
         da1, da2 = torch.empty_like(a1), torch.empty_like(a2)
         db1, db2 = torch.empty_like(b1), torch.empty_like(b2)
         dc = torch.empty_like(c)
@@ -131,8 +142,11 @@ class NodeLevelAttention(torch.autograd.Function):
             da1[p], da2[p], db1[p], db2[p] = d1, d2, e1, e2
             dW[p] = ops.project_bwd(xs[p], dH, K, FP, in_drop=ctx.in_drop, seed=seed,
                                     row_offset=row_offset)
+            if dXin is not None:
+                ops.project_bwd_input(dH, W[p], K, FP, out=dXin[:, p, :], in_drop=ctx.in_drop,
+                                      seed=seed, row_offset=row_offset)
         ctx.saved_per_p = None
-        return dW, da1, db1, da2, db2, dc, None, None, None
+        return dXin, dW, da1, db1, da2, db2, dc, None, None, None
 
 
 class SemanticAttention(torch.autograd.Function):
@@ -245,7 +259,7 @@ def _single_head(seq, out_sz, graph, activation, in_drop, coef_drop, residual, p
     train = bool(training) or in_drop > 0 or coef_drop > 0 or W.requires_grad
     cfg = {"train": train, "in_drop": in_drop, "coef_drop": coef_drop,
            "seeds": (rng.next_seed() if seed is None else seed,), "act": code, "part": None}
-    M = NodeLevelAttention.apply(W, a1, b1, a2, b2, c, (x,), (graph,), cfg)
+    M = NodeLevelAttention.apply(None, W, a1, b1, a2, b2, c, (x,), (graph,), cfg)
     ret = M[:, 0, :out_sz]
     if residual:
         # utils/layers.py:38-42: only the dims-differ branch has an effect

@@ -158,6 +158,30 @@ def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0):
     return dW
 
 
+def project_bwd_input(dH, W, K, FP, out=None, in_drop=0.0, seed=0, row_offset=0):
+    """dX (N,F) = sum_k mask_k/keep * (dH_k @ W_k^T): gradient w.r.t. the layer input
+    (only layers >= 1 of a multi-layer stack need it).  `out`: optional (N,F) view
+    with unit inner stride (e.g. dM_prev[:, p, :])."""
+    lib = _lib.load()
+    _check_heads(K, FP)
+    N = dH.shape[0]
+    F = W.shape[0]
+    dev = dH.device
+    _chk(dH, "dH", (N, D))
+    _chk(W, "W", (F, D), device=dev)
+    if out is None:
+        out = torch.empty((N, F), dtype=torch.float32, device=dev)
+    else:
+        _chk(out, "out", (N, F), device=dev, contiguous=False)
+        if out.stride(1) != 1:
+            raise ValueError("out: rows must be contiguous")
+    _lib.check(lib.han_project_bwd_input(
+        dH.data_ptr(), W.data_ptr(), out.data_ptr(), out.stride(0) if N > 1 else max(F, out.stride(0)),
+        N, F, K, FP, _check_drop(in_drop, "in_drop"), int(seed), int(row_offset), _stream()),
+        "han_project_bwd_input")
+    return out
+
+
 # --------------------------------------------------------------------------- K2
 def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=0.0,
                   fts_drop=0.0, seed=0, row_offset=0, activation=ACT_ELU):

@@ -70,6 +70,13 @@ int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const float *dH, fl
                     void *workspace, size_t workspace_bytes, int64_t N, int F, int K,
                     int FP, float in_drop, uint64_t seed, int64_t row_offset, void *stream);
 
+/* dX = sum_k mask_k/keep * (dH_k W_k^T): gradient w.r.t. the layer INPUT, needed only
+ * for layers >= 1 of a multi-layer stack (models/gat.py:48-57).  dH (N,D); W (F,D);
+ * dX (N,F) with row stride ldo (a slice of the previous layer's dM).            */
+int han_project_bwd_input(const float *dH, const float *W, float *dX, int64_t ldo, int64_t N,
+                          int F, int K, int FP, float in_drop, uint64_t seed,
+                          int64_t row_offset, void *stream);
+
 /* Row splitting for skewed graphs (optional; pass NULL for none).  Rows (sources, in
  * the backward) with more than split_deg stored entries are skipped by the main
  * launch; each is cut into chunks of consecutive edges [chunk_start, chunk_end),

@@ -300,10 +300,12 @@ def flatten_params(params):
 
 
 def init_params(rng, n_metapaths, ft_size, nb_classes, hid=8, n_heads=(8, 1),
-                mp_att_size=128, dtype=np.float64, nonzero_biases=False):
+                mp_att_size=128, dtype=np.float64, nonzero_biases=False, hid_units=None):
     """Initialisers as the reference's TF defaults.
     nonzero_biases=True perturbs the zero-initialised biases so that parity
     tests exercise them."""
+    if hid_units is not None:
+        hid = hid_units[0]
     K = n_heads[0]
     D = K * hid
 
@@ -323,7 +325,25 @@ def init_params(rng, n_metapaths, ft_size, nb_classes, hid=8, n_heads=(8, 1),
                 'c': bias((hid,)),
             })
         heads.append(hp)
+    layers = None
+    if hid_units is not None and len(hid_units) > 1:     # models/gat.py:48-57
+        layers = []
+        for _ in range(n_metapaths):
+            lp, width = [], D
+            for i in range(1, len(hid_units)):
+                hi = hid_units[i]
+                lp.append([{
+                    'W': glorot_uniform(rng, width, hi, (width, hi), dtype),
+                    'a1': glorot_uniform(rng, hi, 1, (hi,), dtype), 'b1': bias(()),
+                    'a2': glorot_uniform(rng, hi, 1, (hi,), dtype), 'b2': bias(()),
+                    'c': bias((hi,)),
+                } for _ in range(n_heads[i])])
+                width = n_heads[i] * hi
+            layers.append(lp)
+        D = n_heads[len(hid_units) - 1] * hid_units[-1]
+    out_extra = {} if layers is None else {'layers': layers}
     return {
+        **out_extra,
         'heads': heads,
         'w_omega': (0.1 * rng.standard_normal((D, mp_att_size))).astype(dtype),
         'b_omega': (0.1 * rng.standard_normal((mp_att_size,))).astype(dtype),

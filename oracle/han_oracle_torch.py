@@ -39,10 +39,34 @@ def to_batched(params, dtype=torch.float64):
         'bc': torch.stack([t(c['b']) for c in params['cls']]),
     }
     assert out['W'].shape[0] == P and out['a1'].shape[1] == K
+    if 'layers' in params:                      # extra node-attention layers, models/gat.py:48-57
+        n_extra = len(params['layers'][0])
+        for i in range(n_extra):
+            lh = [params['layers'][p][i] for p in range(P)]
+            sfx = f'_{i + 1}'
+            out['W' + sfx] = torch.stack([torch.cat([t(h['W']) for h in hp], dim=1) for hp in lh])
+            for nm in ('a1', 'a2', 'b1', 'b2'):
+                out[nm + sfx] = torch.stack([torch.stack([t(h[nm]) for h in hp]) for hp in lh])
+            out['c' + sfx] = torch.stack([torch.cat([t(h['c']) for h in hp]) for hp in lh])
     return out
 
 
 PARAM_ORDER = ('W', 'a1', 'b1', 'a2', 'b2', 'c', 'w_omega', 'b_omega', 'u_omega', 'Wc', 'bc')
+
+
+def n_extra_layers(bp):
+    n = 0
+    while f'W_{n + 1}' in bp:
+        n += 1
+    return n
+
+
+def param_order(bp):
+    """PARAM_ORDER plus the extra layers' variables (after layer 0's, per layer)."""
+    names = list(PARAM_ORDER[:6])
+    for i in range(1, n_extra_layers(bp) + 1):
+        names += [f'{nm}_{i}' for nm in ('W', 'a1', 'b1', 'a2', 'b2', 'c')]
+    return tuple(names) + PARAM_ORDER[6:]
 
 
 def node_attention_dense(x, bias_mat, W, a1, b1, a2, b2, c, keep_in=1.0, keep_coef=1.0,
@@ -133,6 +157,15 @@ def hetegat_forward(x_list, graphs, bp, keep_in=1.0, keep_coef=1.0, masks=None, 
         else:
             e = node_attention_csr(x, g[0], g[1], *args, keep_in=keep_in, keep_coef=keep_coef,
                                    masks=mk)
+        for i in range(1, n_extra_layers(bp) + 1):                      # gat.py:48-57
+            sfx = f'_{i}'
+            largs = tuple(bp[nm + sfx][p] for nm in ('W', 'a1', 'b1', 'a2', 'b2', 'c'))
+            lmk = mk['layers'][i - 1] if (mk is not None and 'layers' in mk) else None
+            if dense:
+                e = node_attention_dense(e, g, *largs, keep_in=keep_in, keep_coef=keep_coef, masks=lmk)
+            else:
+                e = node_attention_csr(e, g[0], g[1], *largs, keep_in=keep_in, keep_coef=keep_coef,
+                                       masks=lmk)
         embeds.append(e[:, None, :])                                    # gat.py:58
     m = torch.cat(embeds, dim=1)                                        # gat.py:60
     final_embed, att = semantic_attention(m, bp['w_omega'], bp['b_omega'], bp['u_omega'])

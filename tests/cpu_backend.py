@@ -61,6 +61,21 @@ def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0):
     return dW.to(torch.float32)
 
 
+def project_bwd_input(dH, W, K, FP, out=None, in_drop=0.0, seed=0, row_offset=0):
+    N, F = dH.shape[0], W.shape[0]
+    d, w = _f64(dH), _f64(W)
+    if in_drop > 0:
+        keep = rng_ref.keep_prob32(in_drop)
+        sm = torch.tensor(rng_ref.seq_mask(seed, N, F, K, in_drop, row_offset))
+        dX = sum(sm[k] / keep * (d[:, k * FP:(k + 1) * FP] @ w[:, k * FP:(k + 1) * FP].t()) for k in range(K))
+    else:
+        dX = d @ w.t()
+    if out is None:
+        out = torch.empty((N, F), dtype=torch.float32)
+    out.copy_(dX.to(torch.float32))
+    return out
+
+
 def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset):
     K, FP = a2.shape
     rows = _rows_of(graph)
@@ -209,7 +224,7 @@ def l2_half_sumsq(param):
     return (param.double() ** 2).sum().mul(0.5).to(torch.float32).reshape(1)
 
 
-_NAMES = ("project_fwd", "project_bwd", "node_attn_fwd", "node_attn_bwd_rows", "node_attn_bwd_cols",
+_NAMES = ("project_fwd", "project_bwd", "project_bwd_input", "node_attn_fwd", "node_attn_bwd_rows", "node_attn_bwd_cols",
           "score_param_bwd", "sem_attn_fwd", "sem_attn_bwd", "classifier_loss", "adam_step",
           "l2_half_sumsq")
 

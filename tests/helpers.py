@@ -25,12 +25,14 @@ def random_adj(rng, n, density, symmetric=True, special_rows=True):
     return a
 
 
-def make_problem(seed, n, f, p, c, densities, dtype=np.float64, nonzero_biases=True):
+def make_problem(seed, n, f, p, c, densities, dtype=np.float64, nonzero_biases=True, hid_units=None,
+                 n_heads=(8, 1)):
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((1, n, f)).astype(dtype)
     adjs = [random_adj(rng, n, densities[i % len(densities)])[None] for i in range(p)]
     biases = [ho.adj_to_bias(a, [n], 1) for a in adjs]
-    params = ho.init_params(rng, p, f, c, nonzero_biases=nonzero_biases)
+    params = ho.init_params(rng, p, f, c, nonzero_biases=nonzero_biases, hid_units=hid_units,
+                            n_heads=n_heads)
     labels = rng.integers(0, c, size=n)
     onehot = np.eye(c)[labels]
     mask = rng.random(n) < 0.4
@@ -42,15 +44,19 @@ def make_problem(seed, n, f, p, c, densities, dtype=np.float64, nonzero_biases=T
 def load_params(model, bp):
     """Copy batched oracle parameters (han_oracle_torch.to_batched) into a built model."""
     with torch.no_grad():
-        for k in ht.PARAM_ORDER:
+        for k in ht.param_order(bp):
             getattr(model, k).copy_(bp[k].to(torch.float32))
 
 
 def build_model(prob, dev, mp_att_size=128):
     from han_amd.gat import HeteGAT_multi
     model = HeteGAT_multi()
-    model.build(prob["p"], prob["f"], prob["c"], (8,), (8, len(prob["params"]["cls"])),
-                mp_att_size, device=dev)
+    hid_units, n_heads = (8,), (8, len(prob["params"]["cls"]))
+    if "layers" in prob["params"]:
+        lp = prob["params"]["layers"][0]
+        hid_units = (8,) + tuple(len(l[0]["a1"]) for l in lp)
+        n_heads = (8,) + tuple(len(l) for l in lp) + (len(prob["params"]["cls"]),)
+    model.build(prob["p"], prob["f"], prob["c"], hid_units, n_heads, mp_att_size, device=dev)
     bp = ht.to_batched(prob["params"])
     load_params(model, bp)
     return model, bp

@@ -666,3 +666,54 @@ def test_bf16_mode_forward_backward(dev, drop):
     assert abs(float(loss) - loss_ref) < 4e-2 * max(1.0, abs(loss_ref))
     for k in ht.PARAM_ORDER:
         assert rel_err(getattr(model, k).grad.cpu().numpy(), gref[k]) < 6e-2, k
+
+
+# ------------------------------------------------------------------------ multi-layer
+@pytest.mark.parametrize("drop", [0.0, 0.6])
+def test_multi_layer_stack_matches_oracle(dev, drop):
+    """models/gat.py:48-57 with hid_units=[8,16], n_heads=[8,4,1]: forward through
+    inference(), and loss + every gradient (incl. han_project_bwd_input, which carries
+    the second layer's gradient back into the first) against the float64 oracle."""
+    from han_amd import layers, ops, rng as hrng
+    prob = make_problem(62, 150, 11, 2, 3, [0.05, 0.4], hid_units=[8, 16], n_heads=(8, 4, 1))
+    model, bp = build_model(prob, dev)
+    x, graphs = gpu_inputs(prob, dev)
+    if drop == 0:
+        lg_np, fe_np, att_np = ho.hetegat_multi_inference([prob["x"]] * 2, 3, 150, False, 0.0, 0.0,
+                                                          prob["biases"], [8, 16], [8, 4, 1], prob["params"])
+        with torch.no_grad():
+            logits, fe, att = model.inference([x[None]] * 2, 3, 150, False, 0.0, 0.0, graphs, [8, 16], [8, 4, 1])
+        assert np.abs(logits.cpu().numpy() - lg_np).max() < TOL
+        assert np.abs(fe.cpu().numpy() - fe_np).max() < TOL
+    hrng.manual_seed(19)
+    seeds = [hrng.next_seed() for _ in range(4)]
+    hrng.manual_seed(19)
+    model.zero_grad_flat()
+    M = model.node_level([x, x], graphs, drop, drop, True, ops.ACT_ELU)
+    Z, _ = layers.SemanticAttention.apply(M, model.w_omega, model.b_omega, model.u_omega)
+    loss, _, logits = layers.ClassifierLoss.apply(Z, model.Wc, model.bc, _t(prob["labels"], dev, torch.int32),
+                                                  _t(prob["mask"].astype(np.uint8), dev, torch.uint8),
+                                                  1.0 / int(prob["mask"].sum()))
+    loss.backward()
+    masks, keep = None, 1.0
+    if drop > 0:
+        keep = rng_ref.keep_prob32(drop)
+        masks = []
+        for q in range(2):
+            rp, ci = ho.bias_to_csr(prob["biases"][q])
+            mk = lambda sd, f, K: {"seq": torch.tensor(rng_ref.seq_mask(sd, 150, f, K, drop)),
+                                   "coef": torch.tensor(rng_ref.coef_mask_csr(sd, rp, ci, K, drop)),
+                                   "fts": torch.tensor(rng_ref.fts_mask(sd, 150, 64, drop))}
+            m0 = mk(seeds[q], 11, 8)
+            m0["layers"] = [mk(seeds[2 + q], 64, 4)]
+            masks.append(m0)
+    bpo = {k: v.clone().requires_grad_(True) for k, v in bp.items()}
+    og = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]
+    lg_ref, _, _ = ht.hetegat_forward([torch.tensor(prob["x"][0])] * 2, og, bpo, keep_in=keep,
+                                      keep_coef=keep, masks=masks)
+    loss_ref = ht.masked_softmax_cross_entropy(lg_ref, torch.tensor(prob["onehot"]), torch.tensor(prob["mask"]))
+    loss_ref.backward()
+    assert rel_err(logits.cpu().numpy(), lg_ref.detach().numpy()) < 1e-4
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 5e-4 * max(1.0, float(loss_ref.detach()))
+    for k in ht.param_order(bp):
+        assert rel_err(getattr(model, k).grad.cpu().numpy(), bpo[k].grad.numpy()) < GTOL, k

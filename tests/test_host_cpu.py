@@ -174,10 +174,14 @@ def test_model_variables_and_initialisers():
     assert float(m.a1.abs().max()) <= math.sqrt(6.0 / 9) + 1e-7
     assert float(m.b1.abs().max()) == 0 and float(m.c.abs().max()) == 0 and float(m.bc.abs().max()) == 0
     assert abs(float(m.w_omega.std()) - 0.1) < 0.01
-    with pytest.raises(NotImplementedError):
-        HeteGAT_multi().build(2, 10, 3, (8, 8), (8, 8, 1), device="cpu")       # multi-layer: not yet
+    m2 = HeteGAT_multi().build(2, 10, 3, (8, 8), (8, 8, 1), device="cpu")      # models/gat.py:48-57
+    assert tuple(m2.W_1.shape) == (2, 64, 64) and tuple(m2.a1_1.shape) == (2, 8, 8)
     with pytest.raises(NotImplementedError):
         HeteGAT_multi().build(2, 10, 3, (8,), (4, 1), device="cpu")            # K*F' != 64
+    with pytest.raises(NotImplementedError):
+        HeteGAT_multi().build(2, 10, 3, (8, 8), (8, 4, 1), device="cpu")       # layer 1: 4*8 != 64
+    with pytest.raises(ValueError):
+        HeteGAT_multi().build(2, 10, 3, (8, 8), (8, 1), device="cpu")          # n_heads too short
 
 
 def test_no_cpu_fallback_in_the_product():
@@ -247,3 +251,54 @@ def test_evaluate_and_checkpoint(cpu_ops, tmp_path):
     assert not torch.equal(snap, model.flat)
     tr.load_checkpoint(path)
     assert torch.equal(snap, model.flat) and tr.opt.t == t
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.6])
+def test_multi_layer_stack_on_cpu_backend(cpu_ops, drop):
+    """models/gat.py:48-57: hid_units=[8,16], n_heads=[8,4,1] -- the second layer
+    reads the first layer's concatenated heads; gradients flow back through both."""
+    from han_amd import layers, rng as hrng
+    from han_amd.gat import HeteGAT_multi
+    prob = make_problem(61, 40, 9, 2, 3, [0.15, 0.4], hid_units=[8, 16], n_heads=(8, 4, 1))
+    bp = ht.to_batched(prob["params"])
+    assert ht.n_extra_layers(bp) == 1 and bp["W_1"].shape == (2, 64, 64) and bp["a1_1"].shape == (2, 4, 16)
+    model = HeteGAT_multi().build(2, 9, 3, (8, 16), (8, 4, 1), device="cpu")
+    load_params(model, bp)
+    graphs = _cpu_graphs(prob)
+    x = torch.tensor(prob["x"][0], dtype=torch.float32)
+    hrng.manual_seed(9)
+    seeds = [hrng.next_seed() for _ in range(4)]          # layer 0: p0,p1 ; layer 1: p0,p1
+    hrng.manual_seed(9)
+    model.zero_grad_flat()
+    M = model.node_level([x, x], graphs, drop, drop, True, 1)
+    Z, _ = layers.SemanticAttention.apply(M, model.w_omega, model.b_omega, model.u_omega)
+    loss, _, _ = layers.ClassifierLoss.apply(Z, model.Wc, model.bc, torch.tensor(prob["labels"], dtype=torch.int32),
+                                             torch.tensor(prob["mask"].astype(np.uint8)),
+                                             1.0 / int(prob["mask"].sum()))
+    loss.backward()
+    masks, keep = None, 1.0
+    if drop > 0:
+        keep = rng_ref.keep_prob32(drop)
+        masks = []
+        for q in range(2):
+            rp, ci = ho.bias_to_csr(prob["biases"][q])
+            mk = lambda sd, f, K: {"seq": torch.tensor(rng_ref.seq_mask(sd, 40, f, K, drop)),
+                                   "coef": torch.tensor(rng_ref.coef_mask_csr(sd, rp, ci, K, drop)),
+                                   "fts": torch.tensor(rng_ref.fts_mask(sd, 40, 64, drop))}
+            m0 = mk(seeds[q], 9, 8)
+            m0["layers"] = [mk(seeds[2 + q], 64, 4)]
+            masks.append(m0)
+    bpo = {k: v.clone().requires_grad_(True) for k, v in bp.items()}
+    og = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]
+    lg_ref, _, _ = ht.hetegat_forward([torch.tensor(prob["x"][0])] * 2, og, bpo, keep_in=keep,
+                                      keep_coef=keep, masks=masks)
+    loss_ref = ht.masked_softmax_cross_entropy(lg_ref, torch.tensor(prob["onehot"]), torch.tensor(prob["mask"]))
+    loss_ref.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-5
+    for k in ht.param_order(bp):
+        assert rel_err(getattr(model, k).grad.numpy(), bpo[k].grad.numpy()) < 1e-4, k
+    # numpy restatement of the multi-layer forward (models/gat.py:48-57) agrees too
+    lg_np, _, _ = ho.hetegat_multi_inference([prob["x"]] * 2, 3, 40, False, 0.0, 0.0, prob["biases"],
+                                             [8, 16], [8, 4, 1], prob["params"])
+    if drop == 0:
+        assert np.abs(lg_np[0] - lg_ref.detach().numpy()).max() < 1e-10
