@@ -139,16 +139,22 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
         st.l += p;
         float pd = p;
         if (TRAIN) {
+            // The 1/keep factors of both dropouts are applied once per row in write_row,
+            // not per edge: here a dropped term is simply zeroed.
             if (drop_c) {   // attention dropout, layers.py:29-30
                 const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
                                                 (uint32_t)j[u] * (uint32_t)KQ + (uint32_t)(head >> 2));
-                pd = rn.field(head & 3) < a.thr_coef ? p * a.inv_keep_coef : 0.f;
+                pd = rn.field(head & 3) < a.thr_coef ? p : 0.f;
             }
-            // projected-row dropout, layers.py:31-32 (after the score was taken)
+            // projected-row dropout, layers.py:31-32 (after the score was taken): AND the
+            // element with the sign-extended keep bit (one v_bfe_i32 + one v_and per element)
             if (a.lsb_mask) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    hv[u][t] = han_keep_bit<BF>(hv[u][t]) ? hv[u][t] * a.inv_keep_fts : 0.f;
+                for (int t = 0; t < 4; ++t) {
+                    const int bits = __float_as_int(hv[u][t]);
+                    const int keep = __builtin_amdgcn_sbfe(bits, BF ? 16 : 0, 1);   // 0 or -1
+                    hv[u][t] = __int_as_float(bits & keep);
+                }
             }
         }
 #pragma unroll
@@ -169,10 +175,12 @@ __device__ __forceinline__ void write_row(const FwdArgs &a, const int64_t row, c
                                           const int q, const int head, const float4_t &c4, const bool writer) {
     constexpr int K = HAN_D / FP;
     const float inv = st.l > 0.f ? 1.f / st.l : 0.f;
+    // acc / accp carry the zero-or-keep terms; the two 1/keep factors go in here
+    const float scale = TRAIN ? inv * a.inv_keep_coef * (a.lsb_mask ? a.inv_keep_fts : 1.f) : inv;
     float4_t pv, ov;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        pv[t] = st.acc[t] * inv + c4[t];
+        pv[t] = st.acc[t] * scale + c4[t];
         ov[t] = a.activation == HAN_ACT_ELU ? han_elu(pv[t]) : pv[t];
     }
     if (writer) {
@@ -180,7 +188,7 @@ __device__ __forceinline__ void write_row(const FwdArgs &a, const int64_t row, c
         if (TRAIN) {
             float4_t ap;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) ap[t] = st.accp[t] * inv;
+            for (int t = 0; t < 4; ++t) ap[t] = st.accp[t] * scale;
             *reinterpret_cast<float4_t *>(a.pre + row * HAN_D + 4 * q) = pv;
             *reinterpret_cast<float4_t *>(a.aggp + row * HAN_D + 4 * q) = ap;
             if ((4 * q) % FP == 0) {

@@ -3,6 +3,7 @@
 Same names, argument meaning and return values as the reference:
 
 * :func:`attn_head`       -- utils/layers.py:7-46  (dense additive-mask form)
+* :func:`attn_head_const_1` -- utils/layers.py:49-81 (HAN_nd ablation)
 * :func:`sp_attn_head`    -- utils/layers.py:85-127 (SparseTensor form)
 * :func:`SimpleAttLayer`  -- utils/layers.py:132-164
 
@@ -286,6 +287,20 @@ def attn_head(seq, out_sz, bias_mat, activation, in_drop=0.0, coef_drop=0.0, res
         return F_torch.elu(inner)
     return _single_head(seq, out_sz, as_graph(bias_mat, seq.device), activation, in_drop,
                         coef_drop, residual, params, training, seed)
+
+
+def attn_head_const_1(seq, out_sz, bias_mat, activation, in_drop=0.0, coef_drop=0.0, residual=False, *,
+                      params, training=False, seed=None):
+    """utils/layers.py:49-81 (the HAN_nd ablation): logits := adjacency, i.e. every
+    stored neighbour gets the same weight 1/deg (mean aggregator).  The same kernel
+    with zero score parameters.  params: W (F,out_sz), c (out_sz,)."""
+    z = torch.zeros_like(params["c"])
+    p = {"W": params["W"], "a1": z, "a2": z, "b1": z.new_zeros(()), "b2": z.new_zeros(()), "c": params["c"]}
+    for k in ("res_W", "res_b"):
+        if k in params:
+            p[k] = params[k]
+    return attn_head(seq, out_sz, bias_mat, activation, in_drop=in_drop, coef_drop=coef_drop,
+                     residual=residual, params=p, training=training, seed=seed)
 
 
 def sp_attn_head(seq, out_sz, adj_mat, activation, nb_nodes, in_drop=0.0, coef_drop=0.0,

@@ -433,6 +433,10 @@ def test_attn_head_and_sp_attn_head_api(dev):
     assert np.abs(out_sp.cpu().numpy() - ref).max() < TOL
     ref_sp = ho.sp_attn_head(prob["x"], head, rp, ci)
     assert np.abs(out_sp.cpu().numpy() - ref_sp).max() < TOL
+    # HAN_nd ablation head (layers.py:49-81): uniform 1/deg weights
+    with torch.no_grad():
+        out_c = layers.attn_head_const_1(x, 8, _t(prob["biases"][0], dev), Fnn.elu, params=params)
+    assert np.abs(out_c.cpu().numpy() - ho.attn_head_const_1(prob["x"], head, prob["biases"][0])).max() < TOL
 
 
 def test_errors_are_loud(dev):
