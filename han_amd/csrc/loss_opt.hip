@@ -25,7 +25,9 @@ struct ClsArgs {
     int C, HC;
 };
 
-template <bool BWD>
+// CM = compile-time bound on the class count (4, 8 or 16): every per-class loop is
+// unrolled to CM, so small C does not pay for 16 shuffle reductions per row.
+template <bool BWD, int CM>
 __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
     __shared__ float Wm[64 * MAXC];
     __shared__ float bm[MAXC];
@@ -45,10 +47,10 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
     const int q = threadIdx.x & 15;
     const int64_t grp0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int64_t ngrp = (int64_t)gridDim.x * 16;
-    float dW[4][MAXC];
-    float dbacc[MAXC];
+    float dW[4][CM];
+    float dbacc[CM];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < CM; ++c) {
         dbacc[c] = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) dW[t][c] = 0.f;
@@ -56,9 +58,9 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
     float loss_acc = 0.f, acc_acc = 0.f;
     for (int64_t row = grp0; row < a.N; row += ngrp) {
         const float4_t z4 = *reinterpret_cast<const float4_t *>(a.Z + row * 64 + 4 * q);
-        float lg[MAXC];
+        float lg[CM];
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < CM; ++c) {
             float s = 0.f;
             if (c < C) {
 #pragma unroll
@@ -71,32 +73,32 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
         if (q < C) {
             float v = 0.f;
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) v = (q == c) ? lg[c] : v;
+            for (int c = 0; c < CM; ++c) v = (q == c) ? lg[c] : v;
             a.logits[row * C + q] = v;
         }
         float mx = lg[0];
         int am = 0;
 #pragma unroll
-        for (int c = 1; c < MAXC; ++c)
+        for (int c = 1; c < CM; ++c)
             if (lg[c] > mx) { mx = lg[c]; am = c; }
         float se = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) se += c < C ? __expf(lg[c] - mx) : 0.f;
+        for (int c = 0; c < CM; ++c) se += c < C ? __expf(lg[c] - mx) : 0.f;
         const int lab = a.labels[row];
         const float w = a.mask[row] ? a.row_weight : 0.f;
         float llab = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) llab = (c == lab) ? lg[c] : llab;
+        for (int c = 0; c < CM; ++c) llab = (c == lab) ? lg[c] : llab;
         if (q == 0) {
             loss_acc += w * (mx + __logf(se) - llab);
             acc_acc += w * (am == lab ? 1.f : 0.f);
         }
         if (BWD) {
             const float inv = 1.f / se;
-            float dl[MAXC];
+            float dl[CM];
             float4_t dz = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
+            for (int c = 0; c < CM; ++c) {
                 dl[c] = c < C ? w * (__expf(lg[c] - mx) * inv - (c == lab ? 1.f : 0.f)) : 0.f;
                 if (c < C) {
 #pragma unroll
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
         if (grp == r) {
             if (BWD) {
 #pragma unroll
-                for (int c = 0; c < MAXC; ++c) {
+                for (int c = 0; c < CM; ++c) {
                     if (c < C) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
@@ -233,8 +235,16 @@ extern "C" int han_classifier_loss(const float *Z, const float *Wc, const float 
     a.Z = Z; a.Wc = Wc; a.bc = bc; a.labels = labels; a.mask = mask; a.row_weight = row_weight;
     a.logits = logits; a.dZ = dZ; a.slab = (float *)workspace; a.N = N; a.C = C; a.HC = HC;
     const int grid = han_grid_for(N > 0 ? N : 1, 16, kClsBlocks);
-    if (bwd) classifier_kernel<true><<<grid, 256, 0, st>>>(a);
-    else classifier_kernel<false><<<grid, 256, 0, st>>>(a);
+    if (C <= 4) {
+        if (bwd) classifier_kernel<true, 4><<<grid, 256, 0, st>>>(a);
+        else classifier_kernel<false, 4><<<grid, 256, 0, st>>>(a);
+    } else if (C <= 8) {
+        if (bwd) classifier_kernel<true, 8><<<grid, 256, 0, st>>>(a);
+        else classifier_kernel<false, 8><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (bwd) classifier_kernel<true, 16><<<grid, 256, 0, st>>>(a);
+        else classifier_kernel<false, 16><<<grid, 256, 0, st>>>(a);
+    }
     HAN_CHECK_LAUNCH();
     const int width = 64 * C + C + 2;
     // loss / accuracy (the last two slab columns), then the head gradients: every

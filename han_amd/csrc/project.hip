@@ -247,7 +247,6 @@ __global__ __launch_bounds__(256) void project_scores_kernel(const ScoreArgs a) 
 // a chunk of rows; partial tiles go to a slab, a second kernel sums the chunks
 // (deterministic, no float atomics).
 // ---------------------------------------------------------------------------
-constexpr int BF = 64;       // f rows of dW per block
 constexpr int BN = 32;       // reduction step (rows of X / dH)
 constexpr int TS_LD = 80;
 
@@ -265,80 +264,134 @@ struct ProjBwdArgs {
     int64_t row_offset;
 };
 
-template <int FP, bool DROP>
+// MT = 16-row (f) MFMA tiles per wave: the block owns 64*MT rows of dW, so dH is
+// re-read F/(64*MT) times; VEC = 16-byte fp32 X loads.  With dropout every head a
+// column tile covers has its own accumulator (A masked per head), as in the forward.
+template <int FP, bool DROP, int MT, bool VEC>
 __global__ __launch_bounds__(256) void project_bwd_kernel(const ProjBwdArgs a) {
     constexpr int K = HAN_D / FP;
-    constexpr int KQ = (K + 3) / 4;   // one RNG call = four 16-bit draws = four heads
-    constexpr int HPT = HeadsPerTile<FP>::value;
-    __shared__ float Xs[BN * TS_LD];
+    constexpr int KQ = (K + 3) / 4;
+    constexpr int HPT = DROP ? HeadsPerTile<FP>::value : 1;
+    constexpr int BFR = 64 * MT;              // f rows of dW per block
+    constexpr int XLD = BFR + 16;             // (XLD mod 32) == 16: conflict-free fragment reads
+    constexpr int XL = (BN * BFR) / 256;      // X elements per thread per step
+    __shared__ float Xs[BN * XLD];
     __shared__ float Gs[BN * TS_LD];
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int f0 = blockIdx.x * BF;
+    const int f0 = blockIdx.x * BFR;
     const int64_t chunk = blockIdx.y;
     const int64_t n_begin = chunk * a.rows_per_chunk;
     const int64_t n_end = (n_begin + a.rows_per_chunk < a.N) ? n_begin + a.rows_per_chunk : a.N;
 
-    f32x4 acc[4];
+    f32x4 acc[MT][4][HPT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int hh = 0; hh < HPT; ++hh) acc[m][t][hh] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float xr[8], gr[8];
+    float xr[XL];
+    float4_t gr4[2];
     auto load_tile = [&](int64_t n0) {
+        if (VEC) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < XL / 4; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx / (BFR / 4), c4 = (idx % (BFR / 4)) * 4;
+                const int64_t row = n0 + r;
+                float4_t v = {0.f, 0.f, 0.f, 0.f};
+                if (row < n_end && f0 + c4 < a.F) v = load_x4(a.X, a.x_bf16, row * a.ldx + f0 + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xr[4 * i + e] = v[e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XL; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx / BFR, cc = idx % BFR;
+                const int64_t row = n0 + r;
+                xr[i] = (row < n_end && f0 + cc < a.F) ? load_x1(a.X, a.x_bf16, row * a.ldx + f0 + cc) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
-            const int r = idx >> 6, cc = idx & 63;
-            const int64_t row = n0 + r;
-            const int f = f0 + cc;
-            xr[i] = (row < n_end && f < a.F) ? load_x1(a.X, a.x_bf16, row * a.ldx + f) : 0.f;
-            gr[i] = row < n_end ? a.dH[row * HAN_D + cc] : 0.f;
+            const int64_t row = n0 + (idx >> 4);
+            gr4[i] = row < n_end ? *reinterpret_cast<const float4_t *>(a.dH + row * HAN_D + (idx & 15) * 4)
+                                 : (float4_t){0.f, 0.f, 0.f, 0.f};
         }
     };
     load_tile(n_begin);
-    const uint32_t fglob = (uint32_t)(f0 + 16 * w + l15);
     for (int64_t n0 = n_begin; n0 < n_end; n0 += BN) {
         __syncthreads();
+        if (VEC) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < XL / 4; ++i) {
+                const int idx = tid + 256 * i;
+                *reinterpret_cast<float4_t *>(Xs + (idx / (BFR / 4)) * XLD + (idx % (BFR / 4)) * 4) =
+                    (float4_t){xr[4 * i], xr[4 * i + 1], xr[4 * i + 2], xr[4 * i + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XL; ++i) {
+                const int idx = tid + 256 * i;
+                Xs[(idx / BFR) * XLD + (idx % BFR)] = xr[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
-            Xs[(idx >> 6) * TS_LD + (idx & 63)] = xr[i];
-            Gs[(idx >> 6) * TS_LD + (idx & 63)] = gr[i];
+            *reinterpret_cast<float4_t *>(Gs + (idx >> 4) * TS_LD + (idx & 15) * 4) = gr4[i];
         }
         __syncthreads();
         if (n0 + BN < n_end) load_tile(n0 + BN);
 #pragma unroll
         for (int kk = 0; kk < BN; kk += 4) {
-            // A[i = f][k = n] = X[n][f]
-            const float av = Xs[(kk + l4) * TS_LD + 16 * w + l15];
+            float bv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv[t] = Gs[(kk + l4) * TS_LD + 16 * t + l15];
             const uint32_t nglob = (uint32_t)(n0 + kk + l4 + a.row_offset);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float bv = Gs[(kk + l4) * TS_LD + 16 * t + l15];
-                if (!DROP) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
-                } else {
+            for (int m = 0; m < MT; ++m) {
+                // A[i = f][k = n] = X[n][f]
+                const int lf = 16 * (w * MT + m) + l15;
+                const float av = Xs[(kk + l4) * XLD + lf];
+                const uint32_t fglob = (uint32_t)(f0 + lf);
 #pragma unroll
-                    for (int hh = 0; hh < HPT; ++hh) {
-                        const int head = (16 * t) / FP + hh;
-                        const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob,
-                                                        fglob * (uint32_t)KQ + (uint32_t)(head >> 2));
-                        const float am = rn.field(head & 3) < a.thr_in ? av : 0.f;
-                        const float bm = (HPT == 1 || (l15 / FP) == hh) ? bv : 0.f;
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bm, acc[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) {
+                    if (!DROP) {
+                        acc[m][t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[m][t][0], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int hh = 0; hh < HPT; ++hh) {
+                            const int head = (16 * t) / FP + hh;
+                            const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob,
+                                                            fglob * (uint32_t)KQ + (uint32_t)(head >> 2));
+                            const float am = rn.field(head & 3) < a.thr_in ? av : 0.f;
+                            acc[m][t][hh] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bv[t], acc[m][t][hh], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
     }
     float *out = a.slab + chunk * (int64_t)a.F * HAN_D;
+    const int myhh = HPT > 1 ? l15 / FP : 0;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = f0 + 16 * w + l4 * 4 + r;
-            if (f < a.F) out[(int64_t)f * HAN_D + 16 * t + l15] = DROP ? acc[t][r] * a.inv_keep_in : acc[t][r];
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = f0 + 16 * (w * MT + m) + l4 * 4 + r;
+                float v = acc[m][t][0][r];
+#pragma unroll
+                for (int hh = 1; hh < HPT; ++hh) v = (myhh == hh) ? acc[m][t][hh][r] : v;
+                if (f < a.F) out[(int64_t)f * HAN_D + 16 * t + l15] = DROP ? v * a.inv_keep_in : v;
+            }
         }
     }
 }
@@ -419,8 +472,10 @@ bool fp_ok(int K, int FP) {
     return K * FP == HAN_D && (FP == 4 || FP == 8 || FP == 16 || FP == 32 || FP == 64);
 }
 
+constexpr int kBwdMT = 2;   // project_bwd: 128 f rows per block
+
 void bwd_geometry(int64_t N, int F, int *ftiles, int64_t *rows_per_chunk, int64_t *nchunks) {
-    *ftiles = (F + BF - 1) / BF;
+    *ftiles = (F + 64 * kBwdMT - 1) / (64 * kBwdMT);
     int64_t target = 1024 / *ftiles;
     if (target < 1) target = 1;
     int64_t rpc = (N + target - 1) / target;
@@ -514,9 +569,15 @@ extern "C" int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const fl
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
     dim3 grid(ftiles, (unsigned)nch);
+    const bool vec = !a.x_bf16 && (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
     HAN_DISPATCH_FP(FP, {
-        if (in_drop > 0.f) project_bwd_kernel<FPC, true><<<grid, 256, 0, st>>>(a);
-        else project_bwd_kernel<FPC, false><<<grid, 256, 0, st>>>(a);
+        if (in_drop > 0.f) {
+            if (vec) project_bwd_kernel<FPC, true, kBwdMT, true><<<grid, 256, 0, st>>>(a);
+            else project_bwd_kernel<FPC, true, kBwdMT, false><<<grid, 256, 0, st>>>(a);
+        } else {
+            if (vec) project_bwd_kernel<FPC, false, kBwdMT, true><<<grid, 256, 0, st>>>(a);
+            else project_bwd_kernel<FPC, false, kBwdMT, false><<<grid, 256, 0, st>>>(a);
+        }
     })
     HAN_CHECK_LAUNCH();
     const int width = F * HAN_D;

@@ -44,6 +44,35 @@ def main():
         t = timeit(lambda: ops.sem_attn_bwd(M, w, b, u, beta, dZ))
         print(json.dumps({"kernel": "sem_attn_bwd", "ms": round(t, 4), "TFLOPs": round(3 * fl / t / 1e9, 1)}))
         del M, dZ, Z, beta
+    if "k2" in which:
+        from han_amd import synth
+        g = synth.random_regular_graph(n, 50, 1234, dev)
+        gt = g.transpose()
+        a1, a2, b1, b2 = rnd(8, 8) * 0.3, rnd(8, 8) * 0.3, rnd(8) * 0.1, rnd(8) * 0.1
+        c = rnd(64) * 0.1
+        X = rnd(n, 64)
+        W = torch.eye(64, device=dev)
+        for tdt in (torch.float32, torch.bfloat16):
+            H, f1, f2 = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.6, fts_drop=0.6, seed=3, table_dtype=tdt)
+            out = torch.empty((n, 64), device=dev)
+            tag = "f32" if tdt == torch.float32 else "bf16"
+            t = timeit(lambda: ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out))
+            print(json.dumps({"kernel": f"k2 fwd eval {tag}", "ms": round(t, 4)}))
+            for cd, fd in ((0.0, 0.0), (0.6, 0.0), (0.0, 0.6), (0.6, 0.6)):
+                t = timeit(lambda: ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=cd,
+                                                     fts_drop=fd, seed=3))
+                print(json.dumps({"kernel": f"k2 fwd train {tag} coef_drop={cd} fts_drop={fd}", "ms": round(t, 4)}))
+            _, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=0.6, fts_drop=0.6, seed=3)
+            pre, lse, aggp, tsum = sv
+            dOut = rnd(n, 64)
+            gg, stats, df1, dc = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, table_dtype=tdt)
+            t = timeit(lambda: ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, table_dtype=tdt))
+            print(json.dumps({"kernel": f"k2 bwd rows {tag}", "ms": round(t, 4)}))
+            for cd in (0.0, 0.6):
+                t = timeit(lambda: ops.node_attn_bwd_cols(gt, gg, stats, H, f2, df1, a1, a2, coef_drop=cd,
+                                                          fts_drop=0.6, seed=3))
+                print(json.dumps({"kernel": f"k2 bwd cols {tag} coef_drop={cd}", "ms": round(t, 4)}))
+        del g, gt, X, H
     if "k1" in which:
         X = rnd(n, f)
         W = rnd(f, 64) * 0.1
