@@ -52,6 +52,7 @@ struct FwdArgs {
     const int64_t *rowptr;
     const int32_t *colidx;
     const void *H;  // fp32 (256-B rows) or bf16 (128-B rows) table
+    const int32_t *gid;   // global id of each table row (halo tables), or null: the index is the id
     int lsb_mask;   // training with fts dropout: the lowest mantissa bit of every H element is its keep bit
     const float *f1;
     const float *a2;
@@ -142,8 +143,9 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
             // The 1/keep factors of both dropouts are applied once per row in write_row,
             // not per edge: here a dropped term is simply zeroed.
             if (drop_c) {   // attention dropout, layers.py:29-30
+                const uint32_t gj = a.gid ? (uint32_t)a.gid[j[u]] : (uint32_t)j[u];
                 const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
-                                                (uint32_t)j[u] * (uint32_t)KQ + (uint32_t)(head >> 2));
+                                                gj * (uint32_t)KQ + (uint32_t)(head >> 2));
                 pd = rn.field(head & 3) < a.thr_coef ? p : 0.f;
             }
             // projected-row dropout, layers.py:31-32 (after the score was taken): AND the
@@ -432,6 +434,7 @@ struct BwdColsArgs {
     const int64_t *colptr;
     const int32_t *rowidx;
     const void *g, *H;   // fp32 or bf16 tables
+    const int32_t *gid;  // global id of each row of the g / stats tables, or null
     const float *stats, *f2, *df1, *a1, *a2;
     int lsb_mask;
     float *dH, *df2;
@@ -496,7 +499,7 @@ __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)
         float am = 1.f;
         if (drop_c) {
             const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF,
-                                            (uint32_t)((int64_t)i[u] + a.dst_offset),
+                                            (uint32_t)((a.gid ? (int64_t)a.gid[i[u]] : (int64_t)i[u]) + a.dst_offset),
                                             sr.gj * (uint32_t)KQ + (uint32_t)(head >> 2));
             am = rn.field(head & 3) < a.thr_coef ? a.inv_keep_coef : 0.f;
         }
@@ -762,7 +765,7 @@ static bool dtype_ok(int dt, int FP) {
 }
 
 extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const void *H, int table_dtype,
-                                 const float *f1, const float *a2, const float *b2,
+                                 const int32_t *table_gid, const float *f1, const float *a2, const float *b2,
                                  const float *c, float *out, int64_t out_stride, float *pre, float *lse,
                                  float *aggp, float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
                                  float coef_drop, float fts_drop, uint64_t seed, int64_t row_offset,
@@ -777,7 +780,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     if ((coef_drop > 0.f || fts_drop > 0.f) && !train) return HAN_E_BADARG;
     if (N == 0) return 0;
     FwdArgs a;
-    a.rowptr = rowptr; a.colidx = colidx; a.H = H; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.a2 = a2; a.b2 = b2; a.c = c;
+    a.rowptr = rowptr; a.colidx = colidx; a.H = H; a.gid = table_gid; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.a2 = a2; a.b2 = b2; a.c = c;
     a.out = out; a.out_stride = out_stride; a.pre = pre; a.lse = lse; a.aggp = aggp; a.tsum = tsum;
     a.N = N; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
@@ -844,7 +847,8 @@ extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, co
 }
 
 extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const void *g,
-                                      const float *stats, const void *H, int table_dtype, const float *f2,
+                                      const float *stats, const int32_t *table_gid, const void *H,
+                                      int table_dtype, const float *f2,
                                       const float *df1, const float *a1, const float *a2,
                                       float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                                       float coef_drop, float fts_drop, uint64_t seed, int64_t src_offset,
@@ -856,7 +860,7 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
     if (NS == 0) return 0;
     BwdColsArgs a;
-    a.colptr = colptr; a.rowidx = rowidx; a.g = g; a.stats = stats; a.H = H; a.lsb_mask = fts_drop > 0.f; a.f2 = f2;
+    a.colptr = colptr; a.rowidx = rowidx; a.g = g; a.stats = stats; a.gid = table_gid; a.H = H; a.lsb_mask = fts_drop > 0.f; a.f2 = f2;
     a.df1 = df1; a.a1 = a1; a.a2 = a2; a.dH = dH; a.df2 = df2; a.NS = NS; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;

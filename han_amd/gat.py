@@ -62,6 +62,7 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         self._built = False
         self._device = torch.device(device) if device is not None else None
         self.partition: NodePartition | None = None
+        self.halo_plans = (None, None)        # (forward, backward) per-meta-path HaloPlan lists
         self._graph_cache: dict = {}
 
     @classmethod
@@ -175,7 +176,8 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
             return {"train": train, "in_drop": float(ffd_drop), "coef_drop": float(attn_drop),
                     "seeds": tuple(rng.next_seed() for _ in graphs) if train else (0,) * len(graphs),
                     "act": act_code, "part": self.partition, "graphs_t": graphs_t,
-                    "table_dtype": self.table_dtype}
+                    "table_dtype": self.table_dtype, "plans_f": self.halo_plans[0],
+                    "plans_b": self.halo_plans[1]}
         M = layers.NodeLevelAttention.apply(None, self.W, self.a1, self.b1, self.a2, self.b2, self.c,
                                             tuple(xs), tuple(graphs), cfg())
         for i in range(1, len(self.extra) + 1):                                 # gat.py:48-57

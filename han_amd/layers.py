@@ -54,7 +54,9 @@ class NodeLevelAttention(torch.autograd.Function):
       cfg     dict: train (bool), in_drop, coef_drop, seeds (tuple of P ints),
               act (kernel activation code), part (NodePartition or None),
               table_dtype (torch.float32 | torch.bfloat16: storage of the H / g tables),
-              graphs_t (tuple of P transposed graphs for the backward, or None)
+              graphs_t (tuple of P transposed graphs for the backward, or None),
+              plans_f / plans_b (per meta-path HaloPlan or None: halo exchange instead of
+              the all-gather, forward / backward tables)
     """
 
     @staticmethod
@@ -73,6 +75,7 @@ class NodeLevelAttention(torch.autograd.Function):
         row_offset = part.row_start if part is not None else 0
         saved = []
         multi = part is not None and part.active
+        plans_f = cfg.get("plans_f") if multi else None      # per meta-path HaloPlan or None
         # all projections first, each table's all-gather started as soon as it exists:
         # the exchange of meta-path p+1.. overlaps the node attention of meta-path p
         proj = []
@@ -81,14 +84,20 @@ class NodeLevelAttention(torch.autograd.Function):
             H, f1, f2 = ops.project_fwd(xs[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
                                         fts_drop=in_drop, seed=seed, row_offset=row_offset,
                                         table_dtype=cfg.get("table_dtype", torch.float32))
-            proj.append((H, f1, f2, part.all_gather_rows_async(H) if multi else None))
+            plan = plans_f[p] if plans_f is not None else None
+            handle = None
+            if multi:      # halo rows only (HaloPlan) or the whole shard (all-gather)
+                handle = plan.exchange_async(H) if plan is not None else part.all_gather_rows_async(H)
+            proj.append((H, f1, f2, handle))
         for p in range(P):
             H, f1, f2, handle = proj[p]
             H_tab = handle.wait() if multi else H
-            _, sv = ops.node_attn_fwd(graphs[p], H_tab, f1, a2[p], b2[p], c[p], out=M[:, p, :],
-                                      train=train, coef_drop=coef_drop, fts_drop=in_drop,
-                                      seed=int(cfg["seeds"][p]), row_offset=row_offset,
-                                      activation=cfg["act"])
+            plan = plans_f[p] if plans_f is not None else None
+            _, sv = ops.node_attn_fwd(plan.graph if plan is not None else graphs[p], H_tab, f1, a2[p], b2[p],
+                                      c[p], out=M[:, p, :], train=train, coef_drop=coef_drop,
+                                      fts_drop=in_drop, seed=int(cfg["seeds"][p]), row_offset=row_offset,
+                                      activation=cfg["act"],
+                                      table_gid=plan.gid if plan is not None else None)
             if train:
                 saved.append((H, f1, f2) + sv)
         del proj
@@ -119,6 +128,7 @@ class NodeLevelAttention(torch.autograd.Function):
         db1, db2 = torch.empty_like(b1), torch.empty_like(b2)
         dc = torch.empty_like(c)
         multi = part is not None and part.active
+        plans_b = cfg.get("plans_b") if multi else None
         rows = []
         for p in range(P):      # row-local halves first; their tables go out while we continue
             H, f1, f2, pre, lse, aggp, tsum = ctx.saved_per_p[p]
@@ -127,7 +137,9 @@ class NodeLevelAttention(torch.autograd.Function):
                                                         table_dtype=H.dtype)
             dc[p] = dcp
             if multi:
-                rows.append((part.all_gather_rows_async(g), part.all_gather_rows_async(stats), df1))
+                plan = plans_b[p] if plans_b is not None else None
+                ex = plan.exchange_async if plan is not None else part.all_gather_rows_async
+                rows.append((ex(g), ex(stats), df1))
             else:
                 rows.append((g, stats, df1))
         for p in range(P):
@@ -135,9 +147,12 @@ class NodeLevelAttention(torch.autograd.Function):
             seed = int(cfg["seeds"][p])
             g_h, st_h, df1 = rows[p]
             g_tab, stats_tab = (g_h.wait(), st_h.wait()) if multi else (g_h, st_h)
-            dH, df2 = ops.node_attn_bwd_cols(graphs_t[p], g_tab, stats_tab, H, f2, df1, a1[p], a2[p],
+            plan = plans_b[p] if plans_b is not None else None
+            dH, df2 = ops.node_attn_bwd_cols(plan.graph if plan is not None else graphs_t[p], g_tab,
+                                             stats_tab, H, f2, df1, a1[p], a2[p],
                                              coef_drop=ctx.coef_drop, fts_drop=ctx.in_drop, seed=seed,
-                                             src_offset=row_offset, dst_offset=0)
+                                             src_offset=row_offset, dst_offset=0,
+                                             table_gid=plan.gid if plan is not None else None)
             rows[p] = None
             d1, d2, e1, e2 = ops.score_param_bwd(H, df1, df2, K=K, FP=FP)
             da1[p], da2[p], db1[p], db2[p] = d1, d2, e1, e2

@@ -184,11 +184,12 @@ def project_bwd_input(dH, W, K, FP, out=None, in_drop=0.0, seed=0, row_offset=0)
 
 # --------------------------------------------------------------------------- K2
 def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=0.0,
-                  fts_drop=0.0, seed=0, row_offset=0, activation=ACT_ELU):
+                  fts_drop=0.0, seed=0, row_offset=0, activation=ACT_ELU, table_gid=None):
     """utils/layers.py:26-35,46.  H_tab (NT,D): gather table of UNDROPPED projected
     rows indexed by graph.colidx (f2_j is recomputed from the gathered row with
     a2 (K,F'), b2 (K,)); with fts_drop > 0 bit 0 of each element is its keep bit
-    (as project_fwd stamped it); f1 (N,K) local rows; c (D,).  `out`: optional (N,D) view with unit inner
+    (as project_fwd stamped it); f1 (N,K) local rows; c (D,).  table_gid (NT,)
+    int32: global id of each table row when H_tab is a [local | halo] table.  `out`: optional (N,D) view with unit inner
     stride (e.g. M[:,p,:]).  Returns out, saved where
     saved = (pre, lse, aggp, tsum) if train else None."""
     lib = _lib.load()
@@ -202,6 +203,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
     _chk(a2, "a2", (K, FP), device=dev)
     _chk(b2, "b2", (K,), device=dev)
     _chk(c, "c", (D,), device=dev)
+    if table_gid is not None:
+        _chk(table_gid, "table_gid", (graph.n_cols,), dtype=torch.int32, device=dev)
     if graph.device != dev:
         raise ValueError("graph and tables must be on the same device")
     if out is None:
@@ -229,7 +232,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     _lib.check(lib.han_node_attn_fwd(
-        graph.rowptr.data_ptr(), graph.colidx.data_ptr(), H_tab.data_ptr(), tcode, f1.data_ptr(),
+        graph.rowptr.data_ptr(), graph.colidx.data_ptr(), H_tab.data_ptr(), tcode,
+        table_gid.data_ptr() if table_gid is not None else None, f1.data_ptr(),
         a2.data_ptr(), b2.data_ptr(), c.data_ptr(), out.data_ptr(), out.stride(0) if N > 1 else D,
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
         int(seed), int(row_offset), int(activation),
@@ -268,7 +272,7 @@ def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=
 
 
 def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=0.0,
-                       fts_drop=0.0, seed=0, src_offset=0, dst_offset=0):
+                       fts_drop=0.0, seed=0, src_offset=0, dst_offset=0, table_gid=None):
     """Transposed-graph half of the K2 backward.  graph_t rows = local sources j,
     its colidx = destinations i indexing g_tab (NT,D) / stats_tab (NT,K,4).
     H (NS,D) undropped local rows (keep bits in bit 0 when fts_drop > 0),
@@ -282,6 +286,8 @@ def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, 
     tcode = _dtype_code(H, "H")
     _chk(g_tab, "g", (graph_t.n_cols, D), device=dev, dtype=H.dtype)
     _chk(stats_tab, "stats", (graph_t.n_cols, K, 4), device=dev)
+    if table_gid is not None:
+        _chk(table_gid, "table_gid", (graph_t.n_cols,), dtype=torch.int32, device=dev)
     _chk(f2, "f2", (NS, K), device=dev)
     _chk(df1, "df1", (NS, K), device=dev)
     _chk(a1, "a1", (K, FP), device=dev)
@@ -292,7 +298,8 @@ def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, 
     split, _keep = _row_split_arg(graph_t, "b")
     _lib.check(lib.han_node_attn_bwd_cols(
         graph_t.rowptr.data_ptr(), graph_t.colidx.data_ptr(), g_tab.data_ptr(),
-        stats_tab.data_ptr(), H.data_ptr(), tcode, f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
+        stats_tab.data_ptr(), table_gid.data_ptr() if table_gid is not None else None, H.data_ptr(),
+        tcode, f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
         NS, graph_t.nnz, K, FP, LEAKY_SLOPE, _check_drop(coef_drop, "coef_drop"), fts_drop,
         int(seed), int(src_offset), int(dst_offset),
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_bwd_cols")

@@ -23,7 +23,7 @@ from .graph import CSRGraph, as_graph
 class HANTrainer:
     def __init__(self, model: HeteGAT_multi, xs, graphs, labels, train_mask, val_mask=None,
                  lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
-                 part: NodePartition | None = None, patience=100):
+                 part: NodePartition | None = None, patience=100, max_halo_fraction=0.6):
         """xs: list of P (N_local,F) feature tensors (this rank's rows);
         graphs: list of P CSRGraph (or dense masks / CSR tuples) -- the GLOBAL graphs when `part` is given
         (they are sharded here), else the local==global graphs;
@@ -40,9 +40,13 @@ class HANTrainer:
             sharded = [self.part.shard_graph(g) for g in graphs]
             self.graphs = [s[0] for s in sharded]
             self.graphs_t = [s[1] for s in sharded]
+            # halo exchange where the graph has locality, all-gather where it has none
+            model.halo_plans = ([self.part.plan_exchange(g, max_halo_fraction) for g in self.graphs],
+                                [self.part.plan_exchange(g, max_halo_fraction) for g in self.graphs_t])
         else:
             self.graphs = list(graphs)
             self.graphs_t = [g.transpose() for g in graphs]
+            model.halo_plans = (None, None)
         self.labels = labels.to(device=dev, dtype=torch.int32).contiguous()
         self.train_mask = train_mask.to(device=dev, dtype=torch.uint8).contiguous()
         self.val_mask = (val_mask if val_mask is not None else train_mask).to(

@@ -101,13 +101,16 @@ size_t han_row_split_workspace(int64_t n_chunks);
  * rowptr (N+1) int64, colidx (E) int32 indexing the NT-row table H (NT,D) (the
  * UNDROPPED projected rows; with fts_drop > 0 bit 0 of every element is its keep
  * bit, as han_project_fwd stamped it); the neighbour score
- * f2_j = H_j[k].a2[k] + b2[k] is recomputed from the gathered row.  f1 (N,K) for the local rows; a2 (K,FP); b2 (K); c (D).  out row i is written
+ * f2_j = H_j[k].a2[k] + b2[k] is recomputed from the gathered row.  table_gid (NT)
+ * int32 or NULL: the GLOBAL node id of each table row when the table is a
+ * [local | halo] table of a node partition (the dropout RNG is keyed by global
+ * ids); NULL means the table index is the global id.  f1 (N,K) for the local rows; a2 (K,FP); b2 (K); c (D).  out row i is written
  * at out + i*out_stride (so the K heads land directly in M[:,p,:],
  * models/gat.py:46,58-60).  Training extras (all or none may be NULL): pre (N,D)
  * pre-activation, lse (N,K) log-sum-exp of the scores, aggp (N,D) and tsum (N,K)
  * -- the LeakyReLU'-weighted aggregates that make df1 row-local in the backward. */
 int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const void *H,
-                      int table_dtype, const float *f1, const float *a2, const float *b2, const float *c, float *out, int64_t out_stride,
+                      int table_dtype, const int32_t *table_gid, const float *f1, const float *a2, const float *b2, const float *c, float *out, int64_t out_stride,
                       float *pre, float *lse, float *aggp, float *tsum, int64_t N,
                       int64_t E, int K, int FP, float slope, float coef_drop,
                       float fts_drop, uint64_t seed, int64_t row_offset, int activation,
@@ -140,7 +143,8 @@ int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *
  * src_offset / the ids in rowidx + dst_offset are the global ids used as RNG
  * keys (must match the forward).                                            */
 int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const void *g,
-                           const float *stats, const void *H, int table_dtype, const float *f2,
+                           const float *stats, const int32_t *table_gid, const void *H,
+                           int table_dtype, const float *f2,
                            const float *df1, const float *a1, const float *a2,
                            float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                            float coef_drop, float fts_drop, uint64_t seed,

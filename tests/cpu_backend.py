@@ -76,7 +76,7 @@ def project_bwd_input(dH, W, K, FP, out=None, in_drop=0.0, seed=0, row_offset=0)
     return out
 
 
-def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset):
+def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset, table_gid=None):
     K, FP = a2.shape
     rows = _rows_of(graph)
     cols = graph.colidx.long()
@@ -94,7 +94,8 @@ def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset)
     am = torch.ones_like(alpha)
     if coef_drop > 0:
         keep = rng_ref.keep_prob32(coef_drop)
-        am = torch.tensor(rng_ref.coef_mask_csr(seed, graph.rowptr.numpy(), graph.colidx.numpy(), K,
+        cols_g = graph.colidx.numpy() if table_gid is None else table_gid.numpy()[graph.colidx.numpy()]
+        am = torch.tensor(rng_ref.coef_mask_csr(seed, graph.rowptr.numpy(), cols_g, K,
                                                 coef_drop, row_offset)) / keep
     hd = h
     if fts_drop > 0:
@@ -105,11 +106,11 @@ def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset)
 
 
 def node_attn_fwd(graph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=0.0, fts_drop=0.0,
-                  seed=0, row_offset=0, activation=1):
+                  seed=0, row_offset=0, activation=1, table_gid=None):
     K, FP = a2.shape
     N = graph.n_rows
     rows, cols, alpha, am, sg, lse, hd = _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop,
-                                                     seed, row_offset)
+                                                     seed, row_offset, table_gid)
     hk = hd.view(-1, K, FP)[cols]                                    # (E,K,FP)
     agg = torch.zeros((N, K, FP), dtype=torch.float64).index_add(0, rows, (alpha * am)[:, :, None] * hk)
     pre = agg.reshape(N, D) + _f64(c)
@@ -143,7 +144,7 @@ def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=1, K=8, FP=
 
 
 def node_attn_bwd_cols(graph_t, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=0.0, fts_drop=0.0,
-                       seed=0, src_offset=0, dst_offset=0):
+                       seed=0, src_offset=0, dst_offset=0, table_gid=None):
     K, FP = a1.shape
     NS = graph_t.n_rows
     src = _rows_of(graph_t)                       # local source j per transposed edge
@@ -155,7 +156,8 @@ def node_attn_bwd_cols(graph_t, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=
     am = torch.ones_like(alpha)
     if coef_drop > 0:
         keep = rng_ref.keep_prob32(coef_drop)
-        am = torch.tensor(rng_ref.coef_draws(seed, dst.numpy() + dst_offset, src.numpy() + src_offset,
+        dst_g = dst.numpy() if table_gid is None else table_gid.numpy()[dst.numpy()]
+        am = torch.tensor(rng_ref.coef_draws(seed, dst_g + dst_offset, src.numpy() + src_offset,
                                              K, coef_drop)) / keep
     h64 = _f64(H)
     mk = torch.ones_like(h64)

@@ -19,8 +19,13 @@ def build_problem(dev, n=257, f=24, p=2, c=3, seed=5):
     rng = np.random.default_rng(seed)
     x = torch.tensor(rng.standard_normal((n, f)), dtype=torch.float32, device=dev)
     graphs = []
+    band = os.environ.get("HAN_TEST_GRAPH") == "band"
     for q in range(p):
-        a = rng.random((n, n)) < (0.02 if q == 0 else 0.15)     # directed: exercises the CSC build
+        if band:      # locality: |i - j| <= 3 + q, directed, so the halo is a handful of boundary rows
+            ii, jj = np.indices((n, n))
+            a = (np.abs(ii - jj) <= 3 + q) & (rng.random((n, n)) < 0.8)
+        else:
+            a = rng.random((n, n)) < (0.02 if q == 0 else 0.15)     # directed: exercises the CSC build
         np.fill_diagonal(a, True)
         rowptr = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(a.sum(1), out=rowptr[1:])
@@ -63,7 +68,9 @@ def run(rank, world, device, epochs, drop, out_path, port, use_cpu_backend):
     for _ in range(epochs):
         hist.append(tr.reduce_metrics(*tr.epoch()))
     if rank == 0:
-        np.savez(out_path, flat=model.flat.detach().cpu().numpy(), hist=np.array(hist))
+        pf, pb = model.halo_plans
+        halo = 0 if pf is None else sum(x is not None for x in pf) + sum(x is not None for x in pb)
+        np.savez(out_path, flat=model.flat.detach().cpu().numpy(), hist=np.array(hist), halo_plans=halo)
     if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()

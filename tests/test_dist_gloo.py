@@ -12,8 +12,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(world, epochs, drop, out, port):
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+def _launch(world, epochs, drop, out, port, extra_env=None):
+    env = dict(os.environ, OMP_NUM_THREADS="2", **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r),
                                str(world), "cpu", str(epochs), str(drop), out, str(port), "1"],
                               env=env, cwd=ROOT) for r in range(world)]
@@ -28,5 +28,19 @@ def test_two_gloo_ranks_match_single_process(tmp_path, drop, port):
     _launch(2, 2, drop, two, port + 2)
     a, b = np.load(one), np.load(two)
     assert np.isfinite(a["flat"]).all()
+    assert np.abs(a["flat"] - b["flat"]).max() < 1e-5
+    assert np.abs(a["hist"] - b["hist"]).max() < 1e-5
+
+
+def test_halo_exchange_on_a_graph_with_locality(tmp_path):
+    """Banded graphs: only a few boundary rows are remote, so the trainer plans a halo
+    exchange (send lists + all-to-all-v + remapped colidx + global-id RNG keys) instead
+    of the all-gather; results must still equal the single-process run."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    env = {"HAN_TEST_GRAPH": "band"}
+    _launch(1, 2, 0.6, one, 29721, env)
+    _launch(2, 2, 0.6, two, 29723, env)
+    a, b = np.load(one), np.load(two)
+    assert int(b["halo_plans"]) == 4          # 2 meta-paths x (forward, backward) all in halo mode
     assert np.abs(a["flat"] - b["flat"]).max() < 1e-5
     assert np.abs(a["hist"] - b["hist"]).max() < 1e-5

@@ -44,3 +44,16 @@ def test_rccl_collectives_on_a_one_rank_group(dev, tmp_path):
     a, b = np.load(one), np.load(forced)
     assert np.abs(a["flat"] - b["flat"]).max() < 1e-6
     assert np.abs(a["hist"] - b["hist"]).max() < 1e-6
+
+
+def test_halo_exchange_two_ranks_real_kernels(dev, tmp_path):
+    """Halo mode (banded graphs) on the real kernels: [local | halo] tables, remapped
+    colidx, table_gid RNG keys, with dropout; equals the single-process run."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    env = {"HAN_TEST_GRAPH": "band"}
+    _launch(1, 3, 0.6, one, 29631, env)
+    _launch(2, 3, 0.6, two, 29633, env)
+    a, b = np.load(one), np.load(two)
+    assert int(b["halo_plans"]) == 4
+    assert np.abs(a["flat"] - b["flat"]).max() < 2e-5
+    assert np.abs(a["hist"] - b["hist"]).max() < 2e-5
