@@ -58,6 +58,7 @@ struct FwdArgs {
     const float *a2;
     const float *b2;
     const float *c;
+    const float *res;   // residual term added before the activation (layers.py:38-40), or null
     float *out;
     int64_t out_stride;
     float *pre, *lse, *aggp, *tsum;
@@ -180,9 +181,11 @@ __device__ __forceinline__ void write_row(const FwdArgs &a, const int64_t row, c
     // acc / accp carry the zero-or-keep terms; the two 1/keep factors go in here
     const float scale = TRAIN ? inv * a.inv_keep_coef * (a.lsb_mask ? a.inv_keep_fts : 1.f) : inv;
     float4_t pv, ov;
+    float4_t r4 = {0.f, 0.f, 0.f, 0.f};
+    if (a.res && writer) r4 = *reinterpret_cast<const float4_t *>(a.res + row * HAN_D + 4 * q);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        pv[t] = st.acc[t] * scale + c4[t];
+        pv[t] = st.acc[t] * scale + c4[t] + r4[t];
         ov[t] = a.activation == HAN_ACT_ELU ? han_elu(pv[t]) : pv[t];
     }
     if (writer) {
@@ -369,6 +372,7 @@ struct BwdRowsArgs {
     const float *dOut;
     int64_t dout_stride;
     const float *pre, *aggp, *tsum, *f1, *lse, *c;
+    const float *res;   // residual term that was added to pre (or null)
     void *g;       // fp32 or bf16 table
     float *stats, *df1;
     float *slab;   // [gridDim.x][64] partial sums of g (for dc)
@@ -391,12 +395,14 @@ __global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsAr
         const float4_t p4 = *reinterpret_cast<const float4_t *>(a.pre + row * HAN_D + 4 * q);
         const float4_t ap4 = *reinterpret_cast<const float4_t *>(a.aggp + row * HAN_D + 4 * q);
         float4_t g4;
+        float4_t r4 = {0.f, 0.f, 0.f, 0.f};
+        if (a.res) r4 = *reinterpret_cast<const float4_t *>(a.res + row * HAN_D + 4 * q);
         float sp = 0.f, dp = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float da = (a.activation == HAN_ACT_ELU && p4[t] <= 0.f) ? __expf(p4[t]) : 1.f;
             g4[t] = d4[t] * da;
-            sp += g4[t] * (p4[t] - c4[t]);
+            sp += g4[t] * (p4[t] - c4[t] - r4[t]);      // g . (the aggregate alone)
             dp += g4[t] * ap4[t];
             dc[t] += g4[t];
         }
@@ -766,7 +772,8 @@ static bool dtype_ok(int dt, int FP) {
 
 extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const void *H, int table_dtype,
                                  const int32_t *table_gid, const float *f1, const float *a2, const float *b2,
-                                 const float *c, float *out, int64_t out_stride, float *pre, float *lse,
+                                 const float *c, const float *res, float *out, int64_t out_stride, float *pre,
+                                 float *lse,
                                  float *aggp, float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
                                  float coef_drop, float fts_drop, uint64_t seed, int64_t row_offset,
                                  int activation, const han_row_split_t *split, void *stream) {
@@ -780,7 +787,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     if ((coef_drop > 0.f || fts_drop > 0.f) && !train) return HAN_E_BADARG;
     if (N == 0) return 0;
     FwdArgs a;
-    a.rowptr = rowptr; a.colidx = colidx; a.H = H; a.gid = table_gid; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.a2 = a2; a.b2 = b2; a.c = c;
+    a.rowptr = rowptr; a.colidx = colidx; a.H = H; a.gid = table_gid; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.a2 = a2; a.b2 = b2; a.c = c; a.res = res;
     a.out = out; a.out_stride = out_stride; a.pre = pre; a.lse = lse; a.aggp = aggp; a.tsum = tsum;
     a.N = N; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
@@ -820,7 +827,8 @@ extern "C" size_t han_node_attn_bwd_workspace(int64_t N, int K, int FP) {
 
 extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *pre,
                                       const float *aggp, const float *tsum, const float *f1,
-                                      const float *lse, const float *c, void *g, int table_dtype,
+                                      const float *lse, const float *c, const float *res, void *g,
+                                      int table_dtype,
                                       float *stats, float *df1, float *dc, void *workspace,
                                       size_t workspace_bytes, int64_t N, int K, int FP, int activation,
                                       void *stream) {
@@ -832,7 +840,7 @@ extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, co
     hipStream_t st = (hipStream_t)stream;
     BwdRowsArgs a;
     a.dOut = dOut; a.dout_stride = dout_stride; a.pre = pre; a.aggp = aggp; a.tsum = tsum;
-    a.f1 = f1; a.lse = lse; a.c = c; a.g = g; a.stats = stats; a.df1 = df1;
+    a.f1 = f1; a.lse = lse; a.c = c; a.res = res; a.g = g; a.stats = stats; a.df1 = df1;
     a.slab = (float *)workspace; a.N = N; a.activation = activation;
     const int grid = han_grid_for(N, 16, kReduceBlocks);
     if (table_dtype == HAN_DTYPE_BF16) {

@@ -42,12 +42,14 @@ class _ClassOrInstance:
 # name -> shape builder; order == flat layout == gradient all-reduce layout.
 # `extra` = [(K_i, FP_i)] for the node-attention layers i >= 1 (models/gat.py:48-57):
 # their variables are named W_i, a1_i, ... and sit right after layer 0's.
-def _param_shapes(P, F, K, FP, A, C, HC, extra=()):
+def _param_shapes(P, F, K, FP, A, C, HC, extra=(), residual=False):
     shapes = [("W", (P, F, D)), ("a1", (P, K, FP)), ("b1", (P, K)), ("a2", (P, K, FP)),
               ("b2", (P, K)), ("c", (P, D))]
     for i, (Ki, FPi) in enumerate(extra, start=1):
         shapes += [(f"W_{i}", (P, D, D)), (f"a1_{i}", (P, Ki, FPi)), (f"b1_{i}", (P, Ki)),
                    (f"a2_{i}", (P, Ki, FPi)), (f"b2_{i}", (P, Ki)), (f"c_{i}", (P, D))]
+        if residual and FPi != D:      # utils/layers.py:38-40: conv1d(seq, F', 1) per head
+            shapes += [(f"Wr_{i}", (P, D, D)), (f"br_{i}", (P, D))]
     return shapes + [("w_omega", (D, A)), ("b_omega", (A,)), ("u_omega", (A,)),
                      ("Wc", (HC, D, C)), ("bc", (HC, C))]
 
@@ -79,7 +81,7 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
     # ------------------------------------------------------------------ params
     def build(self, n_metapaths, ft_size, nb_classes, hid_units=(8,), n_heads=(8, 1),
               mp_att_size=128, device=None, generator: torch.Generator | None = None,
-              table_dtype=torch.float32):
+              table_dtype=torch.float32, residual=False):
         """Create the variables the reference's first inference() call creates
         (SURVEY.md 8a): glorot-uniform conv1d/dense kernels, zero biases,
         N(0, 0.1^2) semantic-attention variables."""
@@ -89,6 +91,9 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         K, FP, HC = int(n_heads[0]), int(hid_units[0]), int(n_heads[-1])
         ops._check_heads(K, FP)
         self.extra = [(int(n_heads[i]), int(hid_units[i])) for i in range(1, len(hid_units))]
+        # residual only ever reaches the layers >= 1 (models/gat.py:43-45 hard-codes False for
+        # layer 0) and only acts when the input width differs from the head width
+        self.residual = bool(residual)
         for Ki, FPi in self.extra:            # every layer's concatenated width is 64 in this build
             ops._check_heads(Ki, FPi)
         if mp_att_size not in (64, 128):
@@ -101,7 +106,7 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         if table_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("table_dtype must be torch.float32 or torch.bfloat16")
         self.table_dtype = table_dtype       # storage of the projected rows / backward tables
-        shapes = _param_shapes(self.P, self.F, K, FP, self.A, self.C, HC, self.extra)
+        shapes = _param_shapes(self.P, self.F, K, FP, self.A, self.C, HC, self.extra, self.residual)
         total = sum(math.prod(s) for _, s in shapes)
         flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.register_buffer("flat", flat, persistent=False)        # storage owner
@@ -130,6 +135,8 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
             uni(getattr(self, f"W_{i}"), math.sqrt(6.0 / (D + FPi)))
             uni(getattr(self, f"a1_{i}"), math.sqrt(6.0 / (FPi + 1)))
             uni(getattr(self, f"a2_{i}"), math.sqrt(6.0 / (FPi + 1)))
+            if self.residual and FPi != D:
+                uni(getattr(self, f"Wr_{i}"), math.sqrt(6.0 / (D + FPi)))
         nrm(self.w_omega, 0.1)                               # utils/layers.py:145-147
         nrm(self.b_omega, 0.1)
         nrm(self.u_omega, 0.1)
@@ -141,7 +148,8 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         return [self._views[n] for n, _ in self.param_shapes()]
 
     def param_shapes(self):
-        return _param_shapes(self.P, self.F, self.K, self.FP, self.A, self.C, self.HC, self.extra)
+        return _param_shapes(self.P, self.F, self.K, self.FP, self.A, self.C, self.HC, self.extra,
+                             self.residual)
 
     def zero_grad_flat(self):
         """Zero the flat gradient buffer and (re)bind every .grad to its slice."""
@@ -179,11 +187,11 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
                     "table_dtype": self.table_dtype, "plans_f": self.halo_plans[0],
                     "plans_b": self.halo_plans[1]}
         M = layers.NodeLevelAttention.apply(None, self.W, self.a1, self.b1, self.a2, self.b2, self.c,
-                                            tuple(xs), tuple(graphs), cfg())
+                                            None, None, tuple(xs), tuple(graphs), cfg())
         for i in range(1, len(self.extra) + 1):                                 # gat.py:48-57
-            g = lambda n: getattr(self, f"{n}_{i}")
+            g = lambda n: getattr(self, f"{n}_{i}", None)
             M = layers.NodeLevelAttention.apply(M, g("W"), g("a1"), g("b1"), g("a2"), g("b2"), g("c"),
-                                                None, tuple(graphs), cfg())
+                                                g("Wr"), g("br"), None, tuple(graphs), cfg())
         return M
 
     @_ClassOrInstance
@@ -196,9 +204,6 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         (gat.py:39).  `training` and `nb_nodes` are accepted and ignored, as in
         the reference; dropout is driven by attn_drop / ffd_drop alone.
         Returns (logits (1,N,C), final_embed (N,K*F'), att_val (N,P))."""
-        if residual:
-            raise NotImplementedError("residual=True is not built (it is False in every "
-                                      "reference config; utils/layers.py:38-42)")
         n = min(len(inputs_list), len(bias_mat_list))
         xs = [layers._squeeze_batch(x, f"inputs_list[{i}]") for i, x in enumerate(inputs_list[:n])]
         for x in xs:
@@ -206,7 +211,10 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
                 raise ValueError("inputs must be GPU tensors: han_amd has no CPU path")
         dev = xs[0].device
         if not self._built:
-            self.build(n, xs[0].shape[1], nb_classes, hid_units, n_heads, mp_att_size, device=dev)
+            self.build(n, xs[0].shape[1], nb_classes, hid_units, n_heads, mp_att_size, device=dev,
+                       residual=residual)
+        if bool(residual) != self.residual:
+            raise ValueError("residual does not match the variables created by the first call")
         if n != self.P or xs[0].shape[1] != self.F or nb_classes != self.C:
             raise ValueError("arguments do not match the variables created by the first call")
         graphs = self._graphs(bias_mat_list[:n], dev)

@@ -44,7 +44,11 @@ def _act_code(activation):
 class NodeLevelAttention(torch.autograd.Function):
     """K1 + K2 for every meta-path: (X_p, graph_p) -> M (N, P, D).
 
-    forward(Xin, W (P,F,D), a1 (P,K,F'), b1 (P,K), a2, b2, c (P,D), xs, graphs, cfg)
+    forward(Xin, W (P,F,D), a1 (P,K,F'), b1 (P,K), a2, b2, c (P,D), Wr, br, xs, graphs, cfg)
+      Wr, br  None, or the residual connection of utils/layers.py:38-40 for layers whose
+              input width differs from the head width: Wr (P,F,D) = the K heads'
+              conv1d(seq, F', 1) kernels side by side, br (P,D) their biases; the term
+              dropout_k(X) @ Wr_k + br_k is added before the activation
       Xin     None for the first layer; for layers >= 1 (models/gat.py:48-57) the
               previous layer's output (N,P,F): meta-path p reads Xin[:, p, :] and the
               backward returns dXin
@@ -60,7 +64,7 @@ class NodeLevelAttention(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, Xin, W, a1, b1, a2, b2, c, xs, graphs, cfg):
+    def forward(ctx, Xin, W, a1, b1, a2, b2, c, Wr, br, xs, graphs, cfg):
         P = len(graphs)
         if Xin is not None:
             Xin = Xin.contiguous()
@@ -88,29 +92,38 @@ class NodeLevelAttention(torch.autograd.Function):
             handle = None
             if multi:      # halo rows only (HaloPlan) or the whole shard (all-gather)
                 handle = plan.exchange_async(H) if plan is not None else part.all_gather_rows_async(H)
-            proj.append((H, f1, f2, handle))
+            R = None
+            if Wr is not None:   # same seed -> the same per-head input-dropout draws as for H
+                R, _, _ = ops.project_fwd(xs[p], Wr[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
+                                          fts_drop=0.0, seed=seed, row_offset=row_offset)
+                R = R + br[p]
+            proj.append((H, f1, f2, handle, R))
         for p in range(P):
-            H, f1, f2, handle = proj[p]
+            H, f1, f2, handle, R = proj[p]
             H_tab = handle.wait() if multi else H
             plan = plans_f[p] if plans_f is not None else None
             _, sv = ops.node_attn_fwd(plan.graph if plan is not None else graphs[p], H_tab, f1, a2[p], b2[p],
                                       c[p], out=M[:, p, :], train=train, coef_drop=coef_drop,
                                       fts_drop=in_drop, seed=int(cfg["seeds"][p]), row_offset=row_offset,
                                       activation=cfg["act"],
-                                      table_gid=plan.gid if plan is not None else None)
+                                      table_gid=plan.gid if plan is not None else None, res=R)
             if train:
-                saved.append((H, f1, f2) + sv)
+                saved.append((H, f1, f2) + sv + (R,))
         del proj
         ctx.cfg, ctx.xs, ctx.graphs = cfg, xs, graphs
         ctx.xin_shape = tuple(Xin.shape) if Xin is not None else None
         ctx.saved_per_p = saved
         ctx.in_drop, ctx.coef_drop = in_drop, coef_drop
-        ctx.save_for_backward(W, a1, b1, a2, b2, c)
+        ctx.has_res = Wr is not None
+        ctx.save_for_backward(W, a1, b1, a2, b2, c, *((Wr,) if Wr is not None else ()))
         return M
 
     @staticmethod
     def backward(ctx, dM):
-        W, a1, b1, a2, b2, c = ctx.saved_tensors
+        W, a1, b1, a2, b2, c = ctx.saved_tensors[:6]
+        Wr = ctx.saved_tensors[6] if ctx.has_res else None
+        dWr = torch.empty_like(Wr) if Wr is not None else None
+        dbr = torch.empty_like(c) if Wr is not None else None
         cfg, xs, graphs = ctx.cfg, ctx.xs, ctx.graphs
         if not cfg["train"]:
             raise RuntimeError("NodeLevelAttention was run with train=False; no backward state")
@@ -130,12 +143,22 @@ class NodeLevelAttention(torch.autograd.Function):
         multi = part is not None and part.active
         plans_b = cfg.get("plans_b") if multi else None
         rows = []
+        dres_in = []
         for p in range(P):      # row-local halves first; their tables go out while we continue
-            H, f1, f2, pre, lse, aggp, tsum = ctx.saved_per_p[p]
+            H, f1, f2, pre, lse, aggp, tsum, R = ctx.saved_per_p[p]
             g, stats, df1, dcp = ops.node_attn_bwd_rows(dM[:, p, :], pre, aggp, tsum, f1, lse, c[p],
                                                         activation=cfg["act"], K=K, FP=FP,
-                                                        table_dtype=H.dtype)
+                                                        table_dtype=H.dtype, res=R)
             dc[p] = dcp
+            if Wr is not None:      # residual: d(pre) = g flows into Wr, br and the input
+                g32 = g if g.dtype == torch.float32 else g.to(torch.float32)
+                seed_p = int(cfg["seeds"][p])
+                dbr[p] = dcp
+                dWr[p] = ops.project_bwd(xs[p], g32, K, FP, in_drop=ctx.in_drop, seed=seed_p,
+                                         row_offset=row_offset)
+                if dXin is not None:
+                    dres_in.append(ops.project_bwd_input(g32, Wr[p], K, FP, in_drop=ctx.in_drop,
+                                                         seed=seed_p, row_offset=row_offset))
             if multi:
                 plan = plans_b[p] if plans_b is not None else None
                 ex = plan.exchange_async if plan is not None else part.all_gather_rows_async
@@ -143,7 +166,7 @@ class NodeLevelAttention(torch.autograd.Function):
             else:
                 rows.append((g, stats, df1))
         for p in range(P):
-            H, f1, f2, pre, lse, aggp, tsum = ctx.saved_per_p[p]
+            H, f1, f2, pre, lse, aggp, tsum, R = ctx.saved_per_p[p]
             seed = int(cfg["seeds"][p])
             g_h, st_h, df1 = rows[p]
             g_tab, stats_tab = (g_h.wait(), st_h.wait()) if multi else (g_h, st_h)
@@ -161,8 +184,10 @@ class NodeLevelAttention(torch.autograd.Function):
             if dXin is not None:
                 ops.project_bwd_input(dH, W[p], K, FP, out=dXin[:, p, :], in_drop=ctx.in_drop,
                                       seed=seed, row_offset=row_offset)
+                if dres_in:
+                    dXin[:, p, :] += dres_in[p]
         ctx.saved_per_p = None
-        return dXin, dW, da1, db1, da2, db2, dc, None, None, None
+        return dXin, dW, da1, db1, da2, db2, dc, dWr, dbr, None, None, None
 
 
 class SemanticAttention(torch.autograd.Function):
@@ -275,7 +300,7 @@ def _single_head(seq, out_sz, graph, activation, in_drop, coef_drop, residual, p
     train = bool(training) or in_drop > 0 or coef_drop > 0 or W.requires_grad
     cfg = {"train": train, "in_drop": in_drop, "coef_drop": coef_drop,
            "seeds": (rng.next_seed() if seed is None else seed,), "act": code, "part": None}
-    M = NodeLevelAttention.apply(None, W, a1, b1, a2, b2, c, (x,), (graph,), cfg)
+    M = NodeLevelAttention.apply(None, W, a1, b1, a2, b2, c, None, None, (x,), (graph,), cfg)
     ret = M[:, 0, :out_sz]
     if residual:
         # utils/layers.py:38-42: only the dims-differ branch has an effect

@@ -184,12 +184,13 @@ def project_bwd_input(dH, W, K, FP, out=None, in_drop=0.0, seed=0, row_offset=0)
 
 # --------------------------------------------------------------------------- K2
 def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=0.0,
-                  fts_drop=0.0, seed=0, row_offset=0, activation=ACT_ELU, table_gid=None):
+                  fts_drop=0.0, seed=0, row_offset=0, activation=ACT_ELU, table_gid=None, res=None):
     """utils/layers.py:26-35,46.  H_tab (NT,D): gather table of UNDROPPED projected
     rows indexed by graph.colidx (f2_j is recomputed from the gathered row with
     a2 (K,F'), b2 (K,)); with fts_drop > 0 bit 0 of each element is its keep bit
     (as project_fwd stamped it); f1 (N,K) local rows; c (D,).  table_gid (NT,)
-    int32: global id of each table row when H_tab is a [local | halo] table.  `out`: optional (N,D) view with unit inner
+    int32: global id of each table row when H_tab is a [local | halo] table.
+    res (N,D) fp32: residual term added before the activation (layers.py:38-40).  `out`: optional (N,D) view with unit inner
     stride (e.g. M[:,p,:]).  Returns out, saved where
     saved = (pre, lse, aggp, tsum) if train else None."""
     lib = _lib.load()
@@ -205,6 +206,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
     _chk(c, "c", (D,), device=dev)
     if table_gid is not None:
         _chk(table_gid, "table_gid", (graph.n_cols,), dtype=torch.int32, device=dev)
+    if res is not None:
+        _chk(res, "res", (N, D), device=dev)
     if graph.device != dev:
         raise ValueError("graph and tables must be on the same device")
     if out is None:
@@ -234,7 +237,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
     _lib.check(lib.han_node_attn_fwd(
         graph.rowptr.data_ptr(), graph.colidx.data_ptr(), H_tab.data_ptr(), tcode,
         table_gid.data_ptr() if table_gid is not None else None, f1.data_ptr(),
-        a2.data_ptr(), b2.data_ptr(), c.data_ptr(), out.data_ptr(), out.stride(0) if N > 1 else D,
+        a2.data_ptr(), b2.data_ptr(), c.data_ptr(), res.data_ptr() if res is not None else None,
+        out.data_ptr(), out.stride(0) if N > 1 else D,
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
         int(seed), int(row_offset), int(activation),
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_fwd")
@@ -245,7 +249,7 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
 
 
 def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=8, FP=8,
-                       table_dtype=torch.float32):
+                       table_dtype=torch.float32, res=None):
     """Row-local half of the K2 backward.  dOut (N,D) view (unit inner stride).
     Returns g (N,D), stats (N,K,4), df1 (N,K), dc (D,)."""
     lib = _lib.load()
@@ -265,7 +269,8 @@ def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=
     ws = _ws(lib.han_node_attn_bwd_workspace(N, K, FP), dev, "rows")
     _lib.check(lib.han_node_attn_bwd_rows(
         dOut.data_ptr(), dOut.stride(0) if N > 1 else D, pre.data_ptr(), aggp.data_ptr(),
-        tsum.data_ptr(), f1.data_ptr(), lse.data_ptr(), c.data_ptr(), g.data_ptr(),
+        tsum.data_ptr(), f1.data_ptr(), lse.data_ptr(), c.data_ptr(),
+        res.data_ptr() if res is not None else None, g.data_ptr(),
         DTYPE_CODE[table_dtype], stats.data_ptr(), df1.data_ptr(), dc.data_ptr(), ws.data_ptr(), ws.numel(), N, K, FP,
         int(activation), _stream()), "han_node_attn_bwd_rows")
     return g, stats, df1, dc

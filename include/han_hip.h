@@ -104,17 +104,19 @@ size_t han_row_split_workspace(int64_t n_chunks);
  * f2_j = H_j[k].a2[k] + b2[k] is recomputed from the gathered row.  table_gid (NT)
  * int32 or NULL: the GLOBAL node id of each table row when the table is a
  * [local | halo] table of a node partition (the dropout RNG is keyed by global
- * ids); NULL means the table index is the global id.  f1 (N,K) for the local rows; a2 (K,FP); b2 (K); c (D).  out row i is written
+ * ids); NULL means the table index is the global id.  res (N,D) or NULL: the
+ * residual term conv1d(seq, F', 1) of layers.py:38-40, added before the activation.  f1 (N,K) for the local rows; a2 (K,FP); b2 (K); c (D).  out row i is written
  * at out + i*out_stride (so the K heads land directly in M[:,p,:],
  * models/gat.py:46,58-60).  Training extras (all or none may be NULL): pre (N,D)
  * pre-activation, lse (N,K) log-sum-exp of the scores, aggp (N,D) and tsum (N,K)
  * -- the LeakyReLU'-weighted aggregates that make df1 row-local in the backward. */
 int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const void *H,
-                      int table_dtype, const int32_t *table_gid, const float *f1, const float *a2, const float *b2, const float *c, float *out, int64_t out_stride,
-                      float *pre, float *lse, float *aggp, float *tsum, int64_t N,
-                      int64_t E, int K, int FP, float slope, float coef_drop,
-                      float fts_drop, uint64_t seed, int64_t row_offset, int activation,
-                      const han_row_split_t *split, void *stream);
+                      int table_dtype, const int32_t *table_gid, const float *f1,
+                      const float *a2, const float *b2, const float *c, const float *res,
+                      float *out, int64_t out_stride, float *pre, float *lse, float *aggp,
+                      float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
+                      float coef_drop, float fts_drop, uint64_t seed, int64_t row_offset,
+                      int activation, const han_row_split_t *split, void *stream);
 
 /* Backward, step 1 (row-local): from dOut (N,D; row stride dout_stride) and
  * the saved pre/aggp/tsum/f1/lse compute
@@ -127,7 +129,8 @@ int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const void *
 size_t han_node_attn_bwd_workspace(int64_t N, int K, int FP);
 int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *pre,
                            const float *aggp, const float *tsum, const float *f1,
-                           const float *lse, const float *c, void *g, int table_dtype,
+                           const float *lse, const float *c, const float *res, void *g,
+                           int table_dtype,
                            float *stats, float *df1, float *dc, void *workspace,
                            size_t workspace_bytes, int64_t N, int K, int FP, int activation,
                            void *stream);

@@ -300,7 +300,8 @@ def flatten_params(params):
 
 
 def init_params(rng, n_metapaths, ft_size, nb_classes, hid=8, n_heads=(8, 1),
-                mp_att_size=128, dtype=np.float64, nonzero_biases=False, hid_units=None):
+                mp_att_size=128, dtype=np.float64, nonzero_biases=False, hid_units=None,
+                residual=False):
     """Initialisers as the reference's TF defaults.
     nonzero_biases=True perturbs the zero-initialised biases so that parity
     tests exercise them."""
@@ -337,6 +338,8 @@ def init_params(rng, n_metapaths, ft_size, nb_classes, hid=8, n_heads=(8, 1),
                     'a1': glorot_uniform(rng, hi, 1, (hi,), dtype), 'b1': bias(()),
                     'a2': glorot_uniform(rng, hi, 1, (hi,), dtype), 'b2': bias(()),
                     'c': bias((hi,)),
+                    **({'res': {'W': glorot_uniform(rng, width, hi, (width, hi), dtype), 'b': bias((hi,))}}
+                       if (residual and hi != width) else {}),
                 } for _ in range(n_heads[i])])
                 width = n_heads[i] * hi
             layers.append(lp)

@@ -48,6 +48,9 @@ def to_batched(params, dtype=torch.float64):
             for nm in ('a1', 'a2', 'b1', 'b2'):
                 out[nm + sfx] = torch.stack([torch.stack([t(h[nm]) for h in hp]) for hp in lh])
             out['c' + sfx] = torch.stack([torch.cat([t(h['c']) for h in hp]) for hp in lh])
+            if 'res' in lh[0][0]:          # residual conv1d(seq, F', 1) per head (layers.py:38-40)
+                out['Wr' + sfx] = torch.stack([torch.cat([t(h['res']['W']) for h in hp], dim=1) for hp in lh])
+                out['br' + sfx] = torch.stack([torch.cat([t(h['res']['b']) for h in hp]) for hp in lh])
     return out
 
 
@@ -66,11 +69,13 @@ def param_order(bp):
     names = list(PARAM_ORDER[:6])
     for i in range(1, n_extra_layers(bp) + 1):
         names += [f'{nm}_{i}' for nm in ('W', 'a1', 'b1', 'a2', 'b2', 'c')]
+        if f'Wr_{i}' in bp:
+            names += [f'Wr_{i}', f'br_{i}']
     return tuple(names) + PARAM_ORDER[6:]
 
 
 def node_attention_dense(x, bias_mat, W, a1, b1, a2, b2, c, keep_in=1.0, keep_coef=1.0,
-                         masks=None):
+                         masks=None, Wr=None, br=None):
     """All K heads of one meta-path, dense additive-mask form.
     utils/layers.py:18-35,46 per head; head concat models/gat.py:46.
     x (N,F); bias_mat (N,N); W (F,D); a1,a2 (K,F'); b1,b2 (K,); c (D,).
@@ -93,12 +98,15 @@ def node_attention_dense(x, bias_mat, W, a1, b1, a2, b2, c, keep_in=1.0, keep_co
         if masks is not None and 'fts' in masks:
             h = h / keep_in * masks['fts'][:, k * Fp:(k + 1) * Fp]     # :32
         vals = coefs @ h                                               # :34
-        outs.append(Fnn.elu(vals + c[k * Fp:(k + 1) * Fp]))            # :35,46
+        ret = vals + c[k * Fp:(k + 1) * Fp]                            # :35
+        if Wr is not None:                                             # :38-40 (seq is the dropped input)
+            ret = ret + xs @ Wr[:, k * Fp:(k + 1) * Fp] + br[k * Fp:(k + 1) * Fp]
+        outs.append(Fnn.elu(ret))                                      # :46
     return torch.cat(outs, dim=-1)
 
 
 def node_attention_csr(x, rowptr, colidx, W, a1, b1, a2, b2, c, keep_in=1.0, keep_coef=1.0,
-                       masks=None, adj_vals=None):
+                       masks=None, adj_vals=None, Wr=None, br=None):
     """All K heads of one meta-path over CSR neighbours only -- what
     sp_attn_head (utils/layers.py:85-127) computes; heads batched.
     masks: 'seq' (K,N,F), 'coef' (E,K), 'fts' (N,D).
@@ -133,7 +141,14 @@ def node_attention_csr(x, rowptr, colidx, W, a1, b1, a2, b2, c, keep_in=1.0, kee
         h = h / keep_in * masks['fts']                                  # :107-108
     msg = coefs[:, :, None] * h.view(N, K, Fp)[cols]                    # (E,K,F')
     vals = torch.zeros((N, K, Fp), dtype=h.dtype).index_add(0, rows, msg)   # :113
-    return Fnn.elu(vals.reshape(N, D) + c)                              # :118,127
+    ret = vals.reshape(N, D) + c                                        # :118
+    if Wr is not None:                                                  # :121-123
+        if masks is not None and 'seq' in masks:
+            ret = ret + torch.cat([(x / keep_in * masks['seq'][k]) @ Wr[:, k * Fp:(k + 1) * Fp]
+                                   for k in range(K)], dim=1) + br
+        else:
+            ret = ret + x @ Wr + br
+    return Fnn.elu(ret)                                                 # :127
 
 
 def semantic_attention(m, w_omega, b_omega, u_omega):
@@ -161,11 +176,12 @@ def hetegat_forward(x_list, graphs, bp, keep_in=1.0, keep_coef=1.0, masks=None, 
             sfx = f'_{i}'
             largs = tuple(bp[nm + sfx][p] for nm in ('W', 'a1', 'b1', 'a2', 'b2', 'c'))
             lmk = mk['layers'][i - 1] if (mk is not None and 'layers' in mk) else None
+            res = dict(Wr=bp['Wr' + sfx][p], br=bp['br' + sfx][p]) if ('Wr' + sfx) in bp else {}
             if dense:
-                e = node_attention_dense(e, g, *largs, keep_in=keep_in, keep_coef=keep_coef, masks=lmk)
+                e = node_attention_dense(e, g, *largs, keep_in=keep_in, keep_coef=keep_coef, masks=lmk, **res)
             else:
                 e = node_attention_csr(e, g[0], g[1], *largs, keep_in=keep_in, keep_coef=keep_coef,
-                                       masks=lmk)
+                                       masks=lmk, **res)
         embeds.append(e[:, None, :])                                    # gat.py:58
     m = torch.cat(embeds, dim=1)                                        # gat.py:60
     final_embed, att = semantic_attention(m, bp['w_omega'], bp['b_omega'], bp['u_omega'])

@@ -106,7 +106,7 @@ def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset,
 
 
 def node_attn_fwd(graph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=0.0, fts_drop=0.0,
-                  seed=0, row_offset=0, activation=1, table_gid=None):
+                  seed=0, row_offset=0, activation=1, table_gid=None, res=None):
     K, FP = a2.shape
     N = graph.n_rows
     rows, cols, alpha, am, sg, lse, hd = _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop,
@@ -114,6 +114,8 @@ def node_attn_fwd(graph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=
     hk = hd.view(-1, K, FP)[cols]                                    # (E,K,FP)
     agg = torch.zeros((N, K, FP), dtype=torch.float64).index_add(0, rows, (alpha * am)[:, :, None] * hk)
     pre = agg.reshape(N, D) + _f64(c)
+    if res is not None:
+        pre = pre + _f64(res)
     o = torch.where(pre > 0, pre, torch.expm1(pre)) if activation == 1 else pre
     if out is None:
         out = torch.empty((N, D), dtype=torch.float32)
@@ -130,12 +132,13 @@ def node_attn_fwd(graph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=
 
 
 def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=1, K=8, FP=8,
-                       table_dtype=torch.float32):
+                       table_dtype=torch.float32, res=None):
     N = pre.shape[0]
     p = _f64(pre)
     da = torch.where(p <= 0, torch.exp(p), torch.ones_like(p)) if activation == 1 else torch.ones_like(p)
     g = _f64(dOut) * da
-    s = (g * (p - _f64(c))).view(N, K, FP).sum(-1)
+    agg = p - _f64(c) - (_f64(res) if res is not None else 0.0)
+    s = (g * agg).view(N, K, FP).sum(-1)
     dp = (g * _f64(aggp)).view(N, K, FP).sum(-1)
     df1 = dp - s * _f64(tsum)
     stats = torch.stack([_f64(f1), _f64(lse), s, torch.zeros_like(s)], dim=-1)

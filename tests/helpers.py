@@ -26,13 +26,13 @@ def random_adj(rng, n, density, symmetric=True, special_rows=True):
 
 
 def make_problem(seed, n, f, p, c, densities, dtype=np.float64, nonzero_biases=True, hid_units=None,
-                 n_heads=(8, 1)):
+                 n_heads=(8, 1), residual=False):
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((1, n, f)).astype(dtype)
     adjs = [random_adj(rng, n, densities[i % len(densities)])[None] for i in range(p)]
     biases = [ho.adj_to_bias(a, [n], 1) for a in adjs]
     params = ho.init_params(rng, p, f, c, nonzero_biases=nonzero_biases, hid_units=hid_units,
-                            n_heads=n_heads)
+                            n_heads=n_heads, residual=residual)
     labels = rng.integers(0, c, size=n)
     onehot = np.eye(c)[labels]
     mask = rng.random(n) < 0.4
@@ -56,7 +56,9 @@ def build_model(prob, dev, mp_att_size=128):
         lp = prob["params"]["layers"][0]
         hid_units = (8,) + tuple(len(l[0]["a1"]) for l in lp)
         n_heads = (8,) + tuple(len(l) for l in lp) + (len(prob["params"]["cls"]),)
-    model.build(prob["p"], prob["f"], prob["c"], hid_units, n_heads, mp_att_size, device=dev)
+    residual = "layers" in prob["params"] and "res" in prob["params"]["layers"][0][0][0]
+    model.build(prob["p"], prob["f"], prob["c"], hid_units, n_heads, mp_att_size, device=dev,
+                residual=residual)
     bp = ht.to_batched(prob["params"])
     load_params(model, bp)
     return model, bp

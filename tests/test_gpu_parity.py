@@ -673,20 +673,24 @@ def test_bf16_mode_forward_backward(dev, drop):
 
 
 # ------------------------------------------------------------------------ multi-layer
-@pytest.mark.parametrize("drop", [0.0, 0.6])
-def test_multi_layer_stack_matches_oracle(dev, drop):
+@pytest.mark.parametrize("drop,residual", [(0.0, False), (0.6, False), (0.0, True), (0.6, True)])
+def test_multi_layer_stack_matches_oracle(dev, drop, residual):
     """models/gat.py:48-57 with hid_units=[8,16], n_heads=[8,4,1]: forward through
     inference(), and loss + every gradient (incl. han_project_bwd_input, which carries
     the second layer's gradient back into the first) against the float64 oracle."""
     from han_amd import layers, ops, rng as hrng
-    prob = make_problem(62, 150, 11, 2, 3, [0.05, 0.4], hid_units=[8, 16], n_heads=(8, 4, 1))
+    prob = make_problem(62, 150, 11, 2, 3, [0.05, 0.4], hid_units=[8, 16], n_heads=(8, 4, 1),
+                        residual=residual)
     model, bp = build_model(prob, dev)
+    assert hasattr(model, "Wr_1") == residual
     x, graphs = gpu_inputs(prob, dev)
     if drop == 0:
         lg_np, fe_np, att_np = ho.hetegat_multi_inference([prob["x"]] * 2, 3, 150, False, 0.0, 0.0,
-                                                          prob["biases"], [8, 16], [8, 4, 1], prob["params"])
+                                                          prob["biases"], [8, 16], [8, 4, 1], prob["params"],
+                                                          residual=residual)
         with torch.no_grad():
-            logits, fe, att = model.inference([x[None]] * 2, 3, 150, False, 0.0, 0.0, graphs, [8, 16], [8, 4, 1])
+            logits, fe, att = model.inference([x[None]] * 2, 3, 150, False, 0.0, 0.0, graphs, [8, 16], [8, 4, 1],
+                                              residual=residual)
         assert np.abs(logits.cpu().numpy() - lg_np).max() < TOL
         assert np.abs(fe.cpu().numpy() - fe_np).max() < TOL
     hrng.manual_seed(19)

@@ -253,16 +253,18 @@ def test_evaluate_and_checkpoint(cpu_ops, tmp_path):
     assert torch.equal(snap, model.flat) and tr.opt.t == t
 
 
-@pytest.mark.parametrize("drop", [0.0, 0.6])
-def test_multi_layer_stack_on_cpu_backend(cpu_ops, drop):
+@pytest.mark.parametrize("drop,residual", [(0.0, False), (0.6, False), (0.0, True), (0.6, True)])
+def test_multi_layer_stack_on_cpu_backend(cpu_ops, drop, residual):
     """models/gat.py:48-57: hid_units=[8,16], n_heads=[8,4,1] -- the second layer
     reads the first layer's concatenated heads; gradients flow back through both."""
     from han_amd import layers, rng as hrng
     from han_amd.gat import HeteGAT_multi
-    prob = make_problem(61, 40, 9, 2, 3, [0.15, 0.4], hid_units=[8, 16], n_heads=(8, 4, 1))
+    prob = make_problem(61, 40, 9, 2, 3, [0.15, 0.4], hid_units=[8, 16], n_heads=(8, 4, 1),
+                        residual=residual)
     bp = ht.to_batched(prob["params"])
+    assert ("Wr_1" in bp) == residual
     assert ht.n_extra_layers(bp) == 1 and bp["W_1"].shape == (2, 64, 64) and bp["a1_1"].shape == (2, 4, 16)
-    model = HeteGAT_multi().build(2, 9, 3, (8, 16), (8, 4, 1), device="cpu")
+    model = HeteGAT_multi().build(2, 9, 3, (8, 16), (8, 4, 1), device="cpu", residual=residual)
     load_params(model, bp)
     graphs = _cpu_graphs(prob)
     x = torch.tensor(prob["x"][0], dtype=torch.float32)
@@ -300,5 +302,5 @@ def test_multi_layer_stack_on_cpu_backend(cpu_ops, drop):
     # numpy restatement of the multi-layer forward (models/gat.py:48-57) agrees too
     lg_np, _, _ = ho.hetegat_multi_inference([prob["x"]] * 2, 3, 40, False, 0.0, 0.0, prob["biases"],
                                              [8, 16], [8, 4, 1], prob["params"])
-    if drop == 0:
+    if drop == 0 and not residual:
         assert np.abs(lg_np[0] - lg_ref.detach().numpy()).max() < 1e-10
