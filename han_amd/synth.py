@@ -22,7 +22,8 @@ def random_regular_graph(n: int, deg: int, seed: int, device="cpu", symmetric=Fa
     nb = torch.randint(0, n, (n, deg - 1), generator=g, device=device, dtype=torch.int32)
     self_ids = torch.arange(n, device=device, dtype=torch.int32)[:, None]
     cols = torch.cat([self_ids, nb], dim=1)
-    cols, _ = torch.sort(cols, dim=1)
+    del nb
+    cols = torch.sort(cols, dim=1).values
     rowptr = torch.arange(0, n * deg + 1, deg, device=device, dtype=torch.int64)
     graph = CSRGraph(rowptr, cols.reshape(-1).contiguous(), n, validate=False)
     if symmetric:
@@ -71,6 +72,8 @@ CONFIGS = {
     "syn-1m": dict(n=1_000_000, f=256, c=4, graphs=[("regular", 50)] * 4),
     "syn-1m-skew": dict(n=1_000_000, f=256, c=4, graphs=[("powerlaw", 50_000_000, 2.1)] * 4),
     "syn-100k": dict(n=100_000, f=256, c=4, graphs=[("regular", 50)] * 4),
+    # BASELINE.json configs[4] (meant for 8 GPUs; fits one 288 GB MI355X with bf16 tables)
+    "syn-10m": dict(n=10_000_000, f=256, c=4, graphs=[("regular", 50)] * 8),
     "tiny": dict(n=512, f=48, c=3, graphs=[("bernoulli", 0.02), ("bernoulli", 0.2)]),
 }
 
