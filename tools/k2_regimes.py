@@ -14,8 +14,48 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from han_amd import ops, synth  # noqa: E402
 
 
+def train_variants(dev, sizes=(1_000_000, 4_000_000)):
+    """Training kernels (forward with both dropouts, transposed-graph backward) in the
+    cache-resident and the HBM-served regime, fp32 and bf16 tables."""
+    for n in sizes:
+        g = synth.random_regular_graph(n, 50, 1234, dev)
+        gt = g.transpose()
+        gen = torch.Generator(device=dev).manual_seed(1)
+        rnd = lambda *s: torch.randn(s, device=dev, generator=gen)
+        X, W = rnd(n, 64), torch.eye(64, device=dev)
+        a1, a2, b1, b2, c = rnd(8, 8) * 0.3, rnd(8, 8) * 0.3, rnd(8) * 0.1, rnd(8) * 0.1, rnd(64) * 0.1
+        out = torch.empty((n, 64), device=dev)
+        dOut = rnd(n, 64)
+        for tdt in (torch.float32, torch.bfloat16):
+            H, f1, f2 = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.6, fts_drop=0.6, seed=3, table_dtype=tdt)
+            tag = "f32" if tdt == torch.float32 else "bf16"
+
+            def timeit(fn, reps=5):
+                fn(); fn()
+                ts = []
+                for _ in range(reps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                return sorted(ts)[len(ts) // 2]
+            te = timeit(lambda: ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out))
+            tt = timeit(lambda: ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=0.6,
+                                                  fts_drop=0.6, seed=3))
+            _, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=0.6, fts_drop=0.6, seed=3)
+            gg, stats, df1, dc = ops.node_attn_bwd_rows(dOut, sv[0], sv[2], sv[3], f1, sv[1], c, table_dtype=tdt)
+            tb = timeit(lambda: ops.node_attn_bwd_cols(gt, gg, stats, H, f2, df1, a1, a2, coef_drop=0.6,
+                                                       fts_drop=0.6, seed=3))
+            print(json.dumps({"N": n, "tables": tag, "fwd_eval_ms": round(te, 3), "fwd_train_ms": round(tt, 3),
+                              "bwd_cols_ms": round(tb, 3)}), flush=True)
+            del H, gg, stats, sv
+        del g, gt
+        torch.cuda.empty_cache()
+
+
 def main():
     dev = torch.device("cuda:0")
+    if "--train" in sys.argv:
+        return train_variants(dev)
     reps = 7
     for n in (250_000, 1_000_000, 2_000_000, 4_000_000, 10_000_000):
         g = synth.random_regular_graph(n, 50, 1234, dev)
