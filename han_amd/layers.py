@@ -300,12 +300,14 @@ def _single_head(seq, out_sz, graph, activation, in_drop, coef_drop, residual, p
     train = bool(training) or in_drop > 0 or coef_drop > 0 or W.requires_grad
     cfg = {"train": train, "in_drop": in_drop, "coef_drop": coef_drop,
            "seeds": (rng.next_seed() if seed is None else seed,), "act": code, "part": None}
-    M = NodeLevelAttention.apply(None, W, a1, b1, a2, b2, c, None, None, (x,), (graph,), cfg)
+    Wr = br = None
+    if residual and Fin != out_sz:
+        # utils/layers.py:38-40: + conv1d(seq, out_sz, 1) of the DROPPED input, before the
+        # activation; when the widths are equal the reference's branch is a no-op (:42)
+        Wr = pad_last(params["res_W"], D)[None]
+        br = pad_last(params["res_b"], D)[None]
+    M = NodeLevelAttention.apply(None, W, a1, b1, a2, b2, c, Wr, br, (x,), (graph,), cfg)
     ret = M[:, 0, :out_sz]
-    if residual:
-        # utils/layers.py:38-42: only the dims-differ branch has an effect
-        if Fin != out_sz:
-            ret = ret + x @ params["res_W"] + params["res_b"]
     if post is not None:
         ret = post(ret)
     return ret[None]     # (1,N,out_sz)
@@ -315,16 +317,11 @@ def attn_head(seq, out_sz, bias_mat, activation, in_drop=0.0, coef_drop=0.0, res
               return_coef=False, *, params, training=False, seed=None):
     """utils/layers.py:7-46.  seq (1,N,F); bias_mat (1,N,N) additive mask, or a
     CSRGraph / (rowptr, colidx) pair.  params: dict W (F,out_sz), a1 (out_sz,),
-    b1 (), a2 (out_sz,), b2 (), c (out_sz,) [+ res_W, res_b].
-    NOTE residual with a non-ELU activation is applied after the kernel."""
+    b1 (), a2 (out_sz,), b2 (), c (out_sz,) [+ res_W (F,out_sz), res_b (out_sz,) when
+    residual=True and F != out_sz]."""
     if return_coef:
         raise NotImplementedError("return_coef would materialise the N x N coefficients; "
                                   "not provided by the CSR kernels")
-    if residual and _act_code(activation)[0] != ops.ACT_IDENTITY:
-        # the residual must be added before the activation (layers.py:40,46)
-        inner = _single_head(seq, out_sz, as_graph(bias_mat, seq.device), None, in_drop, coef_drop,
-                             residual, params, training, seed)
-        return F_torch.elu(inner)
     return _single_head(seq, out_sz, as_graph(bias_mat, seq.device), activation, in_drop,
                         coef_drop, residual, params, training, seed)
 
@@ -355,9 +352,6 @@ def sp_attn_head(seq, out_sz, adj_mat, activation, nb_nodes, in_drop=0.0, coef_d
     g = as_graph(adj_mat, seq.device)
     if g.n_rows != nb_nodes:
         raise ValueError(f"nb_nodes={nb_nodes} but adj_mat has {g.n_rows} rows")
-    if residual and _act_code(activation)[0] != ops.ACT_IDENTITY:
-        inner = _single_head(seq, out_sz, g, None, in_drop, coef_drop, residual, params, training, seed)
-        return F_torch.elu(inner)
     return _single_head(seq, out_sz, g, activation, in_drop, coef_drop, residual, params, training,
                         seed)
 

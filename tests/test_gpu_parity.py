@@ -433,6 +433,14 @@ def test_attn_head_and_sp_attn_head_api(dev):
     assert np.abs(out_sp.cpu().numpy() - ref).max() < TOL
     ref_sp = ho.sp_attn_head(prob["x"], head, rp, ci)
     assert np.abs(out_sp.cpu().numpy() - ref_sp).max() < TOL
+    # residual=True with F (9) != out_sz (8): + conv1d(seq, 8, 1) before the ELU (layers.py:38-40)
+    rngr = np.random.default_rng(8)
+    res = {"W": rngr.standard_normal((9, 8)) * 0.3, "b": rngr.standard_normal(8) * 0.1}
+    ref_res = ho.attn_head(prob["x"], head, prob["biases"][0], residual=True, res_params=res)
+    with torch.no_grad():
+        out_res = layers.attn_head(x, 8, _t(prob["biases"][0], dev), Fnn.elu, residual=True,
+                                   params={**params, "res_W": _t(res["W"], dev), "res_b": _t(res["b"], dev)})
+    assert np.abs(out_res.cpu().numpy() - ref_res).max() < TOL
     # HAN_nd ablation head (layers.py:49-81): uniform 1/deg weights
     with torch.no_grad():
         out_c = layers.attn_head_const_1(x, 8, _t(prob["biases"][0], dev), Fnn.elu, params=params)

@@ -304,3 +304,32 @@ def test_multi_layer_stack_on_cpu_backend(cpu_ops, drop, residual):
                                              [8, 16], [8, 4, 1], prob["params"])
     if drop == 0 and not residual:
         assert np.abs(lg_np[0] - lg_ref.detach().numpy()).max() < 1e-10
+
+
+def test_mat_loader_follows_the_reference_script(tmp_path):
+    """han_amd.process.load_data_mat == ex_acm3025.py:57-87 on a synthetic .mat with the
+    ACM3025 keys: the '- I' on the meta-path matrices, masks, zeroed label rows, and
+    three feature copies for two meta-paths."""
+    import scipy.io as sio
+    from han_amd import process
+    rng = np.random.default_rng(0)
+    n, f, c = 30, 7, 3
+    pap = (rng.random((n, n)) < 0.2).astype(float)
+    pap = np.maximum(pap, pap.T)
+    np.fill_diagonal(pap, 1.0)
+    plp = np.eye(n) + np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1)
+    label = np.eye(c)[rng.integers(0, c, n)]
+    idx = rng.permutation(n)
+    path = str(tmp_path / "ACM_like.mat")
+    sio.savemat(path, {"label": label, "feature": rng.random((n, f)), "PAP": pap, "PLP": plp,
+                       "train_idx": idx[None, :10], "val_idx": idx[None, 10:15], "test_idx": idx[None, 15:]})
+    adj, fea, y_tr, y_va, y_te, m_tr, m_va, m_te = process.load_data_mat(path)
+    assert len(adj) == 2 and len(fea) == 3 and fea[0].shape == (n, f)
+    assert np.array_equal(adj[0], pap - np.eye(n)) and np.array_equal(adj[1], plp - np.eye(n))
+    assert m_tr.sum() == 10 and m_va.sum() == 5 and m_te.sum() == 15 and not (m_tr & m_va).any()
+    assert np.array_equal(y_tr[m_tr], label[m_tr]) and not y_tr[~m_tr].any()
+    # adj_to_bias re-adds I (ex_acm3025.py:118): the edge set equals the original matrix's
+    g = process.adj_to_graph(adj[0], nhood=1)
+    rp, ci = ho.bias_to_csr(ho.adj_to_bias(adj[0][None], [n], 1))
+    assert np.array_equal(g.rowptr.numpy(), rp) and np.array_equal(g.colidx.numpy(), ci)
+    assert g.nnz == int((pap > 0).sum())
