@@ -37,7 +37,7 @@ def k2_algorithmic_bytes(n_rows, nnz, K=8, D=64, s=4, train=False):
     per_edge = 4 + D * s + K * 4
     per_row = D * 4 + K * 4 + 8
     if train:                       # + pre, aggp rows and lse, tsum
-        per_row += 2 * D * s + 2 * K * 4
+        per_row += 2 * D * 4 + 2 * K * 4
     return nnz * per_edge + n_rows * per_row
 
 
@@ -59,12 +59,9 @@ def cpu_baseline(workload_name, n_full, sample_n, seed=1234):
     onehot = torch.nn.functional.one_hot(wl["labels"].long(), wl["c"]).float()
     xs = [wl["x"]] * wl["p"]
     g = torch.Generator().manual_seed(0)
-    masks = []
-    for (rp, ci) in graphs:      # dropout draws are part of the timed work, as in TF
-        masks.append(None)
 
     def one_epoch():
-        mk = []
+        mk = []                  # the dropout draws are part of the timed work, as in TF
         for (rp, ci) in graphs:
             mk.append({"seq": (torch.rand((8, sample_n, wl["f"]), generator=g) < 0.4).float(),
                        "coef": (torch.rand((ci.numel(), 8), generator=g) < 0.4).float(),
