@@ -162,7 +162,7 @@ def main():
     tl, ta, vl, va = trainer.reduce_metrics(*last)
 
     # --- roofline of the dominant kernel (K2 forward, eval instantiation) -------------
-    ms = {"eval": [], "train": []}
+    ms = {"eval": [], "train": [], "bwd_cols": []}
     shape = {}
     for tag, e0, e1, nr, nnz in timing:
         ms[tag].append(e0.elapsed_time(e1))
@@ -196,6 +196,14 @@ def main():
             talg = k2_algorithmic_bytes(nr, nnz, s=esz, train=True)
             extra["k2_train_fwd"] = {"avg_launch_ms": round(tavg, 4),
                                      "achieved_GBs": round(talg / (tavg * 1e-3) / 1e9, 1)}
+        if ms["bwd_cols"]:
+            # transposed-graph backward: per edge rowidx 4 + g row D*s + stats 128; per source
+            # row H_j (D*s) + f2, df1 (K*4 each) + colptr 8 in, dH (D*4) + df2 (K*4) out
+            nr, nnz = shape["bwd_cols"]
+            bavg = sum(ms["bwd_cols"]) / len(ms["bwd_cols"])
+            balg = nnz * (4 + 64 * esz + 128) + nr * (64 * esz + 64 * 4 + 3 * 8 * 4 + 8)
+            extra["k2_bwd_cols"] = {"avg_launch_ms": round(bavg, 4),
+                                    "achieved_GBs": round(balg / (bavg * 1e-3) / 1e9, 1)}
 
     if rank == 0:
         out = {

@@ -51,6 +51,7 @@ __device__ __forceinline__ float dot4(const float4_t &x, const float4_t &y) {
 struct FwdArgs {
     const int64_t *rowptr;
     const int32_t *colidx;
+    const float *edge_val;   // stored adjacency values scaling the logits (layers.py:95-96), or null (binary)
     const void *H;  // fp32 (256-B rows) or bf16 (128-B rows) table
     const int32_t *gid;   // global id of each table row (halo tables), or null: the index is the id
     int lsb_mask;   // training with fts dropout: the lowest mantissa bit of every H element is its keep bit
@@ -109,8 +110,8 @@ struct RowState {
 
 // Gather U neighbour rows and fold them into the running softmax state.
 template <int FP, bool TRAIN, int U, bool BF>
-__device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U], const bool (&valid)[U],
-                                              const float f1h, const uint32_t gi, const int q, const int head,
+__device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U], const float (&w)[U],
+                                              const bool (&valid)[U], const float f1h, const uint32_t gi, const int q, const int head,
                                               const float4_t &a24, const float b2h, const bool drop_c,
                                               RowState<TRAIN> &st) {
     constexpr int KQ = (HAN_D / FP + 3) / 4;
@@ -121,8 +122,9 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
     float mc = st.m;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const float x = f1h + (head_sum<FP>(dot4(hv[u], a24)) + b2h);   // layers.py:24,26
-        sg[u] = x > 0.f ? 1.f : a.slope;
+        // layers.py:24,26; sp_attn_head: adj_ij*f1_i + adj_ij*f2_j (:95-96), w == 1 when binary
+        const float x = w[u] * (f1h + (head_sum<FP>(dot4(hv[u], a24)) + b2h));
+        sg[u] = (x > 0.f ? 1.f : a.slope) * w[u];
         ev[u] = valid[u] ? han_lrelu(x, a.slope) : HAN_NEG_BIG;          // layers.py:27
         mc = fmaxf(mc, ev[u]);
     }
@@ -240,16 +242,19 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
             for (int64_t base = s; base < e; base += 64) {
                 const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
                 const int mycol = a.colidx[base + (lane < cnt ? lane : cnt - 1)];
+                const float myval = a.edge_val ? a.edge_val[base + (lane < cnt ? lane : cnt - 1)] : 1.f;
                 for (int it = 0; it * 4 < cnt; it += U) {
                     int j[U];
+                    float w[U];
                     bool valid[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int idx = (it + u) * 4 + g;
                         valid[u] = idx < cnt;
                         j[u] = __shfl(mycol, idx & 63, 64);
+                        w[u] = a.edge_val ? __shfl(myval, idx & 63, 64) : 1.f;
                     }
-                    consume_edges<FP, TRAIN, U, BF>(a, j, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
+                    consume_edges<FP, TRAIN, U, BF>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
                 }
             }
             st.merge(16);
@@ -266,13 +271,15 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
             }
             for (int64_t it = 0; it < maxlen; it += U) {
                 int j[U];
+                float w[U];
                 bool valid[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     valid[u] = it + u < len;
                     j[u] = (len > 0) ? a.colidx[valid[u] ? s + it + u : s] : 0;
+                    w[u] = (a.edge_val && len > 0) ? a.edge_val[valid[u] ? s + it + u : s] : 1.f;
                 }
-                consume_edges<FP, TRAIN, U, BF>(a, j, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
+                consume_edges<FP, TRAIN, U, BF>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
             }
         }
 
@@ -302,16 +309,19 @@ __global__ __launch_bounds__(256) void node_attn_fwd_chunk_kernel(const FwdArgs 
         for (int64_t base = s; base < e; base += 64) {
             const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
             const int mycol = a.colidx[base + (lane < cnt ? lane : cnt - 1)];
+            const float myval = a.edge_val ? a.edge_val[base + (lane < cnt ? lane : cnt - 1)] : 1.f;
             for (int it = 0; it * 4 < cnt; it += U) {
                 int j[U];
+                float w[U];
                 bool valid[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int idx = (it + u) * 4 + g;
                     valid[u] = idx < cnt;
                     j[u] = __shfl(mycol, idx & 63, 64);
+                    w[u] = a.edge_val ? __shfl(myval, idx & 63, 64) : 1.f;
                 }
-                consume_edges<FP, TRAIN, U, BF>(a, j, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
+                consume_edges<FP, TRAIN, U, BF>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
             }
         }
         st.merge(16);
@@ -441,6 +451,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsAr
 struct BwdColsArgs {
     const int64_t *colptr;
     const int32_t *rowidx;
+    const float *edge_val;   // adjacency values in transposed-graph order, or null (binary)
     const void *g, *H;   // fp32 or bf16 tables
     const int32_t *gid;  // global id of each row of the g / stats tables, or null
     const float *stats, *f2, *df1, *a1, *a2;
@@ -487,8 +498,8 @@ __device__ __forceinline__ SrcRow load_src(const BwdColsArgs &a, const int64_t s
 
 // gather U destinations i of source j and accumulate  acc += alpha~ g_i,  df += dl_ij
 template <int FP, int U, bool BF>
-__device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)[U], const bool (&valid)[U],
-                                            const SrcRow &sr, const int q, const int head, const bool drop_c,
+__device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)[U], const float (&ew)[U],
+                                            const bool (&valid)[U], const SrcRow &sr, const int q, const int head, const bool drop_c,
                                             float (&acc)[4], float &dfacc) {
     constexpr int K = HAN_D / FP;
     constexpr int KQ = (K + 3) / 4;
@@ -500,8 +511,8 @@ __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const float x = st[u][0] + sr.f2h;
-        const float sg = x > 0.f ? 1.f : a.slope;
+        const float x = ew[u] * (st[u][0] + sr.f2h);
+        const float sg = (x > 0.f ? 1.f : a.slope) * ew[u];
         float alpha = __expf(han_lrelu(x, a.slope) - st[u][1]);
         alpha = valid[u] ? alpha : 0.f;
         float am = 1.f;
@@ -568,14 +579,16 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
         }
         for (int64_t it = 0; it < trips; it += U) {
             int i[U];
+            float ew[U];
             bool valid[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t k = (RPW == 1) ? (it + u) * 4 + g : it + u;
                 valid[u] = k < len;
                 i[u] = len > 0 ? a.rowidx[valid[u] ? s + k : s] : 0;
+                ew[u] = (a.edge_val && len > 0) ? a.edge_val[valid[u] ? s + k : s] : 1.f;
             }
-            bwd_consume<FP, U, BF>(a, i, valid, sr, q, head, drop_c, acc, dfacc);
+            bwd_consume<FP, U, BF>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
         }
         if (RPW == 1) {
 #pragma unroll
@@ -607,14 +620,16 @@ __global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsA
         const int64_t trips = (len + 3) >> 2;
         for (int64_t it = 0; it < trips; it += U) {
             int i[U];
+            float ew[U];
             bool valid[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t k = (it + u) * 4 + g;
                 valid[u] = k < len;
                 i[u] = a.rowidx[valid[u] ? s + k : s];
+                ew[u] = a.edge_val ? a.edge_val[valid[u] ? s + k : s] : 1.f;
             }
-            bwd_consume<FP, U, BF>(a, i, valid, sr, q, head, drop_c, acc, dfacc);
+            bwd_consume<FP, U, BF>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
         }
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
@@ -701,6 +716,87 @@ __global__ __launch_bounds__(256) void score_param_bwd_kernel(const void *H, con
     }
 }
 
+// ---------------------------------------------------------------------------
+// Attention coefficients as data (attn_head(..., return_coef=True), layers.py:43-44;
+// models/gat.py:143-172 averages them over the heads).  Diagnostic output, not on the
+// training path: one wave per destination row, lanes stride over the row's stored
+// entries; pass 1 = online (max, sum) per head, pass 2 = write.
+// ---------------------------------------------------------------------------
+struct CoefArgs {
+    const int64_t *rowptr;
+    const int32_t *colidx;
+    const float *edge_val;
+    const int32_t *gid;
+    const float *f1, *f2;
+    float *coef;     // (E,K), or (E) when mean_heads
+    int64_t N;
+    float slope;
+    uint32_t seed_lo, seed_hi, thr_coef;
+    float inv_keep_coef;
+    int64_t row_offset;
+    int mean_heads;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void node_attn_coef_kernel(const CoefArgs a) {
+    constexpr int KQ = (K + 3) / 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const bool drop_c = a.thr_coef < HAN_KEEP_ALL;
+    for (int64_t row = wave0; row < a.N; row += nwaves) {
+        const int64_t s = a.rowptr[row], e = a.rowptr[row + 1];
+        float f1r[K], m[K], l[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            f1r[k] = a.f1[row * K + k];
+            m[k] = HAN_NEG_BIG;
+            l[k] = 0.f;
+        }
+        for (int64_t p = s + lane; p < e; p += 64) {
+            const int64_t j = a.colidx[p];
+            const float w = a.edge_val ? a.edge_val[p] : 1.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float x = han_lrelu(w * (f1r[k] + a.f2[j * K + k]), a.slope);
+                const float M = fmaxf(m[k], x);
+                l[k] = l[k] * __expf(m[k] - M) + __expf(x - M);
+                m[k] = M;
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float m_o = __shfl_xor(m[k], off, 64), l_o = __shfl_xor(l[k], off, 64);
+                const float M = fmaxf(m[k], m_o);
+                l[k] = l[k] * __expf(m[k] - M) + l_o * __expf(m_o - M);
+                m[k] = M;
+            }
+        }
+        const uint32_t gi = (uint32_t)(row + a.row_offset);
+        for (int64_t p = s + lane; p < e; p += 64) {
+            const int64_t j = a.colidx[p];
+            const float w = a.edge_val ? a.edge_val[p] : 1.f;
+            const uint32_t gj = a.gid ? (uint32_t)a.gid[j] : (uint32_t)j;
+            float mean = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float x = han_lrelu(w * (f1r[k] + a.f2[j * K + k]), a.slope);
+                float c = __expf(x - m[k]) / l[k];                                   // layers.py:27
+                if (drop_c) {                                                        // layers.py:29-30
+                    const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
+                                                    gj * (uint32_t)KQ + (uint32_t)(k >> 2));
+                    c = rn.field(k & 3) < a.thr_coef ? c * a.inv_keep_coef : 0.f;
+                }
+                if (a.mean_heads) mean += c;
+                else a.coef[p * K + k] = c;
+            }
+            if (a.mean_heads) a.coef[p] = mean * (1.f / K);
+        }
+    }
+}
+
 constexpr int kReduceBlocks = 1024;
 
 bool fp_supported(int K, int FP) {
@@ -772,7 +868,8 @@ static bool dtype_ok(int dt, int FP) {
     return dt == HAN_DTYPE_F32 || (dt == HAN_DTYPE_BF16 && HAN_BF16_OK(FP));
 }
 
-extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const void *H, int table_dtype,
+extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float *edge_val,
+                                 const void *H, int table_dtype,
                                  const int32_t *table_gid, const float *f1, const float *a2, const float *b2,
                                  const float *c, const float *res, float *out, int64_t out_stride, float *pre,
                                  float *lse,
@@ -789,7 +886,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     if ((coef_drop > 0.f || fts_drop > 0.f) && !train) return HAN_E_BADARG;
     if (N == 0) return 0;
     FwdArgs a;
-    a.rowptr = rowptr; a.colidx = colidx; a.H = H; a.gid = table_gid; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.a2 = a2; a.b2 = b2; a.c = c; a.res = res;
+    a.rowptr = rowptr; a.colidx = colidx; a.edge_val = edge_val; a.H = H; a.gid = table_gid; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.a2 = a2; a.b2 = b2; a.c = c; a.res = res;
     a.out = out; a.out_stride = out_stride; a.pre = pre; a.lse = lse; a.aggp = aggp; a.tsum = tsum;
     a.N = N; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
@@ -856,7 +953,8 @@ extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, co
     return 0;
 }
 
-extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const void *g,
+extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const float *edge_val,
+                                      const void *g,
                                       const float *stats, const int32_t *table_gid, const void *H,
                                       int table_dtype, const float *f2,
                                       const float *df1, const float *a1, const float *a2,
@@ -870,7 +968,7 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
     if (NS == 0) return 0;
     BwdColsArgs a;
-    a.colptr = colptr; a.rowidx = rowidx; a.g = g; a.stats = stats; a.gid = table_gid; a.H = H; a.lsb_mask = fts_drop > 0.f; a.f2 = f2;
+    a.colptr = colptr; a.rowidx = rowidx; a.edge_val = edge_val; a.g = g; a.stats = stats; a.gid = table_gid; a.H = H; a.lsb_mask = fts_drop > 0.f; a.f2 = f2;
     a.df1 = df1; a.a1 = a1; a.a2 = a2; a.dH = dH; a.df2 = df2; a.NS = NS; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
@@ -925,5 +1023,27 @@ extern "C" int han_score_param_bwd(const void *H, int table_dtype, const float *
     o.nseg = 4;
     hipError_t e = han_reduce_slabs((const float *)workspace, grid, 128 + 2 * K, 128 + 2 * K, o, st);
     if (e != hipSuccess) return (int)e;
+    return 0;
+}
+
+extern "C" int han_node_attn_coefs(const int64_t *rowptr, const int32_t *colidx, const float *edge_val,
+                                   const int32_t *table_gid, const float *f1, const float *f2, float *coef,
+                                   int mean_heads, int64_t N, int64_t E, int K, int FP, float slope,
+                                   float coef_drop, uint64_t seed, int64_t row_offset, void *stream) {
+    if (!rowptr || !colidx || !f1 || !f2 || !coef || N < 0 || E < 0) return HAN_E_BADARG;
+    if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
+    if (coef_drop < 0.f || coef_drop >= 1.f) return HAN_E_BADARG;
+    if (N == 0 || E == 0) return 0;
+    CoefArgs a;
+    a.rowptr = rowptr; a.colidx = colidx; a.edge_val = edge_val; a.gid = table_gid; a.f1 = f1; a.f2 = f2;
+    a.coef = coef; a.N = N; a.slope = slope; a.mean_heads = mean_heads;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
+    a.inv_keep_coef = 1.f / (1.f - coef_drop);
+    a.row_offset = row_offset;
+    const int grid = attn_grid(N);
+    hipStream_t st = (hipStream_t)stream;
+    HAN_DISPATCH_FP(FP, { node_attn_coef_kernel<HAN_D / FPC><<<grid, 256, 0, st>>>(a); })
+    HAN_CHECK_LAUNCH();
     return 0;
 }

@@ -181,7 +181,8 @@ class HaloPlan:
         pos = torch.searchsorted(remote, c.clamp(max=int(remote[-1]) if remote.numel() else 0)) \
             if remote.numel() else torch.zeros_like(c)
         new_col = torch.where(is_local, c - part.row_start, pos + self.n_local).to(torch.int32)
-        self.graph = CSRGraph(g_local.rowptr, new_col.contiguous(), self.n_local + self.n_halo, validate=False)
+        self.graph = CSRGraph(g_local.rowptr, new_col.contiguous(), self.n_local + self.n_halo, validate=False,
+                              values=g_local.values)
         local_ids = torch.arange(part.row_start, part.row_end, device=dev, dtype=torch.int64)
         self.gid = torch.cat([local_ids, remote]).to(torch.int32).contiguous()
         self.remote_rows_total = part.n_global - part.n_local
@@ -217,4 +218,5 @@ class GatheredTable:
 def _row_block(g: CSRGraph, r0: int, r1: int, n_cols: int) -> CSRGraph:
     rp = g.rowptr[r0:r1 + 1]
     s, e = int(rp[0]), int(rp[-1])
-    return CSRGraph((rp - rp[0]).contiguous(), g.colidx[s:e].contiguous(), n_cols, validate=False)
+    return CSRGraph((rp - rp[0]).contiguous(), g.colidx[s:e].contiguous(), n_cols, validate=False,
+                    values=g.values[s:e].contiguous() if g.values is not None else None)

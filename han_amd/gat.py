@@ -178,16 +178,19 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
             out.append(hit[1])
         return out
 
-    def node_level(self, xs, graphs, attn_drop, ffd_drop, train, act_code, graphs_t=None):
-        """models/gat.py:39-60: every node-attention layer of every meta-path -> M (N,P,64)."""
-        def cfg():
+    def node_level(self, xs, graphs, attn_drop, ffd_drop, train, act_code, graphs_t=None, coef_sink=None):
+        """models/gat.py:39-60: every node-attention layer of every meta-path -> M (N,P,64).
+        coef_sink: a list that receives, per meta-path, the head-mean coefficients of the
+        FIRST layer (models/gat.py:143-172), or None."""
+        def cfg(**kw):
             return {"train": train, "in_drop": float(ffd_drop), "coef_drop": float(attn_drop),
                     "seeds": tuple(rng.next_seed() for _ in graphs) if train else (0,) * len(graphs),
                     "act": act_code, "part": self.partition, "graphs_t": graphs_t,
                     "table_dtype": self.table_dtype, "plans_f": self.halo_plans[0],
-                    "plans_b": self.halo_plans[1]}
+                    "plans_b": self.halo_plans[1], **kw}
         M = layers.NodeLevelAttention.apply(None, self.W, self.a1, self.b1, self.a2, self.b2, self.c,
-                                            None, None, tuple(xs), tuple(graphs), cfg())
+                                            None, None, tuple(xs), tuple(graphs),
+                                            cfg(coef_sink=coef_sink, coef_mean=True))
         for i in range(1, len(self.extra) + 1):                                 # gat.py:48-57
             g = lambda n: getattr(self, f"{n}_{i}", None)
             M = layers.NodeLevelAttention.apply(M, g("W"), g("a1"), g("b1"), g("a2"), g("b2"), g("c"),
@@ -198,6 +201,12 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
     def inference(self, inputs_list, nb_classes, nb_nodes, training, attn_drop, ffd_drop,
                   bias_mat_list, hid_units, n_heads, activation=F_torch.elu, residual=False,
                   mp_att_size=128):
+        return self._inference(inputs_list, nb_classes, nb_nodes, training, attn_drop, ffd_drop,
+                               bias_mat_list, hid_units, n_heads, activation, residual, mp_att_size)
+
+    def _inference(self, inputs_list, nb_classes, nb_nodes, training, attn_drop, ffd_drop,
+                   bias_mat_list, hid_units, n_heads, activation=F_torch.elu, residual=False,
+                   mp_att_size=128, coef_sink=None):
         """Same positional arguments as models/gat.py:35-37.  `inputs_list[p]`:
         (1,N,F) or (N,F) fp32 GPU tensor; `bias_mat_list[p]`: (1,N,N) additive
         mask, CSRGraph or (rowptr, colidx).  Lists are zipped, shorter wins
@@ -228,7 +237,10 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         attn_drop, ffd_drop = float(attn_drop), float(ffd_drop)
         if not train and (attn_drop > 0 or ffd_drop > 0):
             raise ValueError("dropout > 0 needs gradients enabled (training step)")
-        M = self.node_level(xs, graphs, attn_drop, ffd_drop, train, code)          # gat.py:39-60
+        M = self.node_level(xs, graphs, attn_drop, ffd_drop, train, code, coef_sink=coef_sink)  # gat.py:39-60
+        if coef_sink is not None:
+            coef_sink[:] = [torch.sparse_csr_tensor(g.rowptr, g.colidx.long(), v, (g.n_rows, g.n_cols))
+                            for g, v in zip(graphs, coef_sink)]
         final_embed, att_val = layers.SemanticAttention.apply(M, self.w_omega,     # gat.py:61-63
                                                               self.b_omega, self.u_omega)
         logits = layers.classifier(final_embed, self.Wc, self.bc)                  # gat.py:65-72
@@ -240,3 +252,40 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         return self.inference(inputs_list, self.C, None, None, attn_drop, ffd_drop, bias_mat_list,
                               [self.FP] + [e[1] for e in self.extra],
                               [self.K] + [e[0] for e in self.extra] + [self.HC], mp_att_size=self.A)
+
+
+class HeteGAT(HeteGAT_multi):
+    """models/gat.py:132-203: ONE feature tensor shared by all meta-paths (instead of
+    inputs_list) and the optional `return_coef`."""
+
+    _default = None
+
+    @_ClassOrInstance
+    def inference(self, inputs, nb_classes, nb_nodes, training, attn_drop, ffd_drop,
+                  bias_mat_list, hid_units, n_heads, activation=F_torch.elu, residual=False,
+                  mp_att_size=128, return_coef=False):
+        """Returns (logits, final_embed, att_val[, coef_list]).  coef_list[p] (gat.py:170-172):
+        the first layer's coefficients averaged over its heads, as a torch sparse CSR
+        tensor (N,N) over the stored neighbours of meta-path p (the reference's dense
+        (N,N) tensor is exactly 0 elsewhere); data only, no gradient."""
+        sink = [] if return_coef else None
+        out = self._inference([inputs] * len(bias_mat_list), nb_classes, nb_nodes, training, attn_drop,
+                              ffd_drop, bias_mat_list, hid_units, n_heads, activation, residual,
+                              mp_att_size, coef_sink=sink)
+        return out + (sink,) if return_coef else out
+
+
+class HeteGAT_no_coef(HeteGAT):
+    """models/gat.py:78-130.  (The reference's body reads an undefined `return_coef`,
+    gat.py:93, so it raises NameError when called; this is the evident intent: HeteGAT
+    without the coefficient output.)"""
+
+    _default = None
+
+    @_ClassOrInstance
+    def inference(self, inputs, nb_classes, nb_nodes, training, attn_drop, ffd_drop,
+                  bias_mat_list, hid_units, n_heads, activation=F_torch.elu, residual=False,
+                  mp_att_size=128):
+        return self._inference([inputs] * len(bias_mat_list), nb_classes, nb_nodes, training, attn_drop,
+                               ffd_drop, bias_mat_list, hid_units, n_heads, activation, residual,
+                               mp_att_size)

@@ -26,10 +26,12 @@ class CSRGraph:
 
     rowptr (n_rows+1,) int64, colidx (nnz,) int32, both on `device`.
     `n_cols` is the number of rows of the tables that colidx indexes.
+    `values` (nnz,) fp32 or None: the stored values of sp_attn_head's SparseTensor
+    adj_mat, which scale the logits (utils/layers.py:95-96); None == binary.
     """
 
     def __init__(self, rowptr: torch.Tensor, colidx: torch.Tensor, n_cols: int | None = None,
-                 validate: bool = True):
+                 validate: bool = True, values: torch.Tensor | None = None):
         if rowptr.dtype != torch.int64 or colidx.dtype != torch.int32:
             raise ValueError("rowptr must be int64 and colidx int32")
         if rowptr.dim() != 1 or colidx.dim() != 1 or rowptr.numel() < 1:
@@ -41,6 +43,11 @@ class CSRGraph:
         self.n_rows = rowptr.numel() - 1
         self.n_cols = int(n_cols) if n_cols is not None else self.n_rows
         self.nnz = colidx.numel()
+        if values is not None:
+            if values.shape != (self.nnz,) or values.device != colidx.device:
+                raise ValueError("values must be (nnz,) on the graph's device")
+            values = values.to(torch.float32).contiguous()
+        self.values = values
         self._t = None
         self._split = {}
         if validate:
@@ -69,7 +76,8 @@ class CSRGraph:
         return self.n_rows > 0 and bool((self.degrees() == 0).any())
 
     def to(self, device) -> "CSRGraph":
-        g = CSRGraph(self.rowptr.to(device), self.colidx.to(device), self.n_cols, validate=False)
+        g = CSRGraph(self.rowptr.to(device), self.colidx.to(device), self.n_cols, validate=False,
+                     values=self.values.to(device) if self.values is not None else None)
         return g
 
     # ---- row splitting for skewed degree distributions ---------------------------
@@ -115,7 +123,8 @@ class CSRGraph:
             counts = torch.bincount(cols, minlength=self.n_cols)
             colptr = torch.zeros(self.n_cols + 1, dtype=torch.int64, device=self.device)
             torch.cumsum(counts, 0, out=colptr[1:])
-            t = CSRGraph(colptr, rowidx, n_cols=self.n_rows, validate=False)
+            t = CSRGraph(colptr, rowidx, n_cols=self.n_rows, validate=False,
+                         values=self.values[order] if self.values is not None else None)
             t._t = self
             self._t = t
         return self._t
@@ -177,11 +186,14 @@ class CSRGraph:
 
     @staticmethod
     def from_torch_sparse(t: torch.Tensor) -> "CSRGraph":
-        """Binary pattern of a torch sparse COO/CSR tensor of shape (N,N) or
-        (1,N,N) (the rank-3 SparseTensor of utils/layers.py:85-115)."""
+        """A torch sparse COO/CSR tensor of shape (N,N) or (1,N,N) (the rank-3
+        SparseTensor of utils/layers.py:85-115).  All-ones values give a binary
+        graph; anything else is kept as `values` (they scale the logits, :95-96)."""
+        def vals_of(v):
+            return None if (v.numel() == 0 or bool(torch.all(v == 1))) else v.to(torch.float32)
         if t.layout == torch.sparse_csr:
             return CSRGraph(t.crow_indices().to(torch.int64), t.col_indices().to(torch.int32),
-                            t.shape[-1])
+                            t.shape[-1], values=vals_of(t.values()))
         t = t.coalesce()
         idx = t.indices()
         if idx.shape[0] == 3:
@@ -193,7 +205,7 @@ class CSRGraph:
         rows, cols = idx[0][order], idx[1][order]
         rowptr = torch.zeros(n + 1, dtype=torch.int64, device=t.device)
         torch.cumsum(torch.bincount(rows, minlength=n), 0, out=rowptr[1:])
-        return CSRGraph(rowptr, cols.to(torch.int32), t.shape[-1])
+        return CSRGraph(rowptr, cols.to(torch.int32), t.shape[-1], values=vals_of(t.values()[order]))
 
     def to_bias(self, dtype=torch.float32) -> torch.Tensor:
         """Back to the reference's dense additive mask (1,N,N) -- tests only."""

@@ -60,7 +60,10 @@ class NodeLevelAttention(torch.autograd.Function):
               table_dtype (torch.float32 | torch.bfloat16: storage of the H / g tables),
               graphs_t (tuple of P transposed graphs for the backward, or None),
               plans_f / plans_b (per meta-path HaloPlan or None: halo exchange instead of
-              the all-gather, forward / backward tables)
+              the all-gather, forward / backward tables),
+              coef_sink (None, or a list that receives per meta-path the coefficients
+              of this call as data -- (E,K), or their head mean (E,) with coef_mean=True;
+              return_coef of layers.py:43-44 / models/gat.py:143-172; single GPU only)
     """
 
     @staticmethod
@@ -92,6 +95,12 @@ class NodeLevelAttention(torch.autograd.Function):
             handle = None
             if multi:      # halo rows only (HaloPlan) or the whole shard (all-gather)
                 handle = plan.exchange_async(H) if plan is not None else part.all_gather_rows_async(H)
+            if cfg.get("coef_sink") is not None:
+                if multi:
+                    raise NotImplementedError("return_coef is not provided under a node partition")
+                cfg["coef_sink"].append(ops.node_attn_coefs(
+                    graphs[p], f1, f2, coef_drop=coef_drop, seed=seed, row_offset=row_offset,
+                    mean_heads=bool(cfg.get("coef_mean", False))))
             R = None
             if Wr is not None:   # same seed -> the same per-head input-dropout draws as for H
                 R, _, _ = ops.project_fwd(xs[p], Wr[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
@@ -273,7 +282,7 @@ def _squeeze_batch(seq: torch.Tensor, name="seq") -> torch.Tensor:
 
 
 def _single_head(seq, out_sz, graph, activation, in_drop, coef_drop, residual, params, training,
-                 seed):
+                 seed, return_coef=False):
     """One head of width out_sz through the D=64 kernels: the head occupies
     slot 0 of K = 64/out_sz head slots, the other slots have zero weights."""
     x = _squeeze_batch(seq)
@@ -299,7 +308,8 @@ def _single_head(seq, out_sz, graph, activation, in_drop, coef_drop, residual, p
     code, post = _act_code(activation)
     train = bool(training) or in_drop > 0 or coef_drop > 0 or W.requires_grad
     cfg = {"train": train, "in_drop": in_drop, "coef_drop": coef_drop,
-           "seeds": (rng.next_seed() if seed is None else seed,), "act": code, "part": None}
+           "seeds": (rng.next_seed() if seed is None else seed,), "act": code, "part": None,
+           "coef_sink": [] if return_coef else None}
     Wr = br = None
     if residual and Fin != out_sz:
         # utils/layers.py:38-40: + conv1d(seq, out_sz, 1) of the DROPPED input, before the
@@ -310,6 +320,10 @@ def _single_head(seq, out_sz, graph, activation, in_drop, coef_drop, residual, p
     ret = M[:, 0, :out_sz]
     if post is not None:
         ret = post(ret)
+    if return_coef:       # slot 0 of the K head slots is this head
+        coefs = torch.sparse_csr_tensor(graph.rowptr, graph.colidx.long(),
+                                        cfg["coef_sink"][0][:, 0].contiguous(), (graph.n_rows, graph.n_cols))
+        return ret[None], coefs
     return ret[None]     # (1,N,out_sz)
 
 
@@ -318,12 +332,13 @@ def attn_head(seq, out_sz, bias_mat, activation, in_drop=0.0, coef_drop=0.0, res
     """utils/layers.py:7-46.  seq (1,N,F); bias_mat (1,N,N) additive mask, or a
     CSRGraph / (rowptr, colidx) pair.  params: dict W (F,out_sz), a1 (out_sz,),
     b1 (), a2 (out_sz,), b2 (), c (out_sz,) [+ res_W (F,out_sz), res_b (out_sz,) when
-    residual=True and F != out_sz]."""
-    if return_coef:
-        raise NotImplementedError("return_coef would materialise the N x N coefficients; "
-                                  "not provided by the CSR kernels")
+    residual=True and F != out_sz].
+    return_coef=True also returns `coefs` (:43-44) -- the (dropped) softmax weights --
+    as a torch sparse CSR tensor (N,N) over the stored neighbours (every masked entry
+    of the reference's dense (1,N,N) tensor is exactly 0: exp(-1e9) == 0 in fp32);
+    data only, no gradient flows through it."""
     return _single_head(seq, out_sz, as_graph(bias_mat, seq.device), activation, in_drop,
-                        coef_drop, residual, params, training, seed)
+                        coef_drop, residual, params, training, seed, return_coef=return_coef)
 
 
 def attn_head_const_1(seq, out_sz, bias_mat, activation, in_drop=0.0, coef_drop=0.0, residual=False, *,
@@ -342,13 +357,10 @@ def attn_head_const_1(seq, out_sz, bias_mat, activation, in_drop=0.0, coef_drop=
 
 def sp_attn_head(seq, out_sz, adj_mat, activation, nb_nodes, in_drop=0.0, coef_drop=0.0,
                  residual=False, *, params, training=False, seed=None):
-    """utils/layers.py:85-127.  adj_mat: torch sparse (1,N,N)/(N,N) tensor with a
-    BINARY pattern, a CSRGraph or (rowptr, colidx).  Non-binary values (which
-    scale the logits in the reference, :95-96) are not supported."""
-    if isinstance(adj_mat, torch.Tensor) and adj_mat.layout != torch.strided:
-        vals = adj_mat.coalesce().values() if adj_mat.layout == torch.sparse_coo else adj_mat.values()
-        if vals.numel() and not bool(torch.all(vals == 1)):
-            raise NotImplementedError("sp_attn_head: only binary adjacency values are supported")
+    """utils/layers.py:85-127.  adj_mat: torch sparse (1,N,N)/(N,N) tensor, a
+    CSRGraph or (rowptr, colidx).  Stored values other than 1 scale the logits,
+    e_ij = LeakyReLU(v_ij*f1_i + v_ij*f2_j) (:95-98), as in the reference -- they
+    are not a mask; the softmax runs over the stored entries (:100)."""
     g = as_graph(adj_mat, seq.device)
     if g.n_rows != nb_nodes:
         raise ValueError(f"nb_nodes={nb_nodes} but adj_mat has {g.n_rows} rows")

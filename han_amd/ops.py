@@ -20,8 +20,8 @@ D = 64                     # K * F' of this build
 
 _workspaces: dict = {}
 
-# Optional timing hook (bench.py): a list to which node_attn_fwd appends
-# (tag, start_event, end_event, N, E) recorded on the launch stream.
+# Optional timing hook (bench.py): a list to which node_attn_fwd / node_attn_bwd_cols
+# append (tag, start_event, end_event, N, E) recorded on the launch stream.
 K2_TIMING: list | None = None
 
 
@@ -235,7 +235,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     _lib.check(lib.han_node_attn_fwd(
-        graph.rowptr.data_ptr(), graph.colidx.data_ptr(), H_tab.data_ptr(), tcode,
+        graph.rowptr.data_ptr(), graph.colidx.data_ptr(),
+        graph.values.data_ptr() if graph.values is not None else None, H_tab.data_ptr(), tcode,
         table_gid.data_ptr() if table_gid is not None else None, f1.data_ptr(),
         a2.data_ptr(), b2.data_ptr(), c.data_ptr(), res.data_ptr() if res is not None else None,
         out.data_ptr(), out.stride(0) if N > 1 else D,
@@ -246,6 +247,33 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         ev1.record()
         timing.append(("train" if train else "eval", ev0, ev1, N, graph.nnz))
     return out, saved
+
+
+def node_attn_coefs(graph: CSRGraph, f1, f2, coef_drop=0.0, seed=0, row_offset=0, mean_heads=False,
+                    table_gid=None):
+    """The attention coefficients as data (attn_head(..., return_coef=True),
+    utils/layers.py:27-30,43-44): (E,K) values in the CSR order of `graph`, or their
+    head mean (E,) (models/gat.py:171-172).  f1 (N,K), f2 (NT,K) from project_fwd."""
+    lib = _lib.load()
+    _chk(f1, "f1", None)
+    K = f1.shape[1]
+    FP = D // K
+    _check_heads(K, FP)
+    dev = f1.device
+    _chk(f1, "f1", (graph.n_rows, K))
+    _chk(f2, "f2", (graph.n_cols, K), device=dev)
+    if graph.device != dev:
+        raise ValueError("graph and f1 live on different devices")
+    if table_gid is not None:
+        _chk(table_gid, "table_gid", (graph.n_cols,), dtype=torch.int32, device=dev)
+    coef = torch.empty((graph.nnz,) if mean_heads else (graph.nnz, K), dtype=torch.float32, device=dev)
+    _lib.check(lib.han_node_attn_coefs(
+        graph.rowptr.data_ptr(), graph.colidx.data_ptr(),
+        graph.values.data_ptr() if graph.values is not None else None,
+        table_gid.data_ptr() if table_gid is not None else None, f1.data_ptr(), f2.data_ptr(),
+        coef.data_ptr(), int(bool(mean_heads)), graph.n_rows, graph.nnz, K, FP, LEAKY_SLOPE,
+        _check_drop(coef_drop, "coef_drop"), int(seed), int(row_offset), _stream()), "han_node_attn_coefs")
+    return coef
 
 
 def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=8, FP=8,
@@ -301,13 +329,21 @@ def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, 
     dH = torch.empty((NS, D), dtype=torch.float32, device=dev)
     df2 = torch.empty((NS, K), dtype=torch.float32, device=dev)
     split, _keep = _row_split_arg(graph_t, "b")
+    timing = K2_TIMING
+    if timing is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _lib.check(lib.han_node_attn_bwd_cols(
-        graph_t.rowptr.data_ptr(), graph_t.colidx.data_ptr(), g_tab.data_ptr(),
+        graph_t.rowptr.data_ptr(), graph_t.colidx.data_ptr(),
+        graph_t.values.data_ptr() if graph_t.values is not None else None, g_tab.data_ptr(),
         stats_tab.data_ptr(), table_gid.data_ptr() if table_gid is not None else None, H.data_ptr(),
         tcode, f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
         NS, graph_t.nnz, K, FP, LEAKY_SLOPE, _check_drop(coef_drop, "coef_drop"), fts_drop,
         int(seed), int(src_offset), int(dst_offset),
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_bwd_cols")
+    if timing is not None:
+        ev1.record()
+        timing.append(("bwd_cols", ev0, ev1, NS, graph_t.nnz))
     return dH, df2
 
 

@@ -105,18 +105,34 @@ size_t han_row_split_workspace(int64_t n_chunks);
  * int32 or NULL: the GLOBAL node id of each table row when the table is a
  * [local | halo] table of a node partition (the dropout RNG is keyed by global
  * ids); NULL means the table index is the global id.  res (N,D) or NULL: the
- * residual term conv1d(seq, F', 1) of layers.py:38-40, added before the activation.  f1 (N,K) for the local rows; a2 (K,FP); b2 (K); c (D).  out row i is written
+ * residual term conv1d(seq, F', 1) of layers.py:38-40, added before the activation.
+ * edge_val (E) fp32 in colidx order or NULL: the stored values of sp_attn_head's
+ * SparseTensor adj_mat, which SCALE the logits (e_ij = LeakyReLU(v_ij*(f1_i+f2_j)),
+ * layers.py:95-98) -- NULL is the binary adjacency every shipped config uses.
+ * f1 (N,K) for the local rows; a2 (K,FP); b2 (K); c (D).  out row i is written
  * at out + i*out_stride (so the K heads land directly in M[:,p,:],
  * models/gat.py:46,58-60).  Training extras (all or none may be NULL): pre (N,D)
  * pre-activation, lse (N,K) log-sum-exp of the scores, aggp (N,D) and tsum (N,K)
  * -- the LeakyReLU'-weighted aggregates that make df1 row-local in the backward. */
-int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const void *H,
+int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float *edge_val,
+                      const void *H,
                       int table_dtype, const int32_t *table_gid, const float *f1,
                       const float *a2, const float *b2, const float *c, const float *res,
                       float *out, int64_t out_stride, float *pre, float *lse, float *aggp,
                       float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
                       float coef_drop, float fts_drop, uint64_t seed, int64_t row_offset,
                       int activation, const han_row_split_t *split, void *stream);
+
+/* The attention coefficients themselves (attn_head(..., return_coef=True),
+ * utils/layers.py:27-30,43-44; models/gat.py:143-172 averages them over the heads):
+ * coef[e*K+k] = drop(alpha_ij)[k] for the stored entry e = (i,j) in CSR order, or with
+ * mean_heads != 0 coef[e] = mean_k of those.  f1, f2 (N,K)/(NT,K) as han_project_fwd
+ * wrote them; coef_drop/seed/row_offset/table_gid as in the forward (so the draws are
+ * the ones that forward used).  Diagnostic output: not used by training.            */
+int han_node_attn_coefs(const int64_t *rowptr, const int32_t *colidx, const float *edge_val,
+                        const int32_t *table_gid, const float *f1, const float *f2, float *coef,
+                        int mean_heads, int64_t N, int64_t E, int K, int FP, float slope,
+                        float coef_drop, uint64_t seed, int64_t row_offset, void *stream);
 
 /* Backward, step 1 (row-local): from dOut (N,D; row stride dout_stride) and
  * the saved pre/aggp/tsum/f1/lse compute
@@ -144,8 +160,10 @@ int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *
  * H (keep bits in bit 0 when fts_drop > 0), f2, df1 are the NS local source rows;
  * dH (NS,D), df2 (NS,K) outputs.
  * src_offset / the ids in rowidx + dst_offset are the global ids used as RNG
- * keys (must match the forward).                                            */
-int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const void *g,
+ * keys (must match the forward).  edge_val (E) or NULL: the forward's adjacency
+ * values permuted into the transposed graph's order.                         */
+int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const float *edge_val,
+                           const void *g,
                            const float *stats, const int32_t *table_gid, const void *H,
                            int table_dtype, const float *f2,
                            const float *df1, const float *a1, const float *a2,

@@ -83,7 +83,9 @@ def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset,
     h = _f64(H_tab)
     f2 = (h.view(-1, K, FP) * _f64(a2)[None]).sum(-1) + _f64(b2)
     u = _f64(f1)[rows] + f2[cols]                                  # (E,K)
-    sg = torch.where(u > 0, torch.ones_like(u), torch.full_like(u, SLOPE))
+    w = _f64(graph.values)[:, None] if graph.values is not None else torch.ones((1, 1), dtype=torch.float64)
+    u = w * u                                                      # layers.py:95-96
+    sg = torch.where(u > 0, torch.ones_like(u), torch.full_like(u, SLOPE)) * w
     e = torch.maximum(u, SLOPE * u)
     mx = torch.full((graph.n_rows, K), -1e30, dtype=torch.float64)
     mx = mx.scatter_reduce(0, rows[:, None].expand(-1, K), e, reduce="amax")
@@ -153,8 +155,9 @@ def node_attn_bwd_cols(graph_t, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=
     src = _rows_of(graph_t)                       # local source j per transposed edge
     dst = graph_t.colidx.long()                   # destination i (table index)
     st = _f64(stats_tab)
-    u = st[dst, :, 0] + _f64(f2)[src]
-    sg = torch.where(u > 0, torch.ones_like(u), torch.full_like(u, SLOPE))
+    w = _f64(graph_t.values)[:, None] if graph_t.values is not None else torch.ones((1, 1), dtype=torch.float64)
+    u = w * (st[dst, :, 0] + _f64(f2)[src])
+    sg = torch.where(u > 0, torch.ones_like(u), torch.full_like(u, SLOPE)) * w
     alpha = torch.exp(torch.maximum(u, SLOPE * u) - st[dst, :, 1])
     am = torch.ones_like(alpha)
     if coef_drop > 0:

@@ -12,7 +12,7 @@ import torch
 from oracle import han_oracle as ho
 from oracle import han_oracle_torch as ht
 from tests import rng_ref
-from tests.helpers import build_model, gpu_inputs, make_problem, rel_err
+from tests.helpers import load_params, build_model, gpu_inputs, make_problem, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -445,6 +445,124 @@ def test_attn_head_and_sp_attn_head_api(dev):
     with torch.no_grad():
         out_c = layers.attn_head_const_1(x, 8, _t(prob["biases"][0], dev), Fnn.elu, params=params)
     assert np.abs(out_c.cpu().numpy() - ho.attn_head_const_1(prob["x"], head, prob["biases"][0])).max() < TOL
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.6])
+def test_sp_attn_head_weighted_adjacency_values(dev, drop, monkeypatch):
+    """sp_attn_head with NON-binary stored values: they scale the logits,
+    e_ij = LeakyReLU(v_ij*f1_i + v_ij*f2_j) (layers.py:95-98) -- forward against
+    the NumPy oracle (single head, reference-named call) and all 8 heads + every
+    gradient against float64 autograd of the CSR oracle, with and without the
+    dropouts (same hash masks), incl. split long rows and the low-degree variant."""
+    import torch.nn.functional as Fnn
+    from han_amd import layers, ops
+    from han_amd.graph import CSRGraph
+    monkeypatch.setattr(ops, "SPLIT_DEG", 48)
+    monkeypatch.setattr(ops, "SPLIT_CHUNK", 16)
+    for n, dens in ((120, 0.3), (90, 0.02)):
+        prob = make_problem(77 + n, n, 11, 1, 3, [dens])
+        rng = np.random.default_rng(n)
+        rp, ci = ho.bias_to_csr(prob["biases"][0])
+        vals = rng.uniform(-1.5, 2.0, size=len(ci))           # negative values flip the LeakyReLU branch
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        if drop == 0.0:
+            # reference-named single-head call on a torch sparse (1,N,N) tensor
+            head = prob["params"]["heads"][0][0]
+            idx = np.stack([np.zeros(len(ci)), rows, ci])
+            sp_adj = torch.sparse_coo_tensor(torch.tensor(idx, dtype=torch.long),
+                                             torch.tensor(vals, dtype=torch.float32), (1, n, n)).to(dev)
+            params = {k: _t(v, dev) for k, v in head.items()}
+            with torch.no_grad():
+                out = layers.sp_attn_head(_t(prob["x"], dev), 8, sp_adj, Fnn.elu, n, params=params)
+            ref = ho.sp_attn_head(prob["x"], head, rp, ci, adj_vals=vals.astype(np.float32).astype(np.float64))
+            assert np.abs(out.cpu().numpy() - ref).max() < TOL
+        # all K heads through the autograd Function, gradients vs the CSR oracle
+        bp = ht.to_batched(prob["params"])
+        g = CSRGraph.from_arrays(rp, ci, n, device=dev)
+        v32 = torch.tensor(vals, dtype=torch.float32)
+        g = CSRGraph(g.rowptr, g.colidx, n, values=v32.to(dev))
+        leaf = {k: bp[k][0].clone().to(torch.float32).to(dev).requires_grad_(True)
+                for k in ("W", "a1", "b1", "a2", "b2", "c")}
+        seed = 0xABCDEF12345
+        cfg = {"train": True, "in_drop": drop, "coef_drop": drop, "seeds": (seed,), "act": ops.ACT_ELU,
+               "part": None}
+        x = _t(prob["x"][0], dev)
+        M = layers.NodeLevelAttention.apply(None, *(leaf[k][None] for k in ("W", "a1", "b1", "a2", "b2", "c")),
+                                            None, None, (x,), (g,), cfg)
+        wgt = torch.tensor(rng.standard_normal((n, 64)), dtype=torch.float32, device=dev)
+        (M[:, 0, :] * wgt).sum().backward()
+        ref_leaf = {k: bp[k][0].clone().requires_grad_(True) for k in leaf}
+        masks, keep = None, 1.0
+        if drop > 0:
+            keep = rng_ref.keep_prob32(drop)
+            masks = {"seq": torch.tensor(rng_ref.seq_mask(seed, n, 11, 8, drop)),
+                     "coef": torch.tensor(rng_ref.coef_mask_csr(seed, rp, ci, 8, drop)),
+                     "fts": torch.tensor(rng_ref.fts_mask(seed, n, 64, drop))}
+        ref_out = ht.node_attention_csr(torch.tensor(prob["x"][0]), torch.tensor(rp), torch.tensor(ci),
+                                        ref_leaf["W"], ref_leaf["a1"], ref_leaf["b1"], ref_leaf["a2"],
+                                        ref_leaf["b2"], ref_leaf["c"], keep_in=keep, keep_coef=keep,
+                                        masks=masks, adj_vals=v32.to(torch.float64))
+        (ref_out * wgt.cpu().to(torch.float64)).sum().backward()
+        assert np.abs(M[:, 0, :].detach().cpu().numpy() - ref_out.detach().numpy()).max() < 5 * TOL
+        for k in leaf:
+            assert rel_err(leaf[k].grad.cpu().numpy(), ref_leaf[k].grad.numpy()) < GTOL, k
+
+
+def test_return_coef_and_hetegat_class(dev):
+    """attn_head(..., return_coef=True) (layers.py:43-44) and HeteGAT.inference(...,
+    return_coef=True) (models/gat.py:132-203: shared inputs, head-mean coefficients per
+    meta-path) against the dense oracle; with attention dropout the returned
+    coefficients are the DROPPED ones (the rebinding at layers.py:30)."""
+    import torch.nn.functional as Fnn
+    from han_amd import layers
+    from han_amd.gat import HeteGAT, HeteGAT_no_coef
+    n, p = 60, 2
+    prob = make_problem(41, n, 9, p, 3, [0.15, 0.5])
+    x = _t(prob["x"], dev)
+    head = prob["params"]["heads"][0][0]
+    params = {k: _t(v, dev) for k, v in head.items()}
+    for drop in (0.0, 0.6):
+        seed = 0x5EED5EED
+        rp, ci = ho.bias_to_csr(prob["biases"][0])
+        masks = None
+        if drop > 0:
+            cm = np.zeros((1, n, n))
+            cm[0, np.repeat(np.arange(n), np.diff(rp)), ci] = rng_ref.coef_mask_csr(seed, rp, ci, 8, drop)[:, 0]
+            masks = {"coef": cm}
+        ref_out, ref_coef = ho.attn_head(prob["x"], head, prob["biases"][0], coef_drop=drop,
+                                         return_coef=True, masks=masks)
+        with torch.no_grad():
+            out, coefs = layers.attn_head(x, 8, _t(prob["biases"][0], dev), Fnn.elu, coef_drop=drop,
+                                          return_coef=True, params=params, training=drop > 0, seed=seed)
+        assert coefs.layout == torch.sparse_csr and tuple(coefs.shape) == (n, n)
+        if drop > 0:       # float32 keep probability, as the kernels use it
+            ref_coef = ref_coef * (1.0 - drop) / rng_ref.keep_prob32(drop)
+            ref_out = None
+        assert np.abs(coefs.to_dense().cpu().numpy() - ref_coef[0]).max() < 1e-5
+        if ref_out is not None:
+            assert np.abs(out.cpu().numpy() - ref_out).max() < TOL
+    # HeteGAT: one inputs tensor, coef_list[p] = mean over the 8 heads
+    HeteGAT.reset_default()
+    model = HeteGAT()
+    model.build(p, 9, 3, (8,), (8, 1), 128, device=dev)
+    load_params(model, ht.to_batched(prob["params"]))
+    biases = [_t(b, dev) for b in prob["biases"]]
+    with torch.no_grad():
+        logits, fe, att, coef_list = model.inference(x, 3, n, False, 0.0, 0.0, biases, [8], [8, 1],
+                                                     return_coef=True)
+        m2 = HeteGAT_no_coef()
+        m2.build(p, 9, 3, (8,), (8, 1), 128, device=dev)
+        load_params(m2, ht.to_batched(prob["params"]))
+        out3 = m2.inference(x, 3, n, False, 0.0, 0.0, biases, [8], [8, 1])
+    lg, fe_ref, att_ref = ho.hetegat_multi_inference([prob["x"]] * p, 3, n, False, 0.0, 0.0, prob["biases"],
+                                                     [8], [8, 1], prob["params"])
+    assert np.abs(logits.cpu().numpy() - lg).max() < TOL and len(out3) == 3
+    assert np.abs(out3[0].cpu().numpy() - lg).max() < TOL
+    assert len(coef_list) == p
+    for q in range(p):
+        per_head = [ho.attn_head(prob["x"], prob["params"]["heads"][q][k], prob["biases"][q],
+                                 return_coef=True)[1][0] for k in range(8)]
+        assert np.abs(coef_list[q].to_dense().cpu().numpy() - np.mean(per_head, axis=0)).max() < 1e-5
 
 
 def test_errors_are_loud(dev):

@@ -133,6 +133,43 @@ def test_cpu_backend_gradients_match_oracle(cpu_ops, drop):
     assert off == model.flat.numel()
 
 
+def test_weighted_adjacency_values_on_cpu_backend(cpu_ops):
+    """sp_attn_head's stored values scale the logits (layers.py:95-98): the host path
+    (CSRGraph.values, their permutation into the transposed graph, the autograd
+    wiring) against float64 autograd of the CSR oracle."""
+    from han_amd import layers
+    from han_amd.graph import CSRGraph
+    n = 40
+    prob = make_problem(3, n, 6, 1, 3, [0.2])
+    rng = np.random.default_rng(0)
+    rp, ci = ho.bias_to_csr(prob["biases"][0])
+    vals = torch.tensor(rng.uniform(-1.5, 2.0, size=len(ci)), dtype=torch.float32)
+    g = CSRGraph(torch.tensor(rp), torch.tensor(ci, dtype=torch.int32), n, values=vals)
+    gt = g.transpose()
+    dense = torch.zeros(n, n)
+    dense[np.repeat(np.arange(n), np.diff(rp)), ci] = vals
+    assert torch.equal(dense.t()[_rows(gt), gt.colidx.long()], gt.values)
+    bp = ht.to_batched(prob["params"])
+    names = ("W", "a1", "b1", "a2", "b2", "c")
+    leaf = {k: bp[k][0].clone().to(torch.float32).requires_grad_(True) for k in names}
+    cfg = {"train": True, "in_drop": 0.0, "coef_drop": 0.0, "seeds": (1,), "act": 1, "part": None}
+    x = torch.tensor(prob["x"][0], dtype=torch.float32)
+    M = layers.NodeLevelAttention.apply(None, *(leaf[k][None] for k in names), None, None, (x,), (g,), cfg)
+    wgt = torch.tensor(rng.standard_normal((n, 64)))
+    (M[:, 0, :] * wgt.to(torch.float32)).sum().backward()
+    ref = {k: bp[k][0].clone().requires_grad_(True) for k in names}
+    out = ht.node_attention_csr(torch.tensor(prob["x"][0]), torch.tensor(rp), torch.tensor(ci),
+                                *(ref[k] for k in names), adj_vals=vals.to(torch.float64))
+    (out * wgt).sum().backward()
+    assert np.abs(M[:, 0, :].detach().numpy() - out.detach().numpy()).max() < 1e-5
+    for k in names:
+        assert rel_err(leaf[k].grad.numpy(), ref[k].grad.numpy()) < 1e-4, k
+
+
+def _rows(g):
+    return torch.repeat_interleave(torch.arange(g.n_rows), g.degrees())
+
+
 def test_trainer_epochs_match_oracle_on_cpu_backend(cpu_ops):
     from han_amd.trainer import HANTrainer
     prob = make_problem(31, 50, 8, 2, 3, [0.1, 0.4])
