@@ -33,21 +33,21 @@ SIGNATURES = {
     "han_abi_version": (c_int, []),
     "han_error_string": (c_char_p, [c_int]),
     "han_project_fwd": (c_int, [P, c_int, I64, P, P, P, P, P, P, c_int, P, P, I64, c_int, c_int, c_int,
-                                c_float, c_float, c_uint64, I64, P]),
+                                c_float, c_float, c_uint64, P, I64, P]),
     "han_project_bwd_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
     "han_project_bwd": (c_int, [P, c_int, I64, P, P, P, c_size_t, I64, c_int, c_int, c_int, c_float,
-                                c_uint64, I64, P]),
-    "han_project_bwd_input": (c_int, [P, P, P, I64, I64, c_int, c_int, c_int, c_float, c_uint64, I64, P]),
+                                c_uint64, P, I64, P]),
+    "han_project_bwd_input": (c_int, [P, P, P, I64, I64, c_int, c_int, c_int, c_float, c_uint64, P, I64, P]),
     "han_row_split_workspace": (c_size_t, [I64]),
     "han_node_attn_fwd": (c_int, [P, P, P, P, c_int, P, P, P, P, P, P, P, I64, P, P, P, P, I64, I64, c_int,
-                                  c_int, c_float, c_float, c_float, c_uint64, I64, c_int, P, P]),
+                                  c_int, c_float, c_float, c_float, c_uint64, P, I64, c_int, P, P]),
     "han_node_attn_coefs": (c_int, [P, P, P, P, P, P, P, c_int, I64, I64, c_int, c_int, c_float, c_float,
-                                    c_uint64, I64, P]),
+                                    c_uint64, P, I64, P]),
     "han_node_attn_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
     "han_node_attn_bwd_rows": (c_int, [P, I64, P, P, P, P, P, P, P, P, c_int, P, P, P, P, c_size_t, I64,
                                        c_int, c_int, c_int, P]),
     "han_node_attn_bwd_cols": (c_int, [P, P, P, P, P, P, P, c_int, P, P, P, P, P, P, I64, I64, c_int, c_int,
-                                       c_float, c_float, c_float, c_uint64, I64, I64, P, P]),
+                                       c_float, c_float, c_float, c_uint64, P, I64, I64, P, P]),
     "han_score_param_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
     "han_score_param_bwd": (c_int, [P, c_int, P, P, P, P, P, P, P, c_size_t, I64, c_int, c_int, P]),
     "han_sem_attn_fwd": (c_int, [P, P, P, P, P, P, I64, c_int, c_int, c_int, P]),
@@ -57,7 +57,7 @@ SIGNATURES = {
     "han_classifier_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
     "han_classifier_loss": (c_int, [P, P, P, P, P, c_float, P, P, P, P, P, P, c_size_t, I64,
                                     c_int, c_int, c_int, P]),
-    "han_adam_step": (c_int, [P, P, P, P, I64, c_float, c_float, c_float, c_float, c_float, P]),
+    "han_adam_step": (c_int, [P, P, P, P, I64, c_float, c_float, c_float, c_float, c_float, P, P]),
     "han_l2_half_sumsq": (c_int, [P, I64, P, P, c_size_t, P]),
     "han_bias_row_counts": (c_int, [P, I64, I64, P, P]),
     "han_bias_fill_csr": (c_int, [P, I64, I64, P, P, P]),

@@ -31,10 +31,17 @@ class TFAdam:
         self.v = torch.zeros_like(flat_param)
         self.lr, self.l2, self.b1, self.b2, self.eps = lr, l2_coef, beta1, beta2, eps
         self.t = 0
+        # captured-step mode: the step count lives on the device (1-element int64 tensor,
+        # bumped by the trainer before each step) and the kernel forms lr_t itself
+        self.step_dev: torch.Tensor | None = None
 
     def step(self):
         from . import ops
         self.t += 1
+        if self.step_dev is not None:
+            ops.adam_step(self.p, self.g, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.l2,
+                          step_dev=self.step_dev)
+            return
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
         ops.adam_step(self.p, self.g, self.m, self.v, lr_t, self.b1, self.b2, self.eps, self.l2)
 

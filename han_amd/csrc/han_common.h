@@ -59,6 +59,26 @@ __host__ __device__ __forceinline__ HanRand64 han_rand64(uint32_t seed_lo, uint3
     return r;
 }
 
+// A captured hipGraph replays fixed kernel arguments, so a by-value seed would repeat the
+// same masks every step.  Every seeded entry point therefore also takes `seed_dev`: when
+// non-null the effective seed is splitmix64(seed + *seed_dev), read on the device at
+// kernel start -- the host bumps the device word between replays (a captured add).
+__host__ __device__ __forceinline__ uint64_t han_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ void han_resolve_seed(uint32_t &seed_lo, uint32_t &seed_hi, const uint64_t *seed_dev) {
+    if (seed_dev) {
+        const uint64_t s = han_splitmix64((((uint64_t)seed_hi << 32) | seed_lo) + *seed_dev);
+        seed_lo = (uint32_t)s;
+        seed_hi = (uint32_t)(s >> 32);
+    }
+}
+
 // keep iff the 16-bit field is below keep_prob * 2^16 (65536 = keep everything)
 __host__ __device__ __forceinline__ uint32_t han_keep_threshold(float keep_prob) {
     return (uint32_t)(keep_prob * 65536.0f);

@@ -152,7 +152,11 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
 }
 
 __global__ void adam_kernel(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1,
-                            float b2, float eps, float l2) {
+                            float b2, float eps, float l2, const int64_t *step_dev) {
+    if (step_dev) {   // lr_t holds the base rate; the bias correction comes from the device step count
+        const double t = (double)*step_dev;
+        lr_t = (float)((double)lr_t * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+    }
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float pi = p[i];
@@ -266,11 +270,12 @@ extern "C" int han_classifier_loss(const float *Z, const float *Wc, const float 
 }
 
 extern "C" int han_adam_step(float *param, const float *grad, float *m, float *v, int64_t n, float lr_t,
-                             float beta1, float beta2, float eps, float l2_coef, void *stream) {
+                             float beta1, float beta2, float eps, float l2_coef, const int64_t *step_dev,
+                             void *stream) {
     if (!param || !grad || !m || !v || n < 0) return HAN_E_BADARG;
     if (n == 0) return 0;
     adam_kernel<<<han_grid_for(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(param, grad, m, v, n, lr_t, beta1,
-                                                                            beta2, eps, l2_coef);
+                                                                            beta2, eps, l2_coef, step_dev);
     HAN_CHECK_LAUNCH();
     return 0;
 }

@@ -66,6 +66,7 @@ struct FwdArgs {
     int64_t N;
     float slope;
     uint32_t seed_lo, seed_hi, thr_coef;
+    const uint64_t *seed_dev;
     float inv_keep_coef, inv_keep_fts;
     int64_t row_offset;
     int activation;
@@ -212,7 +213,9 @@ __device__ __forceinline__ void write_row(const FwdArgs &a, const int64_t row, c
 // (Forcing more waves per SIMD on the TRAIN instantiation with __launch_bounds__ spills
 // 92-180 B/lane to scratch and measured 5-25 % slower in both cache and HBM regimes.)
 template <int FP, bool TRAIN, int RPW, int U, bool BF>
-__global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
+__global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) {
+    FwdArgs a = a_in;
+    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     constexpr int K = HAN_D / FP;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
@@ -289,7 +292,9 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a) {
 
 // Split rows, step 1: one wave per chunk of a long row -> un-normalised partial state.
 template <int FP, bool TRAIN, int U, bool BF>
-__global__ __launch_bounds__(256) void node_attn_fwd_chunk_kernel(const FwdArgs a) {
+__global__ __launch_bounds__(256) void node_attn_fwd_chunk_kernel(const FwdArgs a_in) {
+    FwdArgs a = a_in;
+    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     constexpr int K = HAN_D / FP;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
@@ -460,6 +465,7 @@ struct BwdColsArgs {
     int64_t NS;
     float slope;
     uint32_t seed_lo, seed_hi, thr_coef;
+    const uint64_t *seed_dev;
     float inv_keep_coef, inv_keep_fts;
     int64_t src_offset, dst_offset;
     int64_t split_deg;
@@ -544,7 +550,9 @@ __device__ __forceinline__ void write_src(const BwdColsArgs &a, const int64_t sr
 }
 
 template <int FP, int RPW, int U, bool BF>
-__global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsArgs a) {
+__global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsArgs a_in) {
+    BwdColsArgs a = a_in;
+    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
     const int head = (4 * q) / FP;
@@ -604,7 +612,9 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
 
 // Split source rows: one wave per chunk -> partial sums; one 16-lane group per long row adds them.
 template <int FP, int U, bool BF>
-__global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsArgs a) {
+__global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsArgs a_in) {
+    BwdColsArgs a = a_in;
+    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
     const int head = (4 * q) / FP;
@@ -732,13 +742,16 @@ struct CoefArgs {
     int64_t N;
     float slope;
     uint32_t seed_lo, seed_hi, thr_coef;
+    const uint64_t *seed_dev;
     float inv_keep_coef;
     int64_t row_offset;
     int mean_heads;
 };
 
 template <int K>
-__global__ __launch_bounds__(256) void node_attn_coef_kernel(const CoefArgs a) {
+__global__ __launch_bounds__(256) void node_attn_coef_kernel(const CoefArgs a_in) {
+    CoefArgs a = a_in;
+    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     constexpr int KQ = (K + 3) / 4;
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -874,8 +887,9 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
                                  const float *c, const float *res, float *out, int64_t out_stride, float *pre,
                                  float *lse,
                                  float *aggp, float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
-                                 float coef_drop, float fts_drop, uint64_t seed, int64_t row_offset,
-                                 int activation, const han_row_split_t *split, void *stream) {
+                                 float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev,
+                                 int64_t row_offset, int activation, const han_row_split_t *split,
+                                 void *stream) {
     if (!rowptr || !colidx || !H || !f1 || !a2 || !b2 || !c || !out || N < 0 || E < 0 || out_stride < HAN_D)
         return HAN_E_BADARG;
     if (!split_ok(split)) return HAN_E_BADARG;
@@ -889,7 +903,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     a.rowptr = rowptr; a.colidx = colidx; a.edge_val = edge_val; a.H = H; a.gid = table_gid; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.a2 = a2; a.b2 = b2; a.c = c; a.res = res;
     a.out = out; a.out_stride = out_stride; a.pre = pre; a.lse = lse; a.aggp = aggp; a.tsum = tsum;
     a.N = N; a.slope = slope;
-    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
     a.inv_keep_fts = 1.f / (1.f - fts_drop);
@@ -959,8 +973,9 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
                                       int table_dtype, const float *f2,
                                       const float *df1, const float *a1, const float *a2,
                                       float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
-                                      float coef_drop, float fts_drop, uint64_t seed, int64_t src_offset,
-                                      int64_t dst_offset, const han_row_split_t *split, void *stream) {
+                                      float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev,
+                                      int64_t src_offset, int64_t dst_offset, const han_row_split_t *split,
+                                      void *stream) {
     if (!colptr || !rowidx || !g || !stats || !H || !f2 || !df1 || !a1 || !a2 || !dH || !df2 || NS < 0 || E < 0)
         return HAN_E_BADARG;
     if (!split_ok(split)) return HAN_E_BADARG;
@@ -970,7 +985,7 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
     BwdColsArgs a;
     a.colptr = colptr; a.rowidx = rowidx; a.edge_val = edge_val; a.g = g; a.stats = stats; a.gid = table_gid; a.H = H; a.lsb_mask = fts_drop > 0.f; a.f2 = f2;
     a.df1 = df1; a.a1 = a1; a.a2 = a2; a.dH = dH; a.df2 = df2; a.NS = NS; a.slope = slope;
-    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
     a.inv_keep_fts = 1.f / (1.f - fts_drop);
@@ -1029,7 +1044,8 @@ extern "C" int han_score_param_bwd(const void *H, int table_dtype, const float *
 extern "C" int han_node_attn_coefs(const int64_t *rowptr, const int32_t *colidx, const float *edge_val,
                                    const int32_t *table_gid, const float *f1, const float *f2, float *coef,
                                    int mean_heads, int64_t N, int64_t E, int K, int FP, float slope,
-                                   float coef_drop, uint64_t seed, int64_t row_offset, void *stream) {
+                                   float coef_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset,
+                                   void *stream) {
     if (!rowptr || !colidx || !f1 || !f2 || !coef || N < 0 || E < 0) return HAN_E_BADARG;
     if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
     if (coef_drop < 0.f || coef_drop >= 1.f) return HAN_E_BADARG;
@@ -1037,7 +1053,7 @@ extern "C" int han_node_attn_coefs(const int64_t *rowptr, const int32_t *colidx,
     CoefArgs a;
     a.rowptr = rowptr; a.colidx = colidx; a.edge_val = edge_val; a.gid = table_gid; a.f1 = f1; a.f2 = f2;
     a.coef = coef; a.N = N; a.slope = slope; a.mean_heads = mean_heads;
-    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
     a.row_offset = row_offset;

@@ -32,6 +32,7 @@ struct ProjFwdArgs {
     int64_t N;
     int F;
     uint32_t seed_lo, seed_hi, thr_in, thr_fts;   // thr_fts < 2^16: stamp keep bits into H
+    const uint64_t *seed_dev;
     float inv_keep_in;
     int64_t row_offset;
 };
@@ -62,7 +63,9 @@ struct HeadsPerTile { static constexpr int value = FP >= 16 ? 1 : 16 / FP; };
 // head a tile covers gets its own accumulator: the A fragment is masked per head
 // and the columns of the other heads are simply not read back.
 template <int FP, bool DROP, int MT, bool VEC>
-__global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a) {
+__global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a_in) {
+    ProjFwdArgs a = a_in;
+    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     constexpr int K = HAN_D / FP;
     constexpr int KQ = (K + 3) / 4;   // one RNG call = four 16-bit draws = four heads
     constexpr int HPT = DROP ? HeadsPerTile<FP>::value : 1;
@@ -260,6 +263,7 @@ struct ProjBwdArgs {
     int F;
     int64_t rows_per_chunk;
     uint32_t seed_lo, seed_hi, thr_in;
+    const uint64_t *seed_dev;
     float inv_keep_in;
     int64_t row_offset;
 };
@@ -268,7 +272,9 @@ struct ProjBwdArgs {
 // re-read F/(64*MT) times; VEC = 16-byte fp32 X loads.  With dropout every head a
 // column tile covers has its own accumulator (A masked per head), as in the forward.
 template <int FP, bool DROP, int MT, bool VEC>
-__global__ __launch_bounds__(256) void project_bwd_kernel(const ProjBwdArgs a) {
+__global__ __launch_bounds__(256) void project_bwd_kernel(const ProjBwdArgs a_in) {
+    ProjBwdArgs a = a_in;
+    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     constexpr int K = HAN_D / FP;
     constexpr int KQ = (K + 3) / 4;
     constexpr int HPT = DROP ? HeadsPerTile<FP>::value : 1;
@@ -410,12 +416,15 @@ struct ProjBwdInArgs {
     int64_t N;
     int F;
     uint32_t seed_lo, seed_hi, thr_in;
+    const uint64_t *seed_dev;
     float inv_keep_in;
     int64_t row_offset;
 };
 
 template <int FP, bool DROP>
-__global__ __launch_bounds__(256) void project_bwd_input_kernel(const ProjBwdInArgs a) {
+__global__ __launch_bounds__(256) void project_bwd_input_kernel(const ProjBwdInArgs a_in) {
+    ProjBwdInArgs a = a_in;
+    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     constexpr int K = HAN_D / FP;
     constexpr int KQ = (K + 3) / 4;
     constexpr int KS = (FP + 3) / 4;          // MFMA k-steps per head (FP = 4 -> 1, 8 -> 2, ...)
@@ -499,7 +508,8 @@ void bwd_geometry(int64_t N, int F, int *ftiles, int64_t *rows_per_chunk, int64_
 extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const float *W, const float *a1,
                                const float *a2, const float *b1, const float *b2, void *H, int table_dtype,
                                float *f1, float *f2, int64_t N, int F, int K, int FP, float in_drop,
-                               float fts_drop, uint64_t seed, int64_t row_offset, void *stream) {
+                               float fts_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset,
+                               void *stream) {
     if (!X || !W || !a1 || !a2 || !b1 || !b2 || !H || !f1 || !f2 || N < 0 || F <= 0 || ldx < F)
         return HAN_E_BADARG;
     if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
@@ -512,7 +522,7 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
     ProjFwdArgs a;
     a.X = X; a.ldx = ldx; a.W = W; a.H = H; a.N = N; a.F = F;
     a.x_bf16 = x_dtype == HAN_DTYPE_BF16; a.h_bf16 = table_dtype == HAN_DTYPE_BF16;
-    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : HAN_KEEP_ALL;
     a.thr_fts = fts_drop > 0.f ? han_keep_threshold(1.f - fts_drop) : HAN_KEEP_ALL;
     a.inv_keep_in = 1.f / (1.f - in_drop);
@@ -552,7 +562,7 @@ extern "C" size_t han_project_bwd_workspace(int64_t N, int F, int K, int FP) {
 
 extern "C" int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const float *dH, float *dW, void *workspace,
                                size_t workspace_bytes, int64_t N, int F, int K, int FP, float in_drop,
-                               uint64_t seed, int64_t row_offset, void *stream) {
+                               uint64_t seed, const uint64_t *seed_dev, int64_t row_offset, void *stream) {
     if (!X || !dH || !dW || !workspace || N < 0 || F <= 0 || ldx < F) return HAN_E_BADARG;
     if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
     if (x_dtype != HAN_DTYPE_F32 && x_dtype != HAN_DTYPE_BF16) return HAN_E_UNSUPPORTED;
@@ -564,7 +574,7 @@ extern "C" int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const fl
     ProjBwdArgs a;
     a.X = X; a.x_bf16 = x_dtype == HAN_DTYPE_BF16; a.ldx = ldx; a.dH = dH; a.slab = (float *)workspace; a.N = N; a.F = F;
     a.rows_per_chunk = rpc;
-    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : HAN_KEEP_ALL;
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
@@ -587,15 +597,15 @@ extern "C" int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const fl
 }
 
 extern "C" int han_project_bwd_input(const float *dH, const float *W, float *dX, int64_t ldo, int64_t N,
-                                     int F, int K, int FP, float in_drop, uint64_t seed, int64_t row_offset,
-                                     void *stream) {
+                                     int F, int K, int FP, float in_drop, uint64_t seed,
+                                     const uint64_t *seed_dev, int64_t row_offset, void *stream) {
     if (!dH || !W || !dX || N < 0 || F <= 0 || ldo < F) return HAN_E_BADARG;
     if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
     if (in_drop < 0.f || in_drop >= 1.f) return HAN_E_BADARG;
     if (N == 0) return 0;
     ProjBwdInArgs a;
     a.dH = dH; a.W = W; a.dX = dX; a.ldo = ldo; a.N = N; a.F = F;
-    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : HAN_KEEP_ALL;
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;

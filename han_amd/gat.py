@@ -66,6 +66,10 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         self.partition: NodePartition | None = None
         self.halo_plans = (None, None)        # (forward, backward) per-meta-path HaloPlan lists
         self._graph_cache: dict = {}
+        # captured-step mode (HANTrainer(use_graph=True)): a device seed word that the trainer
+        # bumps between replays + fixed per-(layer, meta-path) seed constants (han_hip.h "Seeds")
+        self.step_seed_dev: torch.Tensor | None = None
+        self._fixed_seeds: dict = {}
 
     @classmethod
     def default_instance(cls):
@@ -182,9 +186,19 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         """models/gat.py:39-60: every node-attention layer of every meta-path -> M (N,P,64).
         coef_sink: a list that receives, per meta-path, the head-mean coefficients of the
         FIRST layer (models/gat.py:143-172), or None."""
-        def cfg(**kw):
+        def seeds(layer):
+            if not train:
+                return (0,) * len(graphs)
+            if self.step_seed_dev is None:
+                return tuple(rng.next_seed() for _ in graphs)
+            key = (layer, len(graphs))
+            if key not in self._fixed_seeds:
+                self._fixed_seeds[key] = tuple(rng.next_seed() for _ in graphs)
+            return self._fixed_seeds[key]
+
+        def cfg(layer=0, **kw):
             return {"train": train, "in_drop": float(ffd_drop), "coef_drop": float(attn_drop),
-                    "seeds": tuple(rng.next_seed() for _ in graphs) if train else (0,) * len(graphs),
+                    "seeds": seeds(layer), "seed_dev": self.step_seed_dev if train else None,
                     "act": act_code, "part": self.partition, "graphs_t": graphs_t,
                     "table_dtype": self.table_dtype, "plans_f": self.halo_plans[0],
                     "plans_b": self.halo_plans[1], **kw}
@@ -194,7 +208,7 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         for i in range(1, len(self.extra) + 1):                                 # gat.py:48-57
             g = lambda n: getattr(self, f"{n}_{i}", None)
             M = layers.NodeLevelAttention.apply(M, g("W"), g("a1"), g("b1"), g("a2"), g("b2"), g("c"),
-                                                g("Wr"), g("br"), None, tuple(graphs), cfg())
+                                                g("Wr"), g("br"), None, tuple(graphs), cfg(i))
         return M
 
     @_ClassOrInstance

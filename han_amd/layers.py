@@ -81,6 +81,7 @@ class NodeLevelAttention(torch.autograd.Function):
         M = torch.empty((N, P, D), dtype=torch.float32, device=W.device)
         row_offset = part.row_start if part is not None else 0
         saved = []
+        seed_dev = cfg.get("seed_dev")      # device seed word of a captured step (see han_hip.h "Seeds")
         multi = part is not None and part.active
         plans_f = cfg.get("plans_f") if multi else None      # per meta-path HaloPlan or None
         # all projections first, each table's all-gather started as soon as it exists:
@@ -90,7 +91,7 @@ class NodeLevelAttention(torch.autograd.Function):
             seed = int(cfg["seeds"][p])
             H, f1, f2 = ops.project_fwd(xs[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
                                         fts_drop=in_drop, seed=seed, row_offset=row_offset,
-                                        table_dtype=cfg.get("table_dtype", torch.float32))
+                                        table_dtype=cfg.get("table_dtype", torch.float32), seed_dev=seed_dev)
             plan = plans_f[p] if plans_f is not None else None
             handle = None
             if multi:      # halo rows only (HaloPlan) or the whole shard (all-gather)
@@ -100,11 +101,11 @@ class NodeLevelAttention(torch.autograd.Function):
                     raise NotImplementedError("return_coef is not provided under a node partition")
                 cfg["coef_sink"].append(ops.node_attn_coefs(
                     graphs[p], f1, f2, coef_drop=coef_drop, seed=seed, row_offset=row_offset,
-                    mean_heads=bool(cfg.get("coef_mean", False))))
+                    mean_heads=bool(cfg.get("coef_mean", False)), seed_dev=seed_dev))
             R = None
             if Wr is not None:   # same seed -> the same per-head input-dropout draws as for H
                 R, _, _ = ops.project_fwd(xs[p], Wr[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
-                                          fts_drop=0.0, seed=seed, row_offset=row_offset)
+                                          fts_drop=0.0, seed=seed, row_offset=row_offset, seed_dev=seed_dev)
                 R = R + br[p]
             proj.append((H, f1, f2, handle, R))
         for p in range(P):
@@ -115,7 +116,8 @@ class NodeLevelAttention(torch.autograd.Function):
                                       c[p], out=M[:, p, :], train=train, coef_drop=coef_drop,
                                       fts_drop=in_drop, seed=int(cfg["seeds"][p]), row_offset=row_offset,
                                       activation=cfg["act"],
-                                      table_gid=plan.gid if plan is not None else None, res=R)
+                                      table_gid=plan.gid if plan is not None else None, res=R,
+                                      seed_dev=seed_dev)
             if train:
                 saved.append((H, f1, f2) + sv + (R,))
         del proj
@@ -150,6 +152,7 @@ class NodeLevelAttention(torch.autograd.Function):
         db1, db2 = torch.empty_like(b1), torch.empty_like(b2)
         dc = torch.empty_like(c)
         multi = part is not None and part.active
+        seed_dev = cfg.get("seed_dev")
         plans_b = cfg.get("plans_b") if multi else None
         rows = []
         dres_in = []
@@ -164,10 +167,11 @@ class NodeLevelAttention(torch.autograd.Function):
                 seed_p = int(cfg["seeds"][p])
                 dbr[p] = dcp
                 dWr[p] = ops.project_bwd(xs[p], g32, K, FP, in_drop=ctx.in_drop, seed=seed_p,
-                                         row_offset=row_offset)
+                                         row_offset=row_offset, seed_dev=seed_dev)
                 if dXin is not None:
                     dres_in.append(ops.project_bwd_input(g32, Wr[p], K, FP, in_drop=ctx.in_drop,
-                                                         seed=seed_p, row_offset=row_offset))
+                                                         seed=seed_p, row_offset=row_offset,
+                                                         seed_dev=seed_dev))
             if multi:
                 plan = plans_b[p] if plans_b is not None else None
                 ex = plan.exchange_async if plan is not None else part.all_gather_rows_async
@@ -184,15 +188,16 @@ class NodeLevelAttention(torch.autograd.Function):
                                              stats_tab, H, f2, df1, a1[p], a2[p],
                                              coef_drop=ctx.coef_drop, fts_drop=ctx.in_drop, seed=seed,
                                              src_offset=row_offset, dst_offset=0,
-                                             table_gid=plan.gid if plan is not None else None)
+                                             table_gid=plan.gid if plan is not None else None,
+                                             seed_dev=seed_dev)
             rows[p] = None
             d1, d2, e1, e2 = ops.score_param_bwd(H, df1, df2, K=K, FP=FP)
             da1[p], da2[p], db1[p], db2[p] = d1, d2, e1, e2
             dW[p] = ops.project_bwd(xs[p], dH, K, FP, in_drop=ctx.in_drop, seed=seed,
-                                    row_offset=row_offset)
+                                    row_offset=row_offset, seed_dev=seed_dev)
             if dXin is not None:
                 ops.project_bwd_input(dH, W[p], K, FP, out=dXin[:, p, :], in_drop=ctx.in_drop,
-                                      seed=seed, row_offset=row_offset)
+                                      seed=seed, row_offset=row_offset, seed_dev=seed_dev)
                 if dres_in:
                     dXin[:, p, :] += dres_in[p]
         ctx.saved_per_p = None

@@ -25,6 +25,15 @@ _workspaces: dict = {}
 K2_TIMING: list | None = None
 
 
+def _dev_word(t):
+    """Device pointer of a 1-element int64 tensor (seed_dev / step_dev of the C ABI), or None."""
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int64 and t.numel() == 1):
+        raise ValueError("seed_dev / step_dev must be a 1-element int64 GPU tensor")
+    return t.data_ptr()
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -101,7 +110,7 @@ def _check_drop(p: float, name: str):
 
 # --------------------------------------------------------------------------- K1
 def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_offset=0,
-                table_dtype=torch.float32):
+                table_dtype=torch.float32, seed_dev=None):
     """utils/layers.py:18-24,31-32 for the K heads of one meta-path.
     X (N,F) fp32 or bf16 [row stride >= F]; W (F,D); a1,a2 (K,F'); b1,b2 (K,).
     H is stored in `table_dtype` (float32 or bfloat16; f1/f2 come from the stored rows).
@@ -136,11 +145,11 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
         X.data_ptr(), xcode, X.stride(0) if N > 1 else max(F, X.stride(0)), W.data_ptr(), a1.data_ptr(),
         a2.data_ptr(), b1.data_ptr(), b2.data_ptr(), H.data_ptr(), DTYPE_CODE[table_dtype],
         f1.data_ptr(), f2.data_ptr(), N, F, K, FP,
-        in_drop, fts_drop, int(seed), int(row_offset), _stream()), "han_project_fwd")
+        in_drop, fts_drop, int(seed), _dev_word(seed_dev), int(row_offset), _stream()), "han_project_fwd")
     return H, f1, f2
 
 
-def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0):
+def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0, seed_dev=None):
     """dW (F,D) = dropout_k(X)^T dH."""
     lib = _lib.load()
     _chk(X, "X", contiguous=False, dtype=X.dtype)
@@ -153,12 +162,12 @@ def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0):
     ws = _ws(nbytes, X.device, "proj")
     _lib.check(lib.han_project_bwd(
         X.data_ptr(), xcode, X.stride(0) if N > 1 else max(F, X.stride(0)), dH.data_ptr(), dW.data_ptr(),
-        ws.data_ptr(), ws.numel(), N, F, K, FP, _check_drop(in_drop, "in_drop"), int(seed),
+        ws.data_ptr(), ws.numel(), N, F, K, FP, _check_drop(in_drop, "in_drop"), int(seed), _dev_word(seed_dev),
         int(row_offset), _stream()), "han_project_bwd")
     return dW
 
 
-def project_bwd_input(dH, W, K, FP, out=None, in_drop=0.0, seed=0, row_offset=0):
+def project_bwd_input(dH, W, K, FP, out=None, in_drop=0.0, seed=0, row_offset=0, seed_dev=None):
     """dX (N,F) = sum_k mask_k/keep * (dH_k @ W_k^T): gradient w.r.t. the layer input
     (only layers >= 1 of a multi-layer stack need it).  `out`: optional (N,F) view
     with unit inner stride (e.g. dM_prev[:, p, :])."""
@@ -177,14 +186,15 @@ def project_bwd_input(dH, W, K, FP, out=None, in_drop=0.0, seed=0, row_offset=0)
             raise ValueError("out: rows must be contiguous")
     _lib.check(lib.han_project_bwd_input(
         dH.data_ptr(), W.data_ptr(), out.data_ptr(), out.stride(0) if N > 1 else max(F, out.stride(0)),
-        N, F, K, FP, _check_drop(in_drop, "in_drop"), int(seed), int(row_offset), _stream()),
+        N, F, K, FP, _check_drop(in_drop, "in_drop"), int(seed), _dev_word(seed_dev), int(row_offset), _stream()),
         "han_project_bwd_input")
     return out
 
 
 # --------------------------------------------------------------------------- K2
 def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=0.0,
-                  fts_drop=0.0, seed=0, row_offset=0, activation=ACT_ELU, table_gid=None, res=None):
+                  fts_drop=0.0, seed=0, row_offset=0, activation=ACT_ELU, table_gid=None, res=None,
+                  seed_dev=None):
     """utils/layers.py:26-35,46.  H_tab (NT,D): gather table of UNDROPPED projected
     rows indexed by graph.colidx (f2_j is recomputed from the gathered row with
     a2 (K,F'), b2 (K,)); with fts_drop > 0 bit 0 of each element is its keep bit
@@ -241,7 +251,7 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         a2.data_ptr(), b2.data_ptr(), c.data_ptr(), res.data_ptr() if res is not None else None,
         out.data_ptr(), out.stride(0) if N > 1 else D,
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
-        int(seed), int(row_offset), int(activation),
+        int(seed), _dev_word(seed_dev), int(row_offset), int(activation),
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_fwd")
     if timing is not None:
         ev1.record()
@@ -250,7 +260,7 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
 
 
 def node_attn_coefs(graph: CSRGraph, f1, f2, coef_drop=0.0, seed=0, row_offset=0, mean_heads=False,
-                    table_gid=None):
+                    table_gid=None, seed_dev=None):
     """The attention coefficients as data (attn_head(..., return_coef=True),
     utils/layers.py:27-30,43-44): (E,K) values in the CSR order of `graph`, or their
     head mean (E,) (models/gat.py:171-172).  f1 (N,K), f2 (NT,K) from project_fwd."""
@@ -272,7 +282,7 @@ def node_attn_coefs(graph: CSRGraph, f1, f2, coef_drop=0.0, seed=0, row_offset=0
         graph.values.data_ptr() if graph.values is not None else None,
         table_gid.data_ptr() if table_gid is not None else None, f1.data_ptr(), f2.data_ptr(),
         coef.data_ptr(), int(bool(mean_heads)), graph.n_rows, graph.nnz, K, FP, LEAKY_SLOPE,
-        _check_drop(coef_drop, "coef_drop"), int(seed), int(row_offset), _stream()), "han_node_attn_coefs")
+        _check_drop(coef_drop, "coef_drop"), int(seed), _dev_word(seed_dev), int(row_offset), _stream()), "han_node_attn_coefs")
     return coef
 
 
@@ -305,7 +315,7 @@ def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=
 
 
 def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=0.0,
-                       fts_drop=0.0, seed=0, src_offset=0, dst_offset=0, table_gid=None):
+                       fts_drop=0.0, seed=0, src_offset=0, dst_offset=0, table_gid=None, seed_dev=None):
     """Transposed-graph half of the K2 backward.  graph_t rows = local sources j,
     its colidx = destinations i indexing g_tab (NT,D) / stats_tab (NT,K,4).
     H (NS,D) undropped local rows (keep bits in bit 0 when fts_drop > 0),
@@ -339,7 +349,7 @@ def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, 
         stats_tab.data_ptr(), table_gid.data_ptr() if table_gid is not None else None, H.data_ptr(),
         tcode, f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
         NS, graph_t.nnz, K, FP, LEAKY_SLOPE, _check_drop(coef_drop, "coef_drop"), fts_drop,
-        int(seed), int(src_offset), int(dst_offset),
+        int(seed), _dev_word(seed_dev), int(src_offset), int(dst_offset),
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_bwd_cols")
     if timing is not None:
         ev1.record()
@@ -445,14 +455,16 @@ def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False):
 
 
 # ------------------------------------------------------------------- optimiser
-def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, l2_coef=0.0):
+def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, l2_coef=0.0, step_dev=None):
+    """lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the caller, or -- with step_dev (device step
+    count t) -- the base rate lr, the correction then being computed on the device."""
     lib = _lib.load()
     n = param.numel()
     for t, nme in ((param, "param"), (grad, "grad"), (m, "m"), (v, "v")):
         _chk(t, nme, (n,), device=param.device)
     _lib.check(lib.han_adam_step(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n,
                                  float(lr_t), float(beta1), float(beta2), float(eps),
-                                 float(l2_coef), _stream()), "han_adam_step")
+                                 float(l2_coef), _dev_word(step_dev), _stream()), "han_adam_step")
 
 
 def l2_half_sumsq(param):

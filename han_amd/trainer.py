@@ -23,11 +23,17 @@ from .graph import CSRGraph, as_graph
 class HANTrainer:
     def __init__(self, model: HeteGAT_multi, xs, graphs, labels, train_mask, val_mask=None,
                  lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
-                 part: NodePartition | None = None, patience=100, max_halo_fraction=0.6):
+                 part: NodePartition | None = None, patience=100, max_halo_fraction=0.6,
+                 use_graph=False):
         """xs: list of P (N_local,F) feature tensors (this rank's rows);
         graphs: list of P CSRGraph (or dense masks / CSR tuples) -- the GLOBAL graphs when `part` is given
         (they are sharded here), else the local==global graphs;
-        labels int32 (N_local,) class ids; masks uint8/bool (N_local,)."""
+        labels int32 (N_local,) class ids; masks uint8/bool (N_local,).
+        use_graph: capture one whole epoch (train step + eval forward, ~60 launches) into a
+        hipGraph on its second call and replay it afterwards -- for the launch-bound small
+        graphs (ACM / DBLP sizes).  The per-step dropout seed and Adam's step count then live
+        in a 2-word device state that the graph itself advances (han_hip.h "Seeds").
+        Single-process only."""
         if not model._built:
             raise RuntimeError("build the model first (model.build(...))")
         self.model = model
@@ -60,6 +66,20 @@ class HANTrainer:
         self.patience = patience
         self.vlss_mn, self.vacc_mx, self.curr_step = float("inf"), 0.0, 0
         self.best_state = None
+        self.use_graph = bool(use_graph)
+        self._capture = True          # tests switch this off to run the same device-state flow eagerly
+        self._graph = None
+        self._static_out = None
+        self._graph_calls = 0
+        if self.use_graph:
+            if self.part is not None:
+                raise NotImplementedError("use_graph is for single-process training")
+            # [seed word, Adam step count]; advanced by the first op of every epoch
+            self.step_state = torch.zeros(2, dtype=torch.int64, device=dev)
+            self.step_state[1] = self.opt.t
+            self._step_inc = torch.tensor([-0x61C8864680B583EB, 1], dtype=torch.int64, device=dev)  # 0x9E37...15
+            model.step_seed_dev = self.step_state[0:1]
+            self.opt.step_dev = self.step_state[1:2]
 
     def _global_count(self, mask):
         c = mask.sum().to(torch.float32).reshape(1)
@@ -96,10 +116,43 @@ class HANTrainer:
         return loss, acc
 
     def epoch(self):
-        """One reference epoch; returns device tensors (no host sync)."""
+        """One reference epoch; returns device tensors (no host sync).  With use_graph the
+        tensors are the graph's static outputs: the next epoch() overwrites them."""
+        if self.use_graph:
+            return self._epoch_graph()
         tl, ta = self.train_step()
         vl, va = self.eval_step()
         return tl, ta, vl, va
+
+    def _epoch_body(self):
+        self.step_state.add_(self._step_inc)
+        tl, ta = self.train_step()
+        vl, va = self.eval_step()
+        return tl, ta, vl, va
+
+    def _epoch_graph(self):
+        self._graph_calls += 1
+        if self._graph is not None:
+            self.opt.t += 1                      # the replayed han_adam_step reads the device count
+            self._graph.replay()
+            return self._static_out
+        if self._graph_calls == 1 or not self._capture or not self.model.flat.is_cuda:
+            # warm-up epoch (a real one) on a side stream: sizes every workspace, builds the
+            # cached transposes / row splits, lets autograd set up its buffers
+            if not self.model.flat.is_cuda:
+                return self._epoch_body()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                out = self._epoch_body()
+            torch.cuda.current_stream().wait_stream(side)
+            return out
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._static_out = self._epoch_body()   # recorded, not run (opt.t advanced by step())
+        self._graph = g
+        g.replay()
+        return self._static_out
 
     def reduce_metrics(self, *vals):
         """Sum per-rank partial losses/accuracies (they are already weighted by
@@ -137,6 +190,8 @@ class HANTrainer:
             raise ValueError("checkpoint was written for a different model shape")
         m.flat.copy_(ck["flat"])
         self.opt.load_state_dict(ck["opt"])
+        if self.use_graph:
+            self.step_state[1] = self.opt.t
 
     def restore_best(self):
         """saver.restore(sess, checkpt_file) (ex_acm3025.py:247)."""

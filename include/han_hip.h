@@ -41,6 +41,13 @@ extern "C" {
 #define HAN_DTYPE_F32  0
 #define HAN_DTYPE_BF16 1
 
+/* Seeds.  Every dropout site is a counter-based hash of (seed, stream, global ids), so a
+ * forward, its backward and every node partition regenerate identical masks.  `seed` is
+ * passed by value; `seed_dev` (device pointer, or NULL) exists for captured hipGraphs,
+ * whose kernel arguments are frozen at capture: when non-NULL the effective seed is
+ * splitmix64(seed + *seed_dev), read on the device at kernel start, and the host bumps
+ * that device word between replays.  Pass NULL for plain stream launches.            */
+
 int han_abi_version(void);
 const char *han_error_string(int code);
 
@@ -60,7 +67,7 @@ const char *han_error_string(int code);
 int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const float *W, const float *a1,
                     const float *a2, const float *b1, const float *b2, void *H,
                     int table_dtype, float *f1, float *f2, int64_t N, int F, int K, int FP,
-                    float in_drop, float fts_drop, uint64_t seed, int64_t row_offset,
+                    float in_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset,
                     void *stream);
 
 /* dW = Xk^T dH (per head dropout masks regenerated from the seed).
@@ -68,13 +75,13 @@ int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const float *W, con
 size_t han_project_bwd_workspace(int64_t N, int F, int K, int FP);
 int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const float *dH, float *dW,
                     void *workspace, size_t workspace_bytes, int64_t N, int F, int K,
-                    int FP, float in_drop, uint64_t seed, int64_t row_offset, void *stream);
+                    int FP, float in_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset, void *stream);
 
 /* dX = sum_k mask_k/keep * (dH_k W_k^T): gradient w.r.t. the layer INPUT, needed only
  * for layers >= 1 of a multi-layer stack (models/gat.py:48-57).  dH (N,D); W (F,D);
  * dX (N,F) with row stride ldo (a slice of the previous layer's dM).            */
 int han_project_bwd_input(const float *dH, const float *W, float *dX, int64_t ldo, int64_t N,
-                          int F, int K, int FP, float in_drop, uint64_t seed,
+                          int F, int K, int FP, float in_drop, uint64_t seed, const uint64_t *seed_dev,
                           int64_t row_offset, void *stream);
 
 /* Row splitting for skewed graphs (optional; pass NULL for none).  Rows (sources, in
@@ -120,7 +127,7 @@ int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float 
                       const float *a2, const float *b2, const float *c, const float *res,
                       float *out, int64_t out_stride, float *pre, float *lse, float *aggp,
                       float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
-                      float coef_drop, float fts_drop, uint64_t seed, int64_t row_offset,
+                      float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset,
                       int activation, const han_row_split_t *split, void *stream);
 
 /* The attention coefficients themselves (attn_head(..., return_coef=True),
@@ -132,7 +139,7 @@ int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float 
 int han_node_attn_coefs(const int64_t *rowptr, const int32_t *colidx, const float *edge_val,
                         const int32_t *table_gid, const float *f1, const float *f2, float *coef,
                         int mean_heads, int64_t N, int64_t E, int K, int FP, float slope,
-                        float coef_drop, uint64_t seed, int64_t row_offset, void *stream);
+                        float coef_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset, void *stream);
 
 /* Backward, step 1 (row-local): from dOut (N,D; row stride dout_stride) and
  * the saved pre/aggp/tsum/f1/lse compute
@@ -168,7 +175,7 @@ int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const f
                            int table_dtype, const float *f2,
                            const float *df1, const float *a1, const float *a2,
                            float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
-                           float coef_drop, float fts_drop, uint64_t seed,
+                           float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev,
                            int64_t src_offset, int64_t dst_offset,
                            const han_row_split_t *split, void *stream);
 
@@ -214,10 +221,12 @@ int han_classifier_loss(const float *Z, const float *Wc, const float *bc,
 /* ---- optimiser --------------------------------------------------------------
  * models/base_gattn.py:12-24: L2 on every trainable + tf.train.AdamOptimizer:
  *   g' = g + l2_coef * p;  m,v EMAs;  p -= lr_t * m / (sqrt(v) + eps)
- * with lr_t = lr * sqrt(1-beta2^t)/(1-beta1^t) computed by the caller.      */
+ * with lr_t = lr * sqrt(1-beta2^t)/(1-beta1^t) computed by the caller when step_dev is
+ * NULL; when step_dev (device int64, the step count t >= 1) is given, `lr_t` is the BASE
+ * rate lr and the bias correction is computed on the device (captured hipGraphs).  */
 int han_adam_step(float *param, const float *grad, float *m, float *v, int64_t n,
                   float lr_t, float beta1, float beta2, float eps, float l2_coef,
-                  void *stream);
+                  const int64_t *step_dev, void *stream);
 
 /* sum over all parameters of p^2/2 (the L2 term of the reported loss).
  * out[0] written.  workspace: 4096 floats.                                 */

@@ -19,6 +19,10 @@ D = 64
 SLOPE = 0.2
 
 
+def _eff(seed, seed_dev):
+    return rng_ref.resolve_seed(seed, None if seed_dev is None else int(seed_dev.item()) & ((1 << 64) - 1))
+
+
 def _f64(t):
     return t.detach().to(torch.float64)
 
@@ -28,8 +32,9 @@ def _rows_of(graph):
 
 
 def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_offset=0,
-                table_dtype=torch.float32):
+                table_dtype=torch.float32, seed_dev=None):
     assert table_dtype == torch.float32, "the CPU stand-in covers fp32 tables only"
+    seed = _eff(seed, seed_dev)
     N, F = X.shape
     K, FP = a1.shape
     x, w = _f64(X), _f64(W)
@@ -49,7 +54,8 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
     return H, f1.to(torch.float32), f2.to(torch.float32)
 
 
-def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0):
+def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0, seed_dev=None):
+    seed = _eff(seed, seed_dev)
     N, F = X.shape
     x, d = _f64(X), _f64(dH)
     if in_drop > 0:
@@ -61,7 +67,8 @@ def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0):
     return dW.to(torch.float32)
 
 
-def project_bwd_input(dH, W, K, FP, out=None, in_drop=0.0, seed=0, row_offset=0):
+def project_bwd_input(dH, W, K, FP, out=None, in_drop=0.0, seed=0, row_offset=0, seed_dev=None):
+    seed = _eff(seed, seed_dev)
     N, F = dH.shape[0], W.shape[0]
     d, w = _f64(dH), _f64(W)
     if in_drop > 0:
@@ -108,7 +115,8 @@ def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset,
 
 
 def node_attn_fwd(graph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=0.0, fts_drop=0.0,
-                  seed=0, row_offset=0, activation=1, table_gid=None, res=None):
+                  seed=0, row_offset=0, activation=1, table_gid=None, res=None, seed_dev=None):
+    seed = _eff(seed, seed_dev)
     K, FP = a2.shape
     N = graph.n_rows
     rows, cols, alpha, am, sg, lse, hd = _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop,
@@ -149,7 +157,8 @@ def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=1, K=8, FP=
 
 
 def node_attn_bwd_cols(graph_t, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=0.0, fts_drop=0.0,
-                       seed=0, src_offset=0, dst_offset=0, table_gid=None):
+                       seed=0, src_offset=0, dst_offset=0, table_gid=None, seed_dev=None):
+    seed = _eff(seed, seed_dev)
     K, FP = a1.shape
     NS = graph_t.n_rows
     src = _rows_of(graph_t)                       # local source j per transposed edge
@@ -221,7 +230,10 @@ def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False):
     return logits.detach().to(torch.float32), la, grads
 
 
-def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, l2_coef=0.0):
+def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, l2_coef=0.0, step_dev=None):
+    if step_dev is not None:
+        t = int(step_dev.item())
+        lr_t = float(np.float32(lr_t * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)))
     g = grad + l2_coef * param
     m.mul_(beta1).add_(g, alpha=1 - beta1)
     v.mul_(beta2).addcmul_(g, g, value=1 - beta2)

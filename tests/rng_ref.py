@@ -78,3 +78,19 @@ def fts_mask(seed, n, d, drop, row_offset=0):
     ds = np.arange(d)[None, :]
     x, y = han_rand64(seed, STREAM_FTS, rows, ds // 4)
     return (field(x, y, ds % 4) < _thr(drop)).astype(np.float64)
+
+
+def splitmix64(x):
+    m = (1 << 64) - 1
+    x = (int(x) + 0x9E3779B97F4A7C15) & m
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
+def resolve_seed(seed, seed_dev_value=None):
+    """han_resolve_seed: the effective seed of a launch that was given a device seed word."""
+    if seed_dev_value is None:
+        return int(seed)
+    return splitmix64((int(seed) + int(seed_dev_value)) & ((1 << 64) - 1))

@@ -628,6 +628,58 @@ def test_training_with_dropout_reduces_loss(dev):
     assert np.isfinite(float(tl))
 
 
+def test_captured_epoch_replay_matches_eager_and_oracle(dev):
+    """HANTrainer(use_graph=True): one whole epoch captured into a hipGraph and replayed.
+    (a) bitwise the same parameters as the identical device-state flow launched eagerly;
+    (b) every replay draws fresh dropout masks and the right Adam bias correction: the
+    oracle loop fed masks rebuilt from resolve_seed(fixed seed, device seed word) lands on
+    the same parameters."""
+    from han_amd import rng as hrng
+    from han_amd.trainer import HANTrainer
+    n, f, drop = 70, 12, 0.6
+    prob = make_problem(52, n, f, 2, 3, [0.08, 0.4])
+    x, graphs = gpu_inputs(prob, dev)
+    labels = _t(prob["labels"], dev, torch.int32)
+    tm = _t(prob["mask"].astype(np.uint8), dev, torch.uint8)
+    vm = _t((~prob["mask"]).astype(np.uint8), dev, torch.uint8)
+    trainers = []
+    for capture in (True, False):
+        model, bp = build_model(prob, dev)
+        tr = HANTrainer(model, [x, x], graphs, labels, tm, vm, attn_drop=drop, ffd_drop=drop, use_graph=True)
+        tr._capture = capture
+        trainers.append(tr)
+    bpo = {k: v.clone() for k, v in bp.items()}
+    st = ht.new_adam_state(bpo)
+    og = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]
+    keep = rng_ref.keep_prob32(drop)
+    for ep in range(1, 7):
+        outs = []
+        for tr in trainers:
+            if ep == 1:
+                hrng.manual_seed(77)         # both draw the same fixed seeds on their first call
+            outs.append([float(v) for v in tr.epoch()])
+        assert outs[0] == outs[1], (ep, outs)
+        word = int(trainers[0].step_state[0]) & ((1 << 64) - 1)
+        assert int(trainers[0].step_state[1]) == ep == trainers[0].opt.t
+        fixed = trainers[0].model._fixed_seeds[(0, 2)]
+        assert fixed == trainers[1].model._fixed_seeds[(0, 2)]
+        masks = []
+        for q in range(2):
+            sd = rng_ref.resolve_seed(fixed[q], word)
+            rp, ci = ho.bias_to_csr(prob["biases"][q])
+            masks.append({"seq": torch.tensor(rng_ref.seq_mask(sd, n, f, 8, drop)),
+                          "coef": torch.tensor(rng_ref.coef_mask_csr(sd, rp, ci, 8, drop)),
+                          "fts": torch.tensor(rng_ref.fts_mask(sd, n, 64, drop))})
+        _, vloss, vacc = ht.train_epoch([torch.tensor(prob["x"][0])] * 2, og, bpo, st,
+                                        torch.tensor(prob["onehot"]), torch.tensor(prob["mask"]),
+                                        torch.tensor(~prob["mask"]), keep=keep, masks=masks)
+        assert abs(outs[0][2] - vloss) < 5e-4, ep
+    assert trainers[0]._graph is not None and trainers[1]._graph is None
+    assert torch.equal(trainers[0].model.flat, trainers[1].model.flat)
+    for k in ht.PARAM_ORDER:
+        assert np.abs(getattr(trainers[0].model, k).detach().cpu().numpy() - bpo[k].numpy()).max() < 2e-4, k
+
+
 # ------------------------------------------------------------------- skewed graphs
 @pytest.mark.parametrize("drop", [0.0, 0.6])
 def test_row_split_for_long_rows_matches_oracle(dev, monkeypatch, drop):

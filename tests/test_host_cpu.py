@@ -196,6 +196,49 @@ def test_trainer_epochs_match_oracle_on_cpu_backend(cpu_ops):
     assert tr.early_stopping(2.0, 0.1) is True
 
 
+def test_device_step_state_mode_matches_oracle(cpu_ops):
+    """HANTrainer(use_graph=True) keeps the per-step seed word and Adam's step count in a
+    device state that every epoch advances (han_hip.h "Seeds"); on the CPU backend the same
+    flow runs eagerly.  Masks rebuilt from resolve_seed(fixed seed, state) + the oracle
+    loop must give the same parameters; two epochs must draw different masks."""
+    from han_amd import rng as hrng
+    from han_amd.trainer import HANTrainer
+    n, f, drop = 50, 8, 0.6
+    prob = make_problem(31, n, f, 2, 3, [0.1, 0.4])
+    model, bp = _cpu_model(prob)
+    x = torch.tensor(prob["x"][0], dtype=torch.float32)
+    hrng.manual_seed(123)
+    tr = HANTrainer(model, [x, x], _cpu_graphs(prob), torch.tensor(prob["labels"], dtype=torch.int32),
+                    torch.tensor(prob["mask"].astype(np.uint8)), torch.tensor((~prob["mask"]).astype(np.uint8)),
+                    attn_drop=drop, ffd_drop=drop, use_graph=True)
+    bpo = {k: v.clone() for k, v in bp.items()}
+    st = ht.new_adam_state(bpo)
+    og = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]
+    keep = rng_ref.keep_prob32(drop)
+    seen = []
+    for ep in range(1, 4):
+        tl, ta, vl, va = tr.epoch()
+        assert int(tr.step_state[1]) == ep == tr.opt.t
+        word = int(tr.step_state[0]) & ((1 << 64) - 1)
+        assert word == (ep * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)
+        fixed = model._fixed_seeds[(0, 2)]
+        masks = []
+        for q in range(2):
+            sd = rng_ref.resolve_seed(fixed[q], word)
+            rp, ci = ho.bias_to_csr(prob["biases"][q])
+            masks.append({"seq": torch.tensor(rng_ref.seq_mask(sd, n, f, 8, drop)),
+                          "coef": torch.tensor(rng_ref.coef_mask_csr(sd, rp, ci, 8, drop)),
+                          "fts": torch.tensor(rng_ref.fts_mask(sd, n, 64, drop))})
+        seen.append(masks[0]["fts"])
+        _, vloss, vacc = ht.train_epoch([torch.tensor(prob["x"][0])] * 2, og, bpo, st,
+                                        torch.tensor(prob["onehot"]), torch.tensor(prob["mask"]),
+                                        torch.tensor(~prob["mask"]), keep=keep, masks=masks)
+        assert abs(float(vl) - vloss) < 2e-5 and abs(float(va) - vacc) < 1e-6
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    for k in ht.PARAM_ORDER:
+        assert np.abs(getattr(model, k).detach().numpy() - bpo[k].numpy()).max() < 2e-5, k
+
+
 # -------------------------------------------------------------------- model surface
 def test_model_variables_and_initialisers():
     from han_amd.gat import HeteGAT_multi
