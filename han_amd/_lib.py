@@ -32,7 +32,8 @@ class HanRowSplit(ctypes.Structure):
 SIGNATURES = {
     "han_abi_version": (c_int, []),
     "han_error_string": (c_char_p, [c_int]),
-    "han_project_fwd": (c_int, [P, c_int, I64, P, P, P, P, P, P, c_int, P, P, I64, c_int, c_int, c_int,
+    "han_project_fwd_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
+    "han_project_fwd": (c_int, [P, c_int, I64, P, P, P, P, P, P, c_int, P, P, P, c_size_t, I64, c_int, c_int, c_int,
                                 c_float, c_float, c_uint64, P, I64, P]),
     "han_project_bwd_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
     "han_project_bwd": (c_int, [P, c_int, I64, P, P, P, c_size_t, I64, c_int, c_int, c_int, c_float,

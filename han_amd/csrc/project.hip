@@ -35,6 +35,11 @@ struct ProjFwdArgs {
     const uint64_t *seed_dev;
     float inv_keep_in;
     int64_t row_offset;
+    // split-F for short inputs (few row blocks, long reduction): blockIdx.y owns the
+    // features [y*f_chunk, (y+1)*f_chunk) and writes a raw partial tile to `partial`
+    // ([nsplit][N][64] fp32); project_finish_kernel sums them in a fixed order.
+    int f_chunk;        // multiple of BK; >= F when not split
+    float *partial;     // null when not split
 };
 
 __device__ __forceinline__ float load_x1(const void *X, int bf, int64_t idx) {
@@ -77,6 +82,8 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a_in
     const int lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * BMR;
+    const int k_begin = (int)blockIdx.y * a.f_chunk;
+    const int k_end = (k_begin + a.f_chunk < a.F) ? k_begin + a.f_chunk : a.F;
 
     f32x4 acc[MT][4][HPT];
 #pragma unroll
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a_in
                 const int r = idx >> 3, c4 = (idx & 7) * 4;
                 const int64_t row = row0 + r;
                 float4_t v = {0.f, 0.f, 0.f, 0.f};
-                if (row < a.N && k0 + c4 < a.F) v = load_x4(a.X, a.x_bf16, row * a.ldx + k0 + c4);
+                if (row < a.N && k0 + c4 < k_end) v = load_x4(a.X, a.x_bf16, row * a.ldx + k0 + c4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xr[4 * i + e] = v[e];
             }
@@ -106,19 +113,19 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a_in
                 const int idx = tid + 256 * i;
                 const int r = idx >> 5, cc = idx & 31;
                 const int64_t row = row0 + r;
-                xr[i] = (row < a.N && k0 + cc < a.F) ? load_x1(a.X, a.x_bf16, row * a.ldx + k0 + cc) : 0.f;
+                xr[i] = (row < a.N && k0 + cc < k_end) ? load_x1(a.X, a.x_bf16, row * a.ldx + k0 + cc) : 0.f;
             }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
             const int kw = k0 + (idx >> 4);
-            wr4[i] = kw < a.F ? *reinterpret_cast<const float4_t *>(a.W + (int64_t)kw * HAN_D + (idx & 15) * 4)
+            wr4[i] = kw < k_end ? *reinterpret_cast<const float4_t *>(a.W + (int64_t)kw * HAN_D + (idx & 15) * 4)
                               : (float4_t){0.f, 0.f, 0.f, 0.f};
         }
     };
-    load_tile(0);
-    for (int k0 = 0; k0 < a.F; k0 += BK) {
+    load_tile(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         __syncthreads();   // previous tile's fragment reads are done
         if (VEC) {
 #pragma unroll
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a_in
             *reinterpret_cast<float4_t *>(Ws + (idx >> 4) * WS_LD + (idx & 15) * 4) = wr4[i];
         }
         __syncthreads();
-        if (k0 + BK < a.F) load_tile(k0 + BK);   // in flight under the MFMAs
+        if (k0 + BK < k_end) load_tile(k0 + BK);   // in flight under the MFMAs
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             float bv[4];
@@ -185,6 +192,10 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a_in
 #pragma unroll
                 for (int hh = 1; hh < HPT; ++hh) v = (myhh == hh) ? acc[m][t][hh][r] : v;
                 if (DROP) v *= a.inv_keep_in;
+                if (a.partial) {   // split-F: raw partial sums, finished by project_finish_kernel
+                    if (row < a.N) a.partial[((int64_t)blockIdx.y * a.N + row) * HAN_D + 16 * t + l15] = v;
+                    continue;
+                }
                 uint32_t keepbit = 0, stamp = 0;
                 if (a.thr_fts < HAN_KEEP_ALL) {
                     // projected-row dropout (layers.py:31-32): the keep bit rides in the lowest
@@ -207,6 +218,40 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a_in
                 }
             }
         }
+    }
+}
+
+// split-F epilogue: H[row] = sum over the f-chunks (fixed order), then the same keep-bit
+// stamping / bf16 rounding as the unsplit kernel's epilogue.
+template <bool BF>
+__global__ __launch_bounds__(256) void project_finish_kernel(const ProjFwdArgs a_in, int nsplit) {
+    ProjFwdArgs a = a_in;
+    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
+    const int q = threadIdx.x & 15;
+    const int64_t grp0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t ngrp = (int64_t)gridDim.x * 16;
+    for (int64_t row = grp0; row < a.N; row += ngrp) {
+        float4_t v = {0.f, 0.f, 0.f, 0.f};
+        for (int sidx = 0; sidx < nsplit; ++sidx) {
+            const float4_t pv = *reinterpret_cast<const float4_t *>(a.partial + ((int64_t)sidx * a.N + row) * HAN_D + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += pv[e];
+        }
+        if (a.thr_fts < HAN_KEEP_ALL) {   // layers.py:31-32, d = 4q + e -> counter d/4 = q, field e
+            const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_FTS, (uint32_t)(row + a.row_offset),
+                                            (uint32_t)q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t keepbit = rn.field(e) < a.thr_fts ? 1u : 0u;
+                if (BF) {
+                    const uint32_t b = (han_f32_to_bf16_bits(v[e]) & ~1u) | keepbit;
+                    v[e] = __uint_as_float(b << 16);
+                } else {
+                    v[e] = __uint_as_float((__float_as_uint(v[e]) & ~1u) | keepbit);
+                }
+            }
+        }
+        han_store_row4<BF>(a.H, row, q, v);
     }
 }
 
@@ -505,11 +550,36 @@ void bwd_geometry(int64_t N, int F, int *ftiles, int64_t *rows_per_chunk, int64_
         default: { constexpr int FPC = 64; __VA_ARGS__; } break;  \
     }
 
+// Forward geometry.  Long inputs: 128-row blocks, one block per row tile.  Short inputs
+// (fewer row tiles than CUs, e.g. ACM: N = 3025, F = 1870): 64-row blocks and the
+// reduction over F split into chunks so that ~2 blocks per CU are in flight.
+static void fwd_geometry(int64_t N, int F, int *mt, int *nsplit, int *f_chunk) {
+    *mt = 2; *nsplit = 1; *f_chunk = ((F + BK - 1) / BK) * BK;
+    const int64_t tiles128 = (N + 127) / 128;
+    if (tiles128 >= 256 || F < 4 * BK) return;
+    *mt = 1;
+    const int64_t tiles64 = (N + 63) / 64;
+    int64_t want = (512 + tiles64 - 1) / tiles64;
+    const int64_t max_split = (F + 2 * BK - 1) / (2 * BK);      // at least two K-steps per chunk
+    if (want > max_split) want = max_split;
+    if (want <= 1) return;
+    const int chunk = (int)(((F + want - 1) / want + BK - 1) / BK) * BK;
+    *f_chunk = chunk;
+    *nsplit = (F + chunk - 1) / chunk;
+}
+
+extern "C" size_t han_project_fwd_workspace(int64_t N, int F, int K, int FP) {
+    (void)K; (void)FP;
+    int mt, nsplit, f_chunk;
+    fwd_geometry(N > 0 ? N : 0, F, &mt, &nsplit, &f_chunk);
+    return nsplit > 1 ? (size_t)nsplit * (size_t)N * HAN_D * sizeof(float) : 0;
+}
+
 extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const float *W, const float *a1,
                                const float *a2, const float *b1, const float *b2, void *H, int table_dtype,
-                               float *f1, float *f2, int64_t N, int F, int K, int FP, float in_drop,
-                               float fts_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset,
-                               void *stream) {
+                               float *f1, float *f2, void *workspace, size_t workspace_bytes, int64_t N, int F,
+                               int K, int FP, float in_drop, float fts_drop, uint64_t seed,
+                               const uint64_t *seed_dev, int64_t row_offset, void *stream) {
     if (!X || !W || !a1 || !a2 || !b1 || !b2 || !H || !f1 || !f2 || N < 0 || F <= 0 || ldx < F)
         return HAN_E_BADARG;
     if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
@@ -528,18 +598,33 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
     const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & (a.x_bf16 ? 7 : 15)) == 0);
-    constexpr int MT = 2;
-    const int grid = (int)((N + 64 * MT - 1) / (64 * MT));
-    HAN_DISPATCH_FP(FP, {
-        if (in_drop > 0.f) {
-            if (vec) project_fwd_kernel<FPC, true, MT, true><<<grid, 256, 0, st>>>(a);
-            else project_fwd_kernel<FPC, true, MT, false><<<grid, 256, 0, st>>>(a);
-        } else {
-            if (vec) project_fwd_kernel<FPC, false, MT, true><<<grid, 256, 0, st>>>(a);
-            else project_fwd_kernel<FPC, false, MT, false><<<grid, 256, 0, st>>>(a);
-        }
+    int mt, nsplit;
+    fwd_geometry(N, F, &mt, &nsplit, &a.f_chunk);
+    a.partial = nullptr;
+    if (nsplit > 1) {
+        if (!workspace || workspace_bytes < han_project_fwd_workspace(N, F, K, FP)) return HAN_E_WORKSPACE;
+        a.partial = (float *)workspace;
+    }
+    const dim3 grid((unsigned)((N + 64 * mt - 1) / (64 * mt)), (unsigned)nsplit);
+#define HAN_LAUNCH_FWD(MTC)                                                                  \
+    HAN_DISPATCH_FP(FP, {                                                                    \
+        if (in_drop > 0.f) {                                                                 \
+            if (vec) project_fwd_kernel<FPC, true, MTC, true><<<grid, 256, 0, st>>>(a);      \
+            else project_fwd_kernel<FPC, true, MTC, false><<<grid, 256, 0, st>>>(a);         \
+        } else {                                                                             \
+            if (vec) project_fwd_kernel<FPC, false, MTC, true><<<grid, 256, 0, st>>>(a);     \
+            else project_fwd_kernel<FPC, false, MTC, false><<<grid, 256, 0, st>>>(a);        \
+        }                                                                                    \
     })
+    if (mt == 2) { HAN_LAUNCH_FWD(2) } else { HAN_LAUNCH_FWD(1) }
+#undef HAN_LAUNCH_FWD
     HAN_CHECK_LAUNCH();
+    if (nsplit > 1) {
+        const int fgrid = han_grid_for(N, 16, 256 * 8);
+        if (a.h_bf16) project_finish_kernel<true><<<fgrid, 256, 0, st>>>(a, nsplit);
+        else project_finish_kernel<false><<<fgrid, 256, 0, st>>>(a, nsplit);
+        HAN_CHECK_LAUNCH();
+    }
     ScoreArgs s;
     s.H = H; s.a1 = a1; s.a2 = a2; s.b1 = b1; s.b2 = b2; s.f1 = f1; s.f2 = f2;
     s.N = N;

@@ -141,10 +141,13 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
     H = torch.empty((N, D), dtype=table_dtype, device=dev)
     f1 = torch.empty((N, K), dtype=torch.float32, device=dev)
     f2 = torch.empty((N, K), dtype=torch.float32, device=dev)
+    nbytes = lib.han_project_fwd_workspace(N, F, K, FP)      # > 0 only for short inputs (split-F)
+    ws = _ws(nbytes, dev, "projf") if nbytes else None
     _lib.check(lib.han_project_fwd(
         X.data_ptr(), xcode, X.stride(0) if N > 1 else max(F, X.stride(0)), W.data_ptr(), a1.data_ptr(),
         a2.data_ptr(), b1.data_ptr(), b2.data_ptr(), H.data_ptr(), DTYPE_CODE[table_dtype],
-        f1.data_ptr(), f2.data_ptr(), N, F, K, FP,
+        f1.data_ptr(), f2.data_ptr(), ws.data_ptr() if ws is not None else None,
+        ws.numel() if ws is not None else 0, N, F, K, FP,
         in_drop, fts_drop, int(seed), _dev_word(seed_dev), int(row_offset), _stream()), "han_project_fwd")
     return H, f1, f2
 

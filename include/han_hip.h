@@ -63,10 +63,15 @@ const char *han_error_string(int code);
  * so that K2 applies the mask while it gathers at no extra memory traffic.
  * X (N,F) ldx>=F (elements; x_dtype fp32 or bf16); W (F,D); a1,a2 (K,FP); b1,b2 (K);
  * H (N,D) in table_dtype (f1/f2 are taken from the rows as stored); f1,f2 (N,K).
- * in_drop == 0 -> no input dropout.  row_offset = global id of row 0 (RNG key). */
+ * in_drop == 0 -> no input dropout.  row_offset = global id of row 0 (RNG key).
+ * workspace: han_project_fwd_workspace() bytes (0 for long inputs; short inputs --
+ * fewer 128-row tiles than CUs -- split the reduction over F and sum partial tiles
+ * from it in a fixed order); may be NULL when that is 0.                            */
+size_t han_project_fwd_workspace(int64_t N, int F, int K, int FP);
 int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const float *W, const float *a1,
                     const float *a2, const float *b1, const float *b2, void *H,
-                    int table_dtype, float *f1, float *f2, int64_t N, int F, int K, int FP,
+                    int table_dtype, float *f1, float *f2, void *workspace,
+                    size_t workspace_bytes, int64_t N, int F, int K, int FP,
                     float in_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset,
                     void *stream);
 

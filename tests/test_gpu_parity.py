@@ -25,7 +25,7 @@ def _t(a, dev, dtype=torch.float32):
 
 
 # ----------------------------------------------------------------------------- K1
-@pytest.mark.parametrize("n,f", [(1, 5), (7, 13), (64, 32), (130, 77), (512, 334)])
+@pytest.mark.parametrize("n,f", [(1, 5), (7, 13), (64, 32), (130, 77), (512, 334), (3025, 1870), (700, 129)])
 def test_project_fwd_matches_oracle(dev, n, f):
     from han_amd import ops
     rng = np.random.default_rng(n * 1000 + f)
@@ -43,7 +43,7 @@ def test_project_fwd_matches_oracle(dev, n, f):
     assert np.abs(f2.cpu().numpy() - f2ref).max() < 1e-3 * max(1.0, np.abs(f2ref).max())
 
 
-@pytest.mark.parametrize("n,f", [(7, 13), (130, 77)])
+@pytest.mark.parametrize("n,f", [(7, 13), (130, 77), (130, 300)])      # (130, 300): split-F path
 def test_project_dropout_matches_hash_masks(dev, n, f):
     """Input dropout re-sampled per head (layers.py:18-19) and projected-row
     dropout (layers.py:31-32) with the masks regenerated in NumPy."""

@@ -28,9 +28,10 @@ def timeit(fn, reps=7):
 
 
 def main():
-    which = sys.argv[1:] or ["k1", "k3"]
+    which = [a for a in sys.argv[1:] if "=" not in a] or ["k1", "k3"]
+    kv = dict(a.split("=") for a in sys.argv[1:] if "=" in a)      # e.g. n=3025 f=1870 (ACM shape)
     dev = torch.device("cuda:0")
-    n, p, f = 1_000_000, 4, 256
+    n, p, f = int(kv.get("n", 1_000_000)), int(kv.get("p", 4)), int(kv.get("f", 256))
     gen = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: torch.randn(s, device=dev, generator=gen)
     if "k3" in which:
