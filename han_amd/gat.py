@@ -155,6 +155,14 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         return _param_shapes(self.P, self.F, self.K, self.FP, self.A, self.C, self.HC, self.extra,
                              self.residual)
 
+    def direct_grads(self, flag: bool = True):
+        """Let the backward kernels write each parameter's gradient straight into its slice of
+        `flat_grad` (overwrite, no autograd accumulation): valid when every parameter is used
+        once per step and `loss.backward()` starts at the loss, which is HANTrainer's step."""
+        for v in self._views.values():
+            v._han_direct_grad = bool(flag)
+        return self
+
     def zero_grad_flat(self):
         """Zero the flat gradient buffer and (re)bind every .grad to its slice."""
         self.flat_grad.zero_()

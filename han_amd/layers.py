@@ -41,6 +41,12 @@ def _act_code(activation):
     raise ValueError(f"unsupported activation {activation!r}")
 
 
+def _direct(p) -> bool:
+    """True when parameter `p` asks the backward kernels to write straight into p.grad
+    (set by HeteGAT_multi.direct_grads(True); see NodeLevelAttention.forward)."""
+    return bool(getattr(p, "_han_direct_grad", False)) and p.grad is not None
+
+
 class NodeLevelAttention(torch.autograd.Function):
     """K1 + K2 for every meta-path: (X_p, graph_p) -> M (N, P, D).
 
@@ -126,6 +132,11 @@ class NodeLevelAttention(torch.autograd.Function):
         ctx.saved_per_p = saved
         ctx.in_drop, ctx.coef_drop = in_drop, coef_drop
         ctx.has_res = Wr is not None
+        # direct-gradient mode (HANTrainer): every parameter carries a pre-bound .grad slice of
+        # the flat gradient buffer and is used once per step, so the backward kernels WRITE
+        # their results there and autograd gets None (no copy / accumulate launches)
+        plist = (W, a1, b1, a2, b2, c) + ((Wr, br) if Wr is not None else ())
+        ctx.direct = tuple(p.grad for p in plist) if all(_direct(p) for p in plist) else None
         ctx.save_for_backward(W, a1, b1, a2, b2, c, *((Wr,) if Wr is not None else ()))
         return M
 
@@ -144,13 +155,18 @@ class NodeLevelAttention(torch.autograd.Function):
         dM = dM.contiguous()
         graphs_t = cfg.get("graphs_t") or tuple(g.transpose() for g in graphs)
         row_offset = part.row_start if part is not None else 0
-        dW = torch.empty_like(W)
+        direct = ctx.direct
+        if direct is not None:
+            dW, da1, db1, da2, db2, dc = direct[:6]
+            dWr, dbr = (direct[6], direct[7]) if Wr is not None else (None, None)
+        else:
+            dW = torch.empty_like(W)
+            da1, da2 = torch.empty_like(a1), torch.empty_like(a2)
+            db1, db2 = torch.empty_like(b1), torch.empty_like(b2)
+            dc = torch.empty_like(c)
         dXin = None
         if ctx.xin_shape is not None and ctx.needs_input_grad[0]:
             dXin = torch.empty(ctx.xin_shape, dtype=torch.float32, device=W.device)
-        da1, da2 = torch.empty_like(a1), torch.empty_like(a2)
-        db1, db2 = torch.empty_like(b1), torch.empty_like(b2)
-        dc = torch.empty_like(c)
         multi = part is not None and part.active
         seed_dev = cfg.get("seed_dev")
         plans_b = cfg.get("plans_b") if multi else None
@@ -160,14 +176,13 @@ class NodeLevelAttention(torch.autograd.Function):
             H, f1, f2, pre, lse, aggp, tsum, R = ctx.saved_per_p[p]
             g, stats, df1, dcp = ops.node_attn_bwd_rows(dM[:, p, :], pre, aggp, tsum, f1, lse, c[p],
                                                         activation=cfg["act"], K=K, FP=FP,
-                                                        table_dtype=H.dtype, res=R)
-            dc[p] = dcp
+                                                        table_dtype=H.dtype, res=R, dc_out=dc[p])
             if Wr is not None:      # residual: d(pre) = g flows into Wr, br and the input
                 g32 = g if g.dtype == torch.float32 else g.to(torch.float32)
                 seed_p = int(cfg["seeds"][p])
                 dbr[p] = dcp
-                dWr[p] = ops.project_bwd(xs[p], g32, K, FP, in_drop=ctx.in_drop, seed=seed_p,
-                                         row_offset=row_offset, seed_dev=seed_dev)
+                ops.project_bwd(xs[p], g32, K, FP, in_drop=ctx.in_drop, seed=seed_p,
+                                row_offset=row_offset, seed_dev=seed_dev, out=dWr[p])
                 if dXin is not None:
                     dres_in.append(ops.project_bwd_input(g32, Wr[p], K, FP, in_drop=ctx.in_drop,
                                                          seed=seed_p, row_offset=row_offset,
@@ -191,16 +206,17 @@ class NodeLevelAttention(torch.autograd.Function):
                                              table_gid=plan.gid if plan is not None else None,
                                              seed_dev=seed_dev)
             rows[p] = None
-            d1, d2, e1, e2 = ops.score_param_bwd(H, df1, df2, K=K, FP=FP)
-            da1[p], da2[p], db1[p], db2[p] = d1, d2, e1, e2
-            dW[p] = ops.project_bwd(xs[p], dH, K, FP, in_drop=ctx.in_drop, seed=seed,
-                                    row_offset=row_offset, seed_dev=seed_dev)
+            ops.score_param_bwd(H, df1, df2, K=K, FP=FP, out=(da1[p], da2[p], db1[p], db2[p]))
+            ops.project_bwd(xs[p], dH, K, FP, in_drop=ctx.in_drop, seed=seed,
+                            row_offset=row_offset, seed_dev=seed_dev, out=dW[p])
             if dXin is not None:
                 ops.project_bwd_input(dH, W[p], K, FP, out=dXin[:, p, :], in_drop=ctx.in_drop,
                                       seed=seed, row_offset=row_offset, seed_dev=seed_dev)
                 if dres_in:
                     dXin[:, p, :] += dres_in[p]
         ctx.saved_per_p = None
+        if direct is not None:
+            return (dXin,) + (None,) * 11
         return dXin, dW, da1, db1, da2, db2, dc, dWr, dbr, None, None, None
 
 
@@ -211,6 +227,8 @@ class SemanticAttention(torch.autograd.Function):
     def forward(ctx, M, w_omega, b_omega, u_omega):
         M = M.contiguous()
         Z, beta = ops.sem_attn_fwd(M, w_omega, b_omega, u_omega)
+        plist = (w_omega, b_omega, u_omega)
+        ctx.direct = tuple(p.grad for p in plist) if all(_direct(p) for p in plist) else None
         ctx.save_for_backward(M, w_omega, b_omega, u_omega, beta)
         ctx.mark_non_differentiable(beta)
         return Z, beta
@@ -218,7 +236,9 @@ class SemanticAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dZ, _dbeta):
         M, w, b, u, beta = ctx.saved_tensors
-        dM, dw, db, du = ops.sem_attn_bwd(M, w, b, u, beta, dZ.contiguous())
+        dM, dw, db, du = ops.sem_attn_bwd(M, w, b, u, beta, dZ.contiguous(), out=ctx.direct)
+        if ctx.direct is not None:
+            return dM, None, None, None
         return dM, dw, db, du
 
 
@@ -230,17 +250,25 @@ class ClassifierLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Z, Wc, bc, labels, mask, row_weight):
         need = Z.requires_grad or Wc.requires_grad or bc.requires_grad
+        # direct-gradient mode additionally assumes the loss is the root of backward()
+        # (d loss = 1), which is how HANTrainer calls it
+        ctx.direct = need and _direct(Wc) and _direct(bc)
         logits, loss_acc, grads = ops.classifier_loss(Z.contiguous(), Wc, bc, labels, mask,
-                                                      row_weight, backward=need)
+                                                      row_weight, backward=need,
+                                                      grad_out=(Wc.grad, bc.grad) if ctx.direct else None)
         ctx.grads = grads
         loss, acc = loss_acc[0], loss_acc[1]
         ctx.mark_non_differentiable(acc, logits)
+        if ctx.direct:
+            return loss_acc[0:1].view(()), loss_acc[1:2].view(()), logits
         return loss.clone(), acc.clone(), logits
 
     @staticmethod
     def backward(ctx, dloss, _dacc, _dlogits):
         dZ, dWc, dbc = ctx.grads
         ctx.grads = None
+        if ctx.direct:
+            return dZ, None, None, None, None, None
         return dZ * dloss, dWc * dloss, dbc * dloss, None, None, None
 
 

@@ -34,6 +34,14 @@ def _dev_word(t):
     return t.data_ptr()
 
 
+def _out(t, name, shape, dev):
+    """A caller-provided destination (e.g. a slice of the flat gradient buffer) or a fresh tensor."""
+    if t is None:
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+    _chk(t, name, tuple(shape), device=dev)
+    return t
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -152,15 +160,15 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
     return H, f1, f2
 
 
-def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0, seed_dev=None):
-    """dW (F,D) = dropout_k(X)^T dH."""
+def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0, seed_dev=None, out=None):
+    """dW (F,D) = dropout_k(X)^T dH (written to `out` when given)."""
     lib = _lib.load()
     _chk(X, "X", contiguous=False, dtype=X.dtype)
     xcode = _dtype_code(X, "X")
     N, F = X.shape
     _chk(dH, "dH", (N, D), device=X.device)
     _check_heads(K, FP)
-    dW = torch.empty((F, D), dtype=torch.float32, device=X.device)
+    dW = _out(out, "out", (F, D), X.device)
     nbytes = lib.han_project_bwd_workspace(N, F, K, FP)
     ws = _ws(nbytes, X.device, "proj")
     _lib.check(lib.han_project_bwd(
@@ -290,9 +298,9 @@ def node_attn_coefs(graph: CSRGraph, f1, f2, coef_drop=0.0, seed=0, row_offset=0
 
 
 def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=8, FP=8,
-                       table_dtype=torch.float32, res=None):
+                       table_dtype=torch.float32, res=None, dc_out=None):
     """Row-local half of the K2 backward.  dOut (N,D) view (unit inner stride).
-    Returns g (N,D), stats (N,K,4), df1 (N,K), dc (D,)."""
+    Returns g (N,D), stats (N,K,4), df1 (N,K), dc (D,) [written to dc_out when given]."""
     lib = _lib.load()
     _check_heads(K, FP)
     N = pre.shape[0]
@@ -306,7 +314,7 @@ def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=
     g = torch.empty((N, D), dtype=table_dtype, device=dev)
     stats = torch.empty((N, K, 4), dtype=torch.float32, device=dev)
     df1 = torch.empty((N, K), dtype=torch.float32, device=dev)
-    dc = torch.empty((D,), dtype=torch.float32, device=dev)
+    dc = _out(dc_out, "dc_out", (D,), dev)
     ws = _ws(lib.han_node_attn_bwd_workspace(N, K, FP), dev, "rows")
     _lib.check(lib.han_node_attn_bwd_rows(
         dOut.data_ptr(), dOut.stride(0) if N > 1 else D, pre.data_ptr(), aggp.data_ptr(),
@@ -360,8 +368,8 @@ def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, 
     return dH, df2
 
 
-def score_param_bwd(H, df1, df2, K=8, FP=8):
-    """da1, da2 (K,F'), db1, db2 (K,)."""
+def score_param_bwd(H, df1, df2, K=8, FP=8, out=None):
+    """da1, da2 (K,F'), db1, db2 (K,) [written to the 4 tensors of `out` when given]."""
     lib = _lib.load()
     _check_heads(K, FP)
     N = H.shape[0]
@@ -370,10 +378,11 @@ def score_param_bwd(H, df1, df2, K=8, FP=8):
     tcode = _dtype_code(H, "H")
     _chk(df1, "df1", (N, K), device=dev)
     _chk(df2, "df2", (N, K), device=dev)
-    da1 = torch.empty((K, FP), dtype=torch.float32, device=dev)
-    da2 = torch.empty((K, FP), dtype=torch.float32, device=dev)
-    db1 = torch.empty((K,), dtype=torch.float32, device=dev)
-    db2 = torch.empty((K,), dtype=torch.float32, device=dev)
+    o = out if out is not None else (None,) * 4
+    da1 = _out(o[0], "da1", (K, FP), dev)
+    da2 = _out(o[1], "da2", (K, FP), dev)
+    db1 = _out(o[2], "db1", (K,), dev)
+    db2 = _out(o[3], "db2", (K,), dev)
     ws = _ws(lib.han_score_param_bwd_workspace(N, K, FP), dev, "score")
     _lib.check(lib.han_score_param_bwd(
         H.data_ptr(), tcode, df1.data_ptr(), df2.data_ptr(), da1.data_ptr(), da2.data_ptr(),
@@ -403,7 +412,8 @@ def sem_attn_fwd(M, w_omega, b_omega, u_omega):
     return Z, beta
 
 
-def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ):
+def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ, out=None):
+    """dM, dw, db, du [the last three written to the tensors of `out` when given]."""
     lib = _lib.load()
     N, P, _ = M.shape
     A = w_omega.shape[1]
@@ -412,9 +422,10 @@ def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ):
     _chk(beta, "beta", (N, P), device=dev)
     _chk(dZ, "dZ", (N, D), device=dev)
     dM = torch.empty_like(M)
-    dw = torch.empty_like(w_omega)
-    db = torch.empty_like(b_omega)
-    du = torch.empty_like(u_omega)
+    o = out if out is not None else (None,) * 3
+    dw = _out(o[0], "dw", tuple(w_omega.shape), dev)
+    db = _out(o[1], "db", tuple(b_omega.shape), dev)
+    du = _out(o[2], "du", tuple(u_omega.shape), dev)
     ws = _ws(lib.han_sem_attn_bwd_workspace(N, P, D, A), dev, "sem")
     _lib.check(lib.han_sem_attn_bwd(
         M.data_ptr(), w_omega.data_ptr(), b_omega.data_ptr(), u_omega.data_ptr(), beta.data_ptr(),
@@ -424,11 +435,11 @@ def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ):
 
 
 # ------------------------------------------------------------- classifier + loss
-def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False):
+def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False, grad_out=None):
     """models/gat.py:65-72 + models/base_gattn.py:41-48,61-69.
     Z (N,D); Wc (HC,D,C); bc (HC,C); labels int32 (N,); mask uint8 (N,).
     Returns logits (N,C), loss_acc (2,) [masked CE, masked accuracy] and, if
-    backward, (dZ, dWc, dbc)."""
+    backward, (dZ, dWc, dbc) [dWc, dbc written to the tensors of grad_out when given]."""
     lib = _lib.load()
     _chk(Z, "Z")
     N = Z.shape[0]
@@ -445,8 +456,9 @@ def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False):
     ptrs = (None, None, None)
     if backward:
         dZ = torch.empty((N, D), dtype=torch.float32, device=dev)
-        dWc = torch.empty_like(Wc)
-        dbc = torch.empty_like(bc)
+        go = grad_out if grad_out is not None else (None, None)
+        dWc = _out(go[0], "dWc", tuple(Wc.shape), dev)
+        dbc = _out(go[1], "dbc", tuple(bc.shape), dev)
         grads = (dZ, dWc, dbc)
         ptrs = (dZ.data_ptr(), dWc.data_ptr(), dbc.data_ptr())
     ws = _ws(lib.han_classifier_workspace(N, D, C, HC), dev, "cls")

@@ -37,6 +37,7 @@ class HANTrainer:
         if not model._built:
             raise RuntimeError("build the model first (model.build(...))")
         self.model = model
+        model.direct_grads(True)      # gradients land in model.flat_grad without copy/accumulate launches
         self.part = part if (part is not None and part.active) else None
         model.partition = self.part
         dev = model.flat.device

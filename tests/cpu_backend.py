@@ -54,7 +54,14 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
     return H, f1.to(torch.float32), f2.to(torch.float32)
 
 
-def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0, seed_dev=None):
+def _put(out, val):
+    if out is None:
+        return val
+    out.copy_(val)
+    return out
+
+
+def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0, seed_dev=None, out=None):
     seed = _eff(seed, seed_dev)
     N, F = X.shape
     x, d = _f64(X), _f64(dH)
@@ -64,7 +71,7 @@ def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0, seed_dev=None):
         dW = torch.cat([(x / keep * sm[k]).t() @ d[:, k * FP:(k + 1) * FP] for k in range(K)], 1)
     else:
         dW = x.t() @ d
-    return dW.to(torch.float32)
+    return _put(out, dW.to(torch.float32))
 
 
 def project_bwd_input(dH, W, K, FP, out=None, in_drop=0.0, seed=0, row_offset=0, seed_dev=None):
@@ -142,7 +149,7 @@ def node_attn_fwd(graph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=
 
 
 def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=1, K=8, FP=8,
-                       table_dtype=torch.float32, res=None):
+                       table_dtype=torch.float32, res=None, dc_out=None):
     N = pre.shape[0]
     p = _f64(pre)
     da = torch.where(p <= 0, torch.exp(p), torch.ones_like(p)) if activation == 1 else torch.ones_like(p)
@@ -153,7 +160,7 @@ def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=1, K=8, FP=
     df1 = dp - s * _f64(tsum)
     stats = torch.stack([_f64(f1), _f64(lse), s, torch.zeros_like(s)], dim=-1)
     return (g.to(torch.float32), stats.to(torch.float32).contiguous(), df1.to(torch.float32),
-            g.sum(0).to(torch.float32))
+            _put(dc_out, g.sum(0).to(torch.float32)))
 
 
 def node_attn_bwd_cols(graph_t, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=0.0, fts_drop=0.0,
@@ -188,12 +195,14 @@ def node_attn_bwd_cols(graph_t, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=
     return dH.reshape(NS, D).to(torch.float32), df2.to(torch.float32)
 
 
-def score_param_bwd(H, df1, df2, K=8, FP=8):
+def score_param_bwd(H, df1, df2, K=8, FP=8, out=None):
     hk = _f64(H).view(-1, K, FP)
     da1 = (_f64(df1)[:, :, None] * hk).sum(0)
     da2 = (_f64(df2)[:, :, None] * hk).sum(0)
-    return (da1.to(torch.float32), da2.to(torch.float32), _f64(df1).sum(0).to(torch.float32),
-            _f64(df2).sum(0).to(torch.float32))
+    res = (da1.to(torch.float32), da2.to(torch.float32), _f64(df1).sum(0).to(torch.float32),
+           _f64(df2).sum(0).to(torch.float32))
+    o = out if out is not None else (None,) * 4
+    return tuple(_put(o[i], res[i]) for i in range(4))
 
 
 def sem_attn_fwd(M, w_omega, b_omega, u_omega):
@@ -203,16 +212,18 @@ def sem_attn_fwd(M, w_omega, b_omega, u_omega):
     return (m * beta[..., None]).sum(1).to(torch.float32), beta.to(torch.float32)
 
 
-def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ):
+def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ, out=None):
     m, w, b, u = (_f64(t).requires_grad_(True) for t in (M, w_omega, b_omega, u_omega))
     with torch.enable_grad():
         v = torch.tanh(m @ w + b)
         z = (m * torch.softmax(v @ u, dim=-1)[..., None]).sum(1)
         (z * _f64(dZ)).sum().backward()
-    return tuple(t.grad.to(torch.float32) for t in (m, w, b, u))
+    res = tuple(t.grad.to(torch.float32) for t in (m, w, b, u))
+    o = out if out is not None else (None,) * 3
+    return (res[0],) + tuple(_put(o[i], res[i + 1]) for i in range(3))
 
 
-def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False):
+def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False, grad_out=None):
     z, w, b = (_f64(t).requires_grad_(True) for t in (Z, Wc, bc))
     hc = w.shape[0]
     with torch.enable_grad():
@@ -225,7 +236,9 @@ def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False):
         grads = None
         if backward:
             loss.backward()
-            grads = (z.grad.to(torch.float32), w.grad.to(torch.float32), b.grad.to(torch.float32))
+            go = grad_out if grad_out is not None else (None, None)
+            grads = (z.grad.to(torch.float32), _put(go[0], w.grad.to(torch.float32)),
+                     _put(go[1], b.grad.to(torch.float32)))
     la = torch.stack([loss.detach(), acc]).to(torch.float32)
     return logits.detach().to(torch.float32), la, grads
 
