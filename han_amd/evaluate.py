@@ -2,7 +2,14 @@
 ``jhyexp.py:20-86`` restated -- KNN (k=5) macro/micro-F1 over train fractions
 0.2/0.4/0.6/0.8 x 10 shuffles, and KMeans NMI/ARI x 10.  CPU, scikit-learn, as in
 the reference (``ex_acm3025.py:279-291``); it returns the scores instead of only
-printing them."""
+printing them.
+
+Random streams: the reference draws its shuffles from NumPy's GLOBAL legacy generator
+(``np.random.permutation``, jhyexp.py:33) and lets scikit-learn's KMeans fall back on the
+same global generator (``random_state=None``, jhyexp.py:62).  Here both use ONE
+``np.random.RandomState(seed)`` -- the same bit stream as ``np.random.seed(seed)`` followed
+by the reference's calls -- so a seeded run reproduces the reference's numbers exactly
+(tests/golden/jhyexp_ref.npz holds outputs of the reference's own functions)."""
 from __future__ import annotations
 
 import numpy as np
@@ -13,7 +20,7 @@ def my_KNN(x, y, k=5, split_list=(0.2, 0.4, 0.6, 0.8), time=10, shuffle=True, se
     Returns {split: (macro_f1, micro_f1)} averaged over `time` repetitions."""
     from sklearn.metrics import f1_score
     from sklearn.neighbors import KNeighborsClassifier
-    rng = np.random.default_rng(seed)
+    rng = np.random.RandomState(seed) if not isinstance(seed, np.random.RandomState) else seed
     x = np.squeeze(np.array(x))
     y = np.array(y)
     if y.ndim > 1:
@@ -46,9 +53,10 @@ def my_Kmeans(x, y, k=4, time=10, seed=None, verbose=True):
     if y.ndim > 1:
         y = np.argmax(y, axis=1)
     nmi, ari = [], []
+    rs = np.random.RandomState(seed) if not isinstance(seed, np.random.RandomState) else seed
+    est = KMeans(n_clusters=k, random_state=rs)          # ONE estimator, library defaults (jhyexp.py:62)
     for i in range(time):
-        est = KMeans(n_clusters=k, n_init=10, random_state=None if seed is None else seed + i)
-        pred = est.fit(x).predict(x)
+        pred = est.fit(x, y).predict(x)                  # re-fitted `time` times (jhyexp.py:67-68)
         nmi.append(normalized_mutual_info_score(y, pred))
         ari.append(adjusted_rand_score(y, pred))
     res = float(np.mean(nmi)), float(np.mean(ari))

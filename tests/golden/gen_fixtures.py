@@ -9,6 +9,10 @@
    is the one piece of the reference that runs in this container; its outputs
    pin ``oracle.han_oracle.adj_to_bias`` and ``han_amd.process.adj_to_bias``.
    The fixture holds inputs and outputs only, no reference source.
+3. jhyexp_ref.npz -- outputs of the reference's own ``jhyexp.my_KNN`` / ``my_Kmeans``
+   (``/root/reference/jhyexp.py:20-86``, imported from where it lies; scikit-learn only)
+   on seeded synthetic embeddings with ``np.random.seed(seed)``: pins
+   ``han_amd.evaluate``.  my_KNN only prints, so its stdout lines are parsed.
 2. han_forward_n64.npz -- inputs, parameters and float64 outputs of the oracle
    restatement of HeteGAT_multi.inference (PARITY UNPINNED vs TensorFlow: TF1 is
    not installable here; see oracle/han_oracle.py).
@@ -84,6 +88,43 @@ def gen_forward():
     print("han_forward_n64.npz: logits", lg.shape)
 
 
+def gen_jhyexp():
+    import contextlib
+    import importlib.util
+    import io
+    import re
+    spec = importlib.util.spec_from_file_location("jhyexp_ref", "/root/reference/jhyexp.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = np.random.default_rng(3)
+    n, c = 240, 4
+    y = rng.integers(0, c, n)
+    centers = rng.standard_normal((c, 16)) * 0.55
+    x = centers[y] + rng.standard_normal((n, 16))          # overlapping clusters: scores well below 1
+    out = {"x": x, "y": y, "seed": np.array(11), "time": np.array(3), "k_knn": np.array(5),
+           "k_means": np.array(c)}
+    np.random.seed(11)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ref.my_KNN(x, np.eye(c)[y], k=5, time=3)
+    rows = re.findall(r"split:([0-9.]+), k=5\) f1_macro: ([0-9.]+), f1_micro: ([0-9.]+)", buf.getvalue())
+    assert len(rows) == 4, buf.getvalue()
+    out["knn"] = np.array([[float(v) for v in r] for r in rows])        # (4,3): split, macro, micro (4 decimals)
+    np.random.seed(11)
+    with contextlib.redirect_stdout(io.StringIO()):
+        nmi, ari = ref.my_Kmeans(x, y, k=c, time=3, return_NMI=True)
+    out["kmeans"] = np.array([nmi, ari])
+    import sklearn
+    out["sklearn_version"] = np.array(sklearn.__version__)
+    np.savez_compressed(os.path.join(HERE, "jhyexp_ref.npz"), **out)
+    print("jhyexp_ref.npz:", out["knn"].tolist(), out["kmeans"].tolist())
+
+
 if __name__ == "__main__":
-    gen_adj_to_bias()
-    gen_forward()
+    which = sys.argv[1:] or ["adj", "forward", "jhyexp"]
+    if "adj" in which:
+        gen_adj_to_bias()
+    if "forward" in which:
+        gen_forward()
+    if "jhyexp" in which:
+        gen_jhyexp()

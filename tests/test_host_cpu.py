@@ -308,6 +308,26 @@ def test_base_gattn_loss_functions():
     assert abs(b - ho.masked_accuracy(logits, labels, mask)) < 1e-12
 
 
+def test_evaluate_matches_the_reference_jhyexp_outputs():
+    """tests/golden/jhyexp_ref.npz holds what the reference's OWN jhyexp.my_KNN / my_Kmeans
+    (jhyexp.py:20-86, imported by tests/golden/gen_fixtures.py) printed / returned on seeded
+    embeddings; han_amd.evaluate must reproduce them from the same seed (KNN to the 4
+    printed decimals, KMeans to rounding -- same scikit-learn, same random stream)."""
+    import os
+    import sklearn
+    from han_amd import evaluate
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "jhyexp_ref.npz"))
+    if str(z["sklearn_version"]) != sklearn.__version__:
+        pytest.skip("fixture was generated with another scikit-learn")
+    x, y, seed, time = z["x"], z["y"], int(z["seed"]), int(z["time"])
+    knn = evaluate.my_KNN(x, np.eye(int(z["k_means"]))[y], k=int(z["k_knn"]), time=time, seed=seed, verbose=False)
+    for split, macro, micro in z["knn"]:
+        got = knn[float(split)]
+        assert abs(got[0] - macro) < 6e-5 and abs(got[1] - micro) < 6e-5, (split, got, macro, micro)
+    nmi, ari = evaluate.my_Kmeans(x, y, k=int(z["k_means"]), time=time, seed=seed, verbose=False)
+    assert abs(nmi - z["kmeans"][0]) < 1e-12 and abs(ari - z["kmeans"][1]) < 1e-12
+
+
 def test_evaluate_and_checkpoint(cpu_ops, tmp_path):
     from han_amd import evaluate
     from han_amd.trainer import HANTrainer
