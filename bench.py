@@ -106,13 +106,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # HAN_SHARE_GPU=1 + HAN_DIST_BACKEND=gloo: rehearse the N-rank partition with all ranks on
+    # GPU 0 of a one-GPU box (collectives staged through the host; timings are meaningless)
+    if os.environ.get("HAN_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # HAN_FORCE_COLLECTIVES=1 rehearses the RCCL path on a 1-rank group (single-GPU box)
     use_dist = world > 1 or (os.environ.get("HAN_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("HAN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from han_amd import ops, rng, synth
     from han_amd.dist import NodePartition
@@ -134,6 +142,7 @@ def main():
         return part.local_rows(t).contiguous() if part is not None else t
 
     x_local = loc(wl["x"])
+    e_global = sum(g.nnz for g in wl["graphs"])
     trainer = HANTrainer(model, [x_local] * p, wl["graphs"], loc(wl["labels"]), loc(wl["train_mask"]),
                          loc(wl["val_mask"]), lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
                          part=part, use_graph=args.graph and part is None)
@@ -158,7 +167,7 @@ def main():
     dt = time.perf_counter() - t0
     timing, ops.K2_TIMING = ops.K2_TIMING or [], None
     if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tl, ta, vl, va = trainer.reduce_metrics(*last)
@@ -218,7 +227,7 @@ def main():
             "dtype": "f32" if args.table_dtype == "f32" else "bf16 storage / f32 accumulate",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: N={n} nodes, P={p} meta-paths, "
-                                   f"E={sum(g.nnz for g in trainer.graphs) if not use_dist else 'sharded'} "
+                                   f"E={e_global} "
                                    f"edges, F={wl['f']}, K=8 heads x F'=8, A=128, C={wl['c']}",
                        "parallelism": f"node-partition x{world}" if world > 1 else
                        ("single GPU, epoch replayed from a hipGraph" if trainer.use_graph else "single GPU"),
