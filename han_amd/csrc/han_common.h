@@ -135,6 +135,16 @@ __device__ __forceinline__ float han_elu(float x) { return x > 0.f ? x : (__expf
 template <typename T>
 __device__ __forceinline__ T han_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
 
+// sum over an aligned group of 16 lanes, every lane gets the total: two quad permutes and
+// two row rotations, all DPP modifiers of a v_add_f32 (no ds_bpermute, no LDS traffic)
+__device__ __forceinline__ float han_row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, true));  // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));  // row_ror:8
+    return v;
+}
+
 __device__ __forceinline__ float han_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

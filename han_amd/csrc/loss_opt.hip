@@ -12,7 +12,7 @@
 namespace {
 
 constexpr int MAXC = 16;
-constexpr int kClsBlocks = 512;
+constexpr int kClsBlocks = 2048;   // 8 waves per SIMD: the per-row chain (load, dot, reduce, exp) is latency-bound
 
 // slab row: [64*C] dWm | [C] dbm | loss | acc
 struct ClsArgs {
@@ -56,19 +56,24 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
         for (int t = 0; t < 4; ++t) dW[t][c] = 0.f;
     }
     float loss_acc = 0.f, acc_acc = 0.f;
+    // this lane's 4 rows of the averaged classifier matrix and the biases, in registers
+    float wq[4][CM], bq[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        bq[c] = c < C ? bm[c] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wq[t][c] = c < C ? Wm[(4 * q + t) * C + c] : 0.f;
+    }
     for (int64_t row = grp0; row < a.N; row += ngrp) {
         const float4_t z4 = *reinterpret_cast<const float4_t *>(a.Z + row * 64 + 4 * q);
         float lg[CM];
 #pragma unroll
         for (int c = 0; c < CM; ++c) {
             float s = 0.f;
-            if (c < C) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) s += z4[t] * Wm[(4 * q + t) * C + c];
-            }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
-            lg[c] = c < C ? s + bm[c] : HAN_NEG_BIG;
+            for (int t = 0; t < 4; ++t) s += z4[t] * wq[t][c];
+            s = han_row16_sum(s);
+            lg[c] = c < C ? s + bq[c] : HAN_NEG_BIG;
         }
         if (q < C) {
             float v = 0.f;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
                 if (c < C) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        dz[t] += dl[c] * Wm[(4 * q + t) * C + c];
+                        dz[t] += dl[c] * wq[t][c];
                         dW[t][c] += z4[t] * dl[c];
                     }
                     if (q == 0) dbacc[c] += dl[c];

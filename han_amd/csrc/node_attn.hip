@@ -110,7 +110,7 @@ struct RowState {
 };
 
 // Gather U neighbour rows and fold them into the running softmax state.
-template <int FP, bool TRAIN, int U, bool BF>
+template <int FP, bool TRAIN, int U, bool BF, bool VAL>
 __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U], const float (&w)[U],
                                               const bool (&valid)[U], const float f1h, const uint32_t gi, const int q, const int head,
                                               const float4_t &a24, const float b2h, const bool drop_c,
@@ -124,8 +124,10 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         // layers.py:24,26; sp_attn_head: adj_ij*f1_i + adj_ij*f2_j (:95-96), w == 1 when binary
-        const float x = w[u] * (f1h + (head_sum<FP>(dot4(hv[u], a24)) + b2h));
-        sg[u] = (x > 0.f ? 1.f : a.slope) * w[u];
+        float x = f1h + (head_sum<FP>(dot4(hv[u], a24)) + b2h);
+        if (VAL) x *= w[u];
+        sg[u] = x > 0.f ? 1.f : a.slope;
+        if (VAL) sg[u] *= w[u];
         ev[u] = valid[u] ? han_lrelu(x, a.slope) : HAN_NEG_BIG;          // layers.py:27
         mc = fmaxf(mc, ev[u]);
     }
@@ -212,7 +214,7 @@ __device__ __forceinline__ void write_row(const FwdArgs &a, const int64_t row, c
 // applies the two dropouts.
 // (Forcing more waves per SIMD on the TRAIN instantiation with __launch_bounds__ spills
 // 92-180 B/lane to scratch and measured 5-25 % slower in both cache and HBM regimes.)
-template <int FP, bool TRAIN, int RPW, int U, bool BF>
+template <int FP, bool TRAIN, int RPW, int U, bool BF, bool VAL>
 __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) {
     FwdArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) 
             for (int64_t base = s; base < e; base += 64) {
                 const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
                 const int mycol = a.colidx[base + (lane < cnt ? lane : cnt - 1)];
-                const float myval = a.edge_val ? a.edge_val[base + (lane < cnt ? lane : cnt - 1)] : 1.f;
+                const float myval = VAL ? a.edge_val[base + (lane < cnt ? lane : cnt - 1)] : 1.f;
                 for (int it = 0; it * 4 < cnt; it += U) {
                     int j[U];
                     float w[U];
@@ -255,9 +257,9 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) 
                         const int idx = (it + u) * 4 + g;
                         valid[u] = idx < cnt;
                         j[u] = __shfl(mycol, idx & 63, 64);
-                        w[u] = a.edge_val ? __shfl(myval, idx & 63, 64) : 1.f;
+                        w[u] = VAL ? __shfl(myval, idx & 63, 64) : 1.f;
                     }
-                    consume_edges<FP, TRAIN, U, BF>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
+                    consume_edges<FP, TRAIN, U, BF, VAL>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
                 }
             }
             st.merge(16);
@@ -280,9 +282,9 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) 
                 for (int u = 0; u < U; ++u) {
                     valid[u] = it + u < len;
                     j[u] = (len > 0) ? a.colidx[valid[u] ? s + it + u : s] : 0;
-                    w[u] = (a.edge_val && len > 0) ? a.edge_val[valid[u] ? s + it + u : s] : 1.f;
+                    w[u] = (VAL && len > 0) ? a.edge_val[valid[u] ? s + it + u : s] : 1.f;
                 }
-                consume_edges<FP, TRAIN, U, BF>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
+                consume_edges<FP, TRAIN, U, BF, VAL>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
             }
         }
 
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) 
 }
 
 // Split rows, step 1: one wave per chunk of a long row -> un-normalised partial state.
-template <int FP, bool TRAIN, int U, bool BF>
+template <int FP, bool TRAIN, int U, bool BF, bool VAL>
 __global__ __launch_bounds__(256) void node_attn_fwd_chunk_kernel(const FwdArgs a_in) {
     FwdArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_chunk_kernel(const FwdArgs 
         for (int64_t base = s; base < e; base += 64) {
             const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
             const int mycol = a.colidx[base + (lane < cnt ? lane : cnt - 1)];
-            const float myval = a.edge_val ? a.edge_val[base + (lane < cnt ? lane : cnt - 1)] : 1.f;
+            const float myval = VAL ? a.edge_val[base + (lane < cnt ? lane : cnt - 1)] : 1.f;
             for (int it = 0; it * 4 < cnt; it += U) {
                 int j[U];
                 float w[U];
@@ -324,9 +326,9 @@ __global__ __launch_bounds__(256) void node_attn_fwd_chunk_kernel(const FwdArgs 
                     const int idx = (it + u) * 4 + g;
                     valid[u] = idx < cnt;
                     j[u] = __shfl(mycol, idx & 63, 64);
-                    w[u] = a.edge_val ? __shfl(myval, idx & 63, 64) : 1.f;
+                    w[u] = VAL ? __shfl(myval, idx & 63, 64) : 1.f;
                 }
-                consume_edges<FP, TRAIN, U, BF>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
+                consume_edges<FP, TRAIN, U, BF, VAL>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
             }
         }
         st.merge(16);
@@ -503,7 +505,7 @@ __device__ __forceinline__ SrcRow load_src(const BwdColsArgs &a, const int64_t s
 }
 
 // gather U destinations i of source j and accumulate  acc += alpha~ g_i,  df += dl_ij
-template <int FP, int U, bool BF>
+template <int FP, int U, bool BF, bool VAL>
 __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)[U], const float (&ew)[U],
                                             const bool (&valid)[U], const SrcRow &sr, const int q, const int head, const bool drop_c,
                                             float (&acc)[4], float &dfacc) {
@@ -517,8 +519,10 @@ __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const float x = ew[u] * (st[u][0] + sr.f2h);
-        const float sg = (x > 0.f ? 1.f : a.slope) * ew[u];
+        float x = st[u][0] + sr.f2h;
+        if (VAL) x *= ew[u];
+        float sg = x > 0.f ? 1.f : a.slope;
+        if (VAL) sg *= ew[u];
         float alpha = __expf(han_lrelu(x, a.slope) - st[u][1]);
         alpha = valid[u] ? alpha : 0.f;
         float am = 1.f;
@@ -549,7 +553,7 @@ __device__ __forceinline__ void write_src(const BwdColsArgs &a, const int64_t sr
     if ((4 * q) % FP == 0) a.df2[src * K + head] = dfacc;
 }
 
-template <int FP, int RPW, int U, bool BF>
+template <int FP, int RPW, int U, bool BF, bool VAL>
 __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsArgs a_in) {
     BwdColsArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
@@ -594,9 +598,9 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
                 const int64_t k = (RPW == 1) ? (it + u) * 4 + g : it + u;
                 valid[u] = k < len;
                 i[u] = len > 0 ? a.rowidx[valid[u] ? s + k : s] : 0;
-                ew[u] = (a.edge_val && len > 0) ? a.edge_val[valid[u] ? s + k : s] : 1.f;
+                ew[u] = (VAL && len > 0) ? a.edge_val[valid[u] ? s + k : s] : 1.f;
             }
-            bwd_consume<FP, U, BF>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+            bwd_consume<FP, U, BF, VAL>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
         }
         if (RPW == 1) {
 #pragma unroll
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
 }
 
 // Split source rows: one wave per chunk -> partial sums; one 16-lane group per long row adds them.
-template <int FP, int U, bool BF>
+template <int FP, int U, bool BF, bool VAL>
 __global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsArgs a_in) {
     BwdColsArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
@@ -637,9 +641,9 @@ __global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsA
                 const int64_t k = (it + u) * 4 + g;
                 valid[u] = k < len;
                 i[u] = a.rowidx[valid[u] ? s + k : s];
-                ew[u] = a.edge_val ? a.edge_val[valid[u] ? s + k : s] : 1.f;
+                ew[u] = VAL ? a.edge_val[valid[u] ? s + k : s] : 1.f;
             }
-            bwd_consume<FP, U, BF>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+            bwd_consume<FP, U, BF, VAL>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
         }
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
@@ -843,38 +847,50 @@ bool split_ok(const han_row_split_t *sp) {
 // bf16 tables are built for the reference head shape only (8 heads x 8)
 #define HAN_BF16_OK(FPV) ((FPV) == 8)
 
-template <int FPC, bool BF>
-static void launch_fwd(const FwdArgs &a, bool train, bool low, bool has_split, hipStream_t st) {
+template <int FPC, bool BF, bool VAL>
+static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split, hipStream_t st) {
     if (low) {
         const int grid = attn_grid((a.N + 3) / 4);
-        if (train) node_attn_fwd_kernel<FPC, true, 4, 2, BF><<<grid, 256, 0, st>>>(a);
-        else node_attn_fwd_kernel<FPC, false, 4, 2, BF><<<grid, 256, 0, st>>>(a);
+        if (train) node_attn_fwd_kernel<FPC, true, 4, 2, BF, VAL><<<grid, 256, 0, st>>>(a);
+        else node_attn_fwd_kernel<FPC, false, 4, 2, BF, VAL><<<grid, 256, 0, st>>>(a);
     } else {
         const int grid = attn_grid(a.N);
-        if (train) node_attn_fwd_kernel<FPC, true, 1, 4, BF><<<grid, 256, 0, st>>>(a);
-        else node_attn_fwd_kernel<FPC, false, 1, 4, BF><<<grid, 256, 0, st>>>(a);
+        if (train) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL><<<grid, 256, 0, st>>>(a);
+        else node_attn_fwd_kernel<FPC, false, 1, 4, BF, VAL><<<grid, 256, 0, st>>>(a);
     }
     if (has_split) {
         const int cgrid = attn_grid(a.n_chunks);
         const int fgrid = (int)((a.n_long + 15) / 16);
         if (train) {
-            node_attn_fwd_chunk_kernel<FPC, true, 4, BF><<<cgrid, 256, 0, st>>>(a);
+            node_attn_fwd_chunk_kernel<FPC, true, 4, BF, VAL><<<cgrid, 256, 0, st>>>(a);
             node_attn_fwd_finish_kernel<FPC, true><<<fgrid, 256, 0, st>>>(a);
         } else {
-            node_attn_fwd_chunk_kernel<FPC, false, 4, BF><<<cgrid, 256, 0, st>>>(a);
+            node_attn_fwd_chunk_kernel<FPC, false, 4, BF, VAL><<<cgrid, 256, 0, st>>>(a);
             node_attn_fwd_finish_kernel<FPC, false><<<fgrid, 256, 0, st>>>(a);
         }
     }
 }
 
-template <int FPC, bool BF>
-static void launch_bwd_cols(const BwdColsArgs &a, bool low, bool has_split, hipStream_t st) {
-    if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
-    else node_attn_bwd_cols_kernel<FPC, 1, 4, BF><<<attn_grid(a.NS), 256, 0, st>>>(a);
+template <int FPC, bool BF, bool VAL>
+static void launch_bwd_cols_v(const BwdColsArgs &a, bool low, bool has_split, hipStream_t st) {
+    if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF, VAL><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
+    else node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL><<<attn_grid(a.NS), 256, 0, st>>>(a);
     if (has_split) {
-        node_attn_bwd_chunk_kernel<FPC, 4, BF><<<attn_grid(a.n_chunks), 256, 0, st>>>(a);
+        node_attn_bwd_chunk_kernel<FPC, 4, BF, VAL><<<attn_grid(a.n_chunks), 256, 0, st>>>(a);
         node_attn_bwd_finish_kernel<FPC, BF><<<(int)((a.n_long + 15) / 16), 256, 0, st>>>(a);
     }
+}
+
+// the binary-adjacency instantiation (every shipped config) carries no edge-value registers
+template <int FPC, bool BF>
+static void launch_fwd(const FwdArgs &a, bool train, bool low, bool has_split, hipStream_t st) {
+    if (a.edge_val) launch_fwd_v<FPC, BF, true>(a, train, low, has_split, st);
+    else launch_fwd_v<FPC, BF, false>(a, train, low, has_split, st);
+}
+template <int FPC, bool BF>
+static void launch_bwd_cols(const BwdColsArgs &a, bool low, bool has_split, hipStream_t st) {
+    if (a.edge_val) launch_bwd_cols_v<FPC, BF, true>(a, low, has_split, st);
+    else launch_bwd_cols_v<FPC, BF, false>(a, low, has_split, st);
 }
 
 static bool dtype_ok(int dt, int FP) {

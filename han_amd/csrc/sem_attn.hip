@@ -91,8 +91,7 @@ __global__ __launch_bounds__(256) void sem_attn_fwd_kernel(const float *__restri
                 float s = 0.f;
 #pragma unroll
                 for (int t = 0; t < TA; ++t) s += fast_tanh(acc[t][reg] + bcol[t]) * ucol[t];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+                s = han_row16_sum(s);
                 if (l15 == 0) sc[buf * ROWS + 16 * w + 4 * l4 + reg] = s;
             }
         }
@@ -198,8 +197,7 @@ __global__ __launch_bounds__(256) void sem_attn_fwd_wave_kernel(const float *__r
             float s = 0.f;
 #pragma unroll
             for (int t = 0; t < TA; ++t) s += fast_tanh(acc[t][reg] + bcol[t]) * ucol[t];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+            s = han_row16_sum(s);
             sc[reg] = s;     // every lane of the group holds the score of row 4*l4 + reg
         }
 #pragma unroll
@@ -457,8 +455,7 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_kernel(const float *__r
                 const float4_t mv = *reinterpret_cast<const float4_t *>(M + rc * 64 + 4 * l15);
                 const float4_t dz = *reinterpret_cast<const float4_t *>(dZ + (rc / P) * 64 + 4 * l15);
                 float d = mv[0] * dz[0] + mv[1] * dz[1] + mv[2] * dz[2] + mv[3] * dz[3];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) d += __shfl_xor(d, o, 64);
+                d = han_row16_sum(d);
                 dbt[rr] = d;
                 bt[rr] = ok ? beta[rc] : 0.f;        // beta is (N,P) flat == row index
             }
