@@ -257,11 +257,12 @@ class ClassifierLoss(torch.autograd.Function):
                                                       row_weight, backward=need,
                                                       grad_out=(Wc.grad, bc.grad) if ctx.direct else None)
         ctx.grads = grads
-        loss, acc = loss_acc[0], loss_acc[1]
+        if ctx.direct:      # views of the kernel's output pair: no clone launches
+            loss, acc = loss_acc[0:1].view(()), loss_acc[1:2].view(())
+        else:
+            loss, acc = loss_acc[0].clone(), loss_acc[1].clone()
         ctx.mark_non_differentiable(acc, logits)
-        if ctx.direct:
-            return loss_acc[0:1].view(()), loss_acc[1:2].view(()), logits
-        return loss.clone(), acc.clone(), logits
+        return loss, acc, logits
 
     @staticmethod
     def backward(ctx, dloss, _dacc, _dlogits):
