@@ -906,7 +906,8 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
                                  float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev,
                                  int64_t row_offset, int activation, const han_row_split_t *split,
                                  void *stream) {
-    if (!rowptr || !colidx || !H || !f1 || !a2 || !b2 || !c || !out || N < 0 || E < 0 || out_stride < HAN_D)
+    if (N == 0) return 0;   // nothing to do; row pointers of empty tensors may be null
+    if (!rowptr || (!colidx && E > 0) || !H || !f1 || !a2 || !b2 || !c || !out || N < 0 || E < 0 || out_stride < HAN_D)
         return HAN_E_BADARG;
     if (!split_ok(split)) return HAN_E_BADARG;
     if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
@@ -992,7 +993,7 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
                                       float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev,
                                       int64_t src_offset, int64_t dst_offset, const han_row_split_t *split,
                                       void *stream) {
-    if (!colptr || !rowidx || !g || !stats || !H || !f2 || !df1 || !a1 || !a2 || !dH || !df2 || NS < 0 || E < 0)
+    if (!colptr || (!rowidx && E > 0) || !g || !stats || !H || !f2 || !df1 || !a1 || !a2 || !dH || !df2 || NS < 0 || E < 0)
         return HAN_E_BADARG;
     if (!split_ok(split)) return HAN_E_BADARG;
     if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
@@ -1062,7 +1063,7 @@ extern "C" int han_node_attn_coefs(const int64_t *rowptr, const int32_t *colidx,
                                    int mean_heads, int64_t N, int64_t E, int K, int FP, float slope,
                                    float coef_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset,
                                    void *stream) {
-    if (!rowptr || !colidx || !f1 || !f2 || !coef || N < 0 || E < 0) return HAN_E_BADARG;
+    if (!rowptr || (!colidx && E > 0) || !f1 || !f2 || (!coef && E > 0) || N < 0 || E < 0) return HAN_E_BADARG;
     if (!fp_supported(K, FP)) return HAN_E_UNSUPPORTED;
     if (coef_drop < 0.f || coef_drop >= 1.f) return HAN_E_BADARG;
     if (N == 0 || E == 0) return 0;

@@ -580,6 +580,7 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
                                float *f1, float *f2, void *workspace, size_t workspace_bytes, int64_t N, int F,
                                int K, int FP, float in_drop, float fts_drop, uint64_t seed,
                                const uint64_t *seed_dev, int64_t row_offset, void *stream) {
+    if (N == 0) return 0;   // nothing to do; row pointers of empty tensors may be null
     if (!X || !W || !a1 || !a2 || !b1 || !b2 || !H || !f1 || !f2 || N < 0 || F <= 0 || ldx < F)
         return HAN_E_BADARG;
     if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;

@@ -653,6 +653,7 @@ int launch_bwd(const float *M, const float *w, const float *b, const float *u, c
 extern "C" int han_sem_attn_fwd(const float *M, const float *w_omega, const float *b_omega,
                                 const float *u_omega, float *Z, float *beta, int64_t N, int P, int D, int A,
                                 void *stream) {
+    if (N == 0) return 0;   // nothing to do; row pointers of empty tensors may be null
     if (!M || !w_omega || !b_omega || !u_omega || !Z || !beta || N < 0 || P <= 0) return HAN_E_BADARG;
     if (D != HAN_D || P > 64 || (A != 64 && A != 128)) return HAN_E_UNSUPPORTED;
     if (N == 0) return 0;

@@ -29,7 +29,9 @@ extern "C" {
 
 #define HAN_ABI_VERSION 1
 
-#define HAN_E_BADARG   (-1)   /* null pointer, negative size, inconsistent shape */
+#define HAN_E_BADARG   (-1)   /* null pointer, negative size, inconsistent shape.  The forward
+                              * entry points return 0 at once for N == 0 (empty tensors may
+                              * carry null data pointers)                                  */
 #define HAN_E_UNSUPPORTED (-2) /* shape outside this build (e.g. K*FP != 64)     */
 #define HAN_E_WORKSPACE (-3)  /* workspace too small                            */
 

@@ -322,7 +322,8 @@ def test_dropout_statistics(dev):
 
 
 # ----------------------------------------------------------------------------- K3
-@pytest.mark.parametrize("n,p,a", [(1, 1, 128), (50, 2, 128), (333, 4, 128), (40, 3, 64)])
+@pytest.mark.parametrize("n,p,a", [(1, 1, 128), (50, 2, 128), (333, 4, 128), (40, 3, 64), (2000, 8, 128),
+                                   (77, 5, 64), (3, 16, 128), (1000, 4, 64), (5000, 1, 64), (129, 64, 128)])
 def test_semantic_attention_fwd_bwd(dev, n, p, a):
     from han_amd import ops
     rng = np.random.default_rng(n + p)
@@ -341,6 +342,28 @@ def test_semantic_attention_fwd_bwd(dev, n, p, a):
     assert rel_err(dw.cpu().numpy(), tw.grad.numpy()) < GTOL
     assert rel_err(db.cpu().numpy(), tb.grad.numpy()) < GTOL
     assert rel_err(du.cpu().numpy(), tu.grad.numpy()) < GTOL
+
+
+def test_empty_inputs_are_noops(dev):
+    """N == 0 / E == 0 through the C ABI: every entry point returns without launching
+    (edge case of SURVEY.md section 4: empty inputs)."""
+    from han_amd import ops
+    from han_amd.graph import CSRGraph
+    z = lambda *s: torch.zeros(s, device=dev)
+    H, f1, f2 = ops.project_fwd(z(0, 7), z(7, 64), z(8, 8), z(8, 8), z(8), z(8))
+    assert H.shape == (0, 64) and f1.shape == (0, 8)
+    g = CSRGraph(torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev), 0)
+    out, _ = ops.node_attn_fwd(g, H, f1, z(8, 8), z(8), z(64))
+    assert out.shape == (0, 64)
+    Z, beta = ops.sem_attn_fwd(z(0, 2, 64), z(64, 128), z(128), z(128))
+    assert Z.shape == (0, 64) and beta.shape == (0, 2)
+    # a graph whose rows are all empty: out = act(c) for every row (no neighbour, no softmax)
+    g2 = CSRGraph(torch.zeros(6, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev), 5)
+    c = torch.linspace(-1, 1, 64, device=dev)
+    H5, f15, _ = ops.project_fwd(z(5, 7) + 1, z(7, 64) + 0.1, z(8, 8), z(8, 8), z(8), z(8))
+    out2, _ = ops.node_attn_fwd(g2, H5, f15, z(8, 8), z(8), c)
+    ref = torch.where(c > 0, c, torch.expm1(c))
+    assert torch.allclose(out2, ref[None].expand(5, -1), atol=1e-6)
 
 
 # ----------------------------------------------------------- classifier / loss / opt
