@@ -588,6 +588,48 @@ def test_return_coef_and_hetegat_class(dev):
         assert np.abs(coef_list[q].to_dense().cpu().numpy() - np.mean(per_head, axis=0)).max() < 1e-5
 
 
+def test_c_abi_demo_program(dev):
+    """examples/c_abi_demo.cpp drives K1 -> K2 -> K3 through include/han_hip.h from plain
+    C++ (hipMalloc + a HIP stream; no Python, no torch types at the boundary).  Its inputs
+    come from a fixed LCG, rebuilt here; its printed outputs must match the oracle."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import __graft_entry__ as entry
+    exe = entry.build_c_demo()          # no-op when the binary is newer than its source and the library
+    n, f, deg = 300, 24, 5
+    r = subprocess.run([exe, str(n), str(f), str(deg)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    vals = np.array([float(t) for t in r.stdout.split()])
+    assert vals.size == 2 * n * 64
+    M, Z = vals[:n * 64].reshape(n, 64), vals[n * 64:].reshape(n, 64)
+    state = np.uint32(12345)
+
+    def lcg(count, scale=1.0):
+        nonlocal state
+        out = np.empty(count, dtype=np.float32)
+        s = int(state)
+        for i in range(count):
+            s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+            out[i] = np.float32(s >> 8) * np.float32(1.0 / 16777216.0) - np.float32(0.5)
+        state = np.uint32(s)
+        return (out * np.float32(scale)).astype(np.float64)
+
+    X = lcg(n * f).reshape(n, f)
+    W = lcg(f * 64, 0.5).reshape(f, 64)
+    a1, a2 = lcg(64).reshape(8, 8), lcg(64).reshape(8, 8)
+    b1, b2, c = lcg(8, 0.2), lcg(8, 0.2), lcg(64, 0.2)
+    wo, bo, uo = lcg(64 * 128, 0.4).reshape(64, 128), lcg(128, 0.2), lcg(128)
+    rp = np.arange(0, n * deg + 1, deg)
+    ci = ((np.arange(n)[:, None] + np.arange(deg)[None, :]) % n).reshape(-1)
+    heads = [{"W": W[:, 8 * k:8 * k + 8], "a1": a1[k], "a2": a2[k], "b1": b1[k], "b2": b2[k],
+              "c": c[8 * k:8 * k + 8]} for k in range(8)]
+    ref = np.concatenate([ho.sp_attn_head(X[None], h, rp, ci)[0] for h in heads], axis=1)
+    assert np.abs(M - ref).max() < TOL
+    Zr = ho.simple_att_layer(ref[:, None, :], wo, bo, uo)
+    assert np.abs(Z - Zr).max() < TOL
+
+
 def test_errors_are_loud(dev):
     from han_amd import ops
     from han_amd.graph import CSRGraph
