@@ -146,6 +146,11 @@ def main():
     trainer = HANTrainer(model, [x_local] * p, wl["graphs"], loc(wl["labels"]), loc(wl["train_mask"]),
                          loc(wl["val_mask"]), lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
                          part=part, use_graph=args.graph and part is None)
+    exchange = None
+    if part is not None:
+        plans = model.halo_plans[0]
+        exchange = ["halo %.1f%% of the remote rows" % (100.0 * pl.halo_fraction) if pl is not None else "all-gather"
+                    for pl in plans]
     if part is not None:
         wl["graphs"] = None          # the global graphs are no longer needed on this rank
     torch.cuda.synchronize()
@@ -231,6 +236,7 @@ def main():
                                    f"edges, F={wl['f']}, K=8 heads x F'=8, A=128, C={wl['c']}",
                        "parallelism": f"node-partition x{world}" if world > 1 else
                        ("single GPU, epoch replayed from a hipGraph" if trainer.use_graph else "single GPU"),
+                       **({"exchange": exchange} if exchange is not None else {}),
                        "dropout": "0.6/0.6 (train step)", "optimizer": "TF-form Adam lr 0.005, L2 0.001"},
             "final": {"train_loss": round(tl, 5), "train_acc": round(ta, 5),
                       "val_loss": round(vl, 5), "val_acc": round(va, 5)},

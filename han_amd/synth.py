@@ -31,6 +31,22 @@ def random_regular_graph(n: int, deg: int, seed: int, device="cpu", symmetric=Fa
     return graph
 
 
+def banded_graph(n: int, deg: int, window: int, seed: int, device="cpu") -> CSRGraph:
+    """Graph with locality (what a partitioner leaves of a real meta-path graph): row i has
+    its self-loop + (deg-1) neighbours uniform in [i-window, i+window] (wrapping).  Under a
+    contiguous node partition only ~2*window remote rows per rank are referenced, so the
+    halo exchange (dist.HaloPlan) replaces the all-gather."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    off = torch.randint(-window, window + 1, (n, deg - 1), generator=g, device=device, dtype=torch.int32)
+    ids = torch.arange(n, device=device, dtype=torch.int32)[:, None]
+    cols = torch.cat([ids, torch.remainder(ids + off, n)], dim=1)
+    del off
+    cols = torch.sort(cols, dim=1).values
+    rowptr = torch.arange(0, n * deg + 1, deg, device=device, dtype=torch.int64)
+    return CSRGraph(rowptr, cols.reshape(-1).contiguous(), n, validate=False)
+
+
 def powerlaw_graph(n: int, nnz: int, alpha: float, seed: int, device="cpu") -> CSRGraph:
     """Skewed variant: row degrees ~ Zipf-like with exponent alpha, scaled to
     about `nnz` edges, every row keeps its self-loop; neighbours uniform."""
@@ -71,6 +87,8 @@ CONFIGS = {
                                                   ("bernoulli", 12924399 / 4057 ** 2)]),
     "syn-1m": dict(n=1_000_000, f=256, c=4, graphs=[("regular", 50)] * 4),
     "syn-1m-skew": dict(n=1_000_000, f=256, c=4, graphs=[("powerlaw", 50_000_000, 2.1)] * 4),
+    # locality: neighbours within +-20000 of the row id -> halo exchange under a node partition
+    "syn-1m-local": dict(n=1_000_000, f=256, c=4, graphs=[("banded", 50, 20_000)] * 4),
     "syn-100k": dict(n=100_000, f=256, c=4, graphs=[("regular", 50)] * 4),
     # BASELINE.json configs[4] (meant for 8 GPUs; fits one 288 GB MI355X with bf16 tables)
     "syn-10m": dict(n=10_000_000, f=256, c=4, graphs=[("regular", 50)] * 8),
@@ -84,6 +102,8 @@ def make_graph(spec, n, seed, device):
         return random_regular_graph(n, spec[1], seed, device)
     if kind == "powerlaw":
         return powerlaw_graph(n, spec[1], spec[2], seed, device)
+    if kind == "banded":
+        return banded_graph(n, spec[1], min(spec[2], max(n // 4, 1)), seed, device)
     if kind == "bernoulli":
         return bernoulli_graph(n, spec[1], seed, device)
     raise ValueError(kind)
