@@ -43,6 +43,21 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 constexpr int ROWS = 64;   // rows per block iteration (4 waves x 16)
 
+// A node with P = 8 / 16 meta-paths spans 2 / 4 of the 16-lane groups of a wave tile (4 rows
+// each): reductions over its rows finish with one / two cross-group exchanges.
+template <int P>
+__device__ __forceinline__ float node_xsum(float v) {
+    if (P >= 8) v += __shfl_xor(v, 16, 64);
+    if (P >= 16) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+template <int P>
+__device__ __forceinline__ float node_xmax(float v) {
+    if (P >= 8) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if (P >= 16) v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
 template <int CA>
 __global__ __launch_bounds__(256) void sem_attn_fwd_kernel(const float *__restrict__ M, const float *Wg,
                                                            const float *bw, const float *uw, float *Z,
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(256) void sem_attn_fwd_kernel(const float *__restri
     }
 }
 
-// Forward for P in {1,2,4} (P divides 4): the P rows of a node sit in ONE 16-lane
+// Forward for P in {1,2,4} (P divides 4; P = 8, 16 span 2 / 4 groups, see node_xsum): the P rows of a node sit in ONE 16-lane
 // group of the accumulator layout (rows 4*l4 .. 4*l4+3), so the per-node softmax
 // and the weighted sum finish inside the group -- no LDS exchange, no barrier; each
 // wave streams its own 16-row tiles.
@@ -200,29 +215,57 @@ __global__ __launch_bounds__(256) void sem_attn_fwd_wave_kernel(const float *__r
             s = han_row16_sum(s);
             sc[reg] = s;     // every lane of the group holds the score of row 4*l4 + reg
         }
+        if constexpr (P <= 4) {
 #pragma unroll
-        for (int k = 0; k < 4 / P; ++k) {       // the 4/P nodes of this lane group
-            const int64_t row = r0 + 4 * l4 + k * P;
-            if (row < R) {
-                float mx = sc[k * P];
+            for (int k = 0; k < 4 / P; ++k) {       // the 4/P nodes of this lane group
+                const int64_t row = r0 + 4 * l4 + k * P;
+                if (row < R) {
+                    float mx = sc[k * P];
 #pragma unroll
-                for (int p = 1; p < P; ++p) mx = fmaxf(mx, sc[k * P + p]);
-                float e[P], den = 0.f;
+                    for (int p = 1; p < P; ++p) mx = fmaxf(mx, sc[k * P + p]);
+                    float e[P], den = 0.f;
 #pragma unroll
-                for (int p = 0; p < P; ++p) { e[p] = __expf(sc[k * P + p] - mx); den += e[p]; }
-                const float inv = 1.f / den;
-                float4_t z = {0.f, 0.f, 0.f, 0.f};
-                float mine = 0.f;
+                    for (int p = 0; p < P; ++p) { e[p] = __expf(sc[k * P + p] - mx); den += e[p]; }
+                    const float inv = 1.f / den;
+                    float4_t z = {0.f, 0.f, 0.f, 0.f};
+                    float mine = 0.f;
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const float bp = e[p] * inv;
+                    for (int p = 0; p < P; ++p) {
+                        const float bp = e[p] * inv;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) z[c] += bp * mz[k * P + p][c];
-                    mine = (l15 == p) ? bp : mine;
+                        for (int c = 0; c < 4; ++c) z[c] += bp * mz[k * P + p][c];
+                        mine = (l15 == p) ? bp : mine;
+                    }
+                    const int64_t node = row / P;
+                    *reinterpret_cast<float4_t *>(Z + node * 64 + 4 * l15) = z;
+                    if (l15 < P) beta[node * P + l15] = mine;
                 }
-                const int64_t node = row / P;
-                *reinterpret_cast<float4_t *>(Z + node * 64 + 4 * l15) = z;
-                if (l15 < P) beta[node * P + l15] = mine;
+            }
+        } else {
+            // P = 8 / 16: the node's rows sit in P/4 lane groups; every lane takes part in the
+            // cross-group exchanges (nodes are aligned, so a valid node never mixes with padding)
+            float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+            mx = node_xmax<P>(mx);
+            float e[4], den = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) { e[reg] = __expf(sc[reg] - mx); den += e[reg]; }
+            den = node_xsum<P>(den);
+            const float inv = 1.f / den;
+            float4_t z = {0.f, 0.f, 0.f, 0.f};
+            float mine = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float bp = e[reg] * inv;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) z[c] += bp * mz[reg][c];
+                mine = (l15 == reg) ? bp : mine;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) z[c] = node_xsum<P>(z[c]);
+            const int64_t row = r0 + 4 * l4;
+            if (row < R) {
+                if (l4 % (P / 4) == 0) *reinterpret_cast<float4_t *>(Z + (row / P) * 64 + 4 * l15) = z;
+                if (l15 < 4) beta[row + l15] = mine;      // beta is (N,P) flat == row index
             }
         }
     }
@@ -401,8 +444,9 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_kernel(const float *__restri
     for (int i = threadIdx.x; i < 64 * A + 2 * A; i += 256) out[i] = red[i];
 }
 
-// Backward for P in {1,2,4}: as in the forward, the P rows of a node share one
-// 16-lane group of the accumulator layout, so d beta / d s are formed inside the
+// Backward for P in {1,2,4,8,16}: as in the forward, the P rows of a node share one
+// 16-lane group of the accumulator layout (P/4 groups for P = 8, 16: one or two cross-group
+// exchanges), so d beta / d s are formed inside the
 // group (lane = 4 features of a row) and the whole tile flow G1 -> dpre -> G3 -> G2
 // is wave-local: no block barrier in the main loop.
 template <int CA, int P>
@@ -459,13 +503,22 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_kernel(const float *__r
                 dbt[rr] = d;
                 bt[rr] = ok ? beta[rc] : 0.f;        // beta is (N,P) flat == row index
             }
+            if constexpr (P <= 4) {
 #pragma unroll
-            for (int k = 0; k < 4 / P; ++k) {
+                for (int k = 0; k < 4 / P; ++k) {
+                    float S = 0.f;
+#pragma unroll
+                    for (int p2 = 0; p2 < P; ++p2) S += bt[k * P + p2] * dbt[k * P + p2];
+#pragma unroll
+                    for (int p2 = 0; p2 < P; ++p2) ds[k * P + p2] = bt[k * P + p2] * (dbt[k * P + p2] - S);
+                }
+            } else {     // P = 8 / 16: the node's rows span P/4 lane groups
                 float S = 0.f;
 #pragma unroll
-                for (int p2 = 0; p2 < P; ++p2) S += bt[k * P + p2] * dbt[k * P + p2];
+                for (int rr = 0; rr < 4; ++rr) S += bt[rr] * dbt[rr];
+                S = node_xsum<P>(S);
 #pragma unroll
-                for (int p2 = 0; p2 < P; ++p2) ds[k * P + p2] = bt[k * P + p2] * (dbt[k * P + p2] - S);
+                for (int rr = 0; rr < 4; ++rr) ds[rr] = bt[rr] * (dbt[rr] - S);
             }
         }
         // ---- G1: pre = M_tile . Womega
@@ -592,13 +645,15 @@ int launch_fwd(const float *M, const float *w, const float *b, const float *u, f
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    if (P == 1 || P == 2 || P == 4) {
+    if (P == 1 || P == 2 || P == 4 || P == 8 || P == 16) {
         constexpr bool WREG = false;
         const size_t wlds = WREG ? 0 : (size_t)64 * (64 * CA + 16) * sizeof(float);
         const int grid = han_grid_for(N * P, 64, 256 * (WREG ? 2 : 4));
         if (P == 1) sem_attn_fwd_wave_kernel<CA, 1, WREG><<<grid, 256, wlds, st>>>(M, w, b, u, Z, beta, N);
         else if (P == 2) sem_attn_fwd_wave_kernel<CA, 2, WREG><<<grid, 256, wlds, st>>>(M, w, b, u, Z, beta, N);
-        else sem_attn_fwd_wave_kernel<CA, 4, WREG><<<grid, 256, wlds, st>>>(M, w, b, u, Z, beta, N);
+        else if (P == 4) sem_attn_fwd_wave_kernel<CA, 4, WREG><<<grid, 256, wlds, st>>>(M, w, b, u, Z, beta, N);
+        else if (P == 8) sem_attn_fwd_wave_kernel<CA, 8, WREG><<<grid, 256, wlds, st>>>(M, w, b, u, Z, beta, N);
+        else sem_attn_fwd_wave_kernel<CA, 16, WREG><<<grid, 256, wlds, st>>>(M, w, b, u, Z, beta, N);
         HAN_CHECK_LAUNCH();
         return 0;
     }
@@ -616,26 +671,23 @@ int launch_bwd(const float *M, const float *w, const float *b, const float *u, c
     hipError_t e = hipFuncSetAttribute((const void *)sem_attn_bwd_kernel<CA>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    if (P == 1 || P == 2 || P == 4) {
+    if (P == 1 || P == 2 || P == 4 || P == 8 || P == 16) {
         const int grid = han_grid_for(N > 0 ? N * P : 1, 64, kSemBwdBlocks);
         *grid_out = grid;
         hipError_t e2 = hipSuccess;
-        if (P == 1) {
-            e2 = hipFuncSetAttribute((const void *)sem_attn_bwd_wave_kernel<CA, 1>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e2 == hipSuccess)
-                sem_attn_bwd_wave_kernel<CA, 1><<<grid, 256, lds, st>>>(M, w, b, u, beta, dZ, dM, slab, N);
-        } else if (P == 2) {
-            e2 = hipFuncSetAttribute((const void *)sem_attn_bwd_wave_kernel<CA, 2>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e2 == hipSuccess)
-                sem_attn_bwd_wave_kernel<CA, 2><<<grid, 256, lds, st>>>(M, w, b, u, beta, dZ, dM, slab, N);
-        } else {
-            e2 = hipFuncSetAttribute((const void *)sem_attn_bwd_wave_kernel<CA, 4>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e2 == hipSuccess)
-                sem_attn_bwd_wave_kernel<CA, 4><<<grid, 256, lds, st>>>(M, w, b, u, beta, dZ, dM, slab, N);
+#define HAN_LAUNCH_BWD_WAVE(PV)                                                                          \
+    e2 = hipFuncSetAttribute((const void *)sem_attn_bwd_wave_kernel<CA, PV>,                             \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+    if (e2 == hipSuccess)                                                                                \
+        sem_attn_bwd_wave_kernel<CA, PV><<<grid, 256, lds, st>>>(M, w, b, u, beta, dZ, dM, slab, N);
+        switch (P) {
+            case 1: HAN_LAUNCH_BWD_WAVE(1) break;
+            case 2: HAN_LAUNCH_BWD_WAVE(2) break;
+            case 4: HAN_LAUNCH_BWD_WAVE(4) break;
+            case 8: HAN_LAUNCH_BWD_WAVE(8) break;
+            default: HAN_LAUNCH_BWD_WAVE(16) break;
         }
+#undef HAN_LAUNCH_BWD_WAVE
         if (e2 != hipSuccess) return (int)e2;
         HAN_CHECK_LAUNCH();
         return 0;
