@@ -855,8 +855,12 @@ static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split,
         else node_attn_fwd_kernel<FPC, false, 4, 2, BF, VAL><<<grid, 256, 0, st>>>(a);
     } else {
         const int grid = attn_grid(a.N);
+        // bf16 rows are 128 B: the eval forward (and the backward gather) keep 8 steps in flight
+        // to cover the HBM latency (measured -6..-12 %); the training forward is VALU-bound
+        // (RNG + masks per edge) and gets slower with the longer unroll
+        constexpr int UE = BF ? 8 : 4;
         if (train) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL><<<grid, 256, 0, st>>>(a);
-        else node_attn_fwd_kernel<FPC, false, 1, 4, BF, VAL><<<grid, 256, 0, st>>>(a);
+        else node_attn_fwd_kernel<FPC, false, 1, UE, BF, VAL><<<grid, 256, 0, st>>>(a);
     }
     if (has_split) {
         const int cgrid = attn_grid(a.n_chunks);
@@ -874,7 +878,7 @@ static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split,
 template <int FPC, bool BF, bool VAL>
 static void launch_bwd_cols_v(const BwdColsArgs &a, bool low, bool has_split, hipStream_t st) {
     if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF, VAL><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
-    else node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL><<<attn_grid(a.NS), 256, 0, st>>>(a);
+    else node_attn_bwd_cols_kernel<FPC, 1, (BF ? 8 : 4), BF, VAL><<<attn_grid(a.NS), 256, 0, st>>>(a);
     if (has_split) {
         node_attn_bwd_chunk_kernel<FPC, 4, BF, VAL><<<attn_grid(a.n_chunks), 256, 0, st>>>(a);
         node_attn_bwd_finish_kernel<FPC, BF><<<(int)((a.n_long + 15) / 16), 256, 0, st>>>(a);
