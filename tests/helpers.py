@@ -51,11 +51,13 @@ def load_params(model, bp):
 def build_model(prob, dev, mp_att_size=128):
     from han_amd.gat import HeteGAT_multi
     model = HeteGAT_multi()
-    hid_units, n_heads = (8,), (8, len(prob["params"]["cls"]))
+    heads0 = prob["params"]["heads"][0]
+    k0, fp0 = len(heads0), len(heads0[0]["a1"])          # first layer: K heads of width F'
+    hid_units, n_heads = (fp0,), (k0, len(prob["params"]["cls"]))
     if "layers" in prob["params"]:
         lp = prob["params"]["layers"][0]
-        hid_units = (8,) + tuple(len(l[0]["a1"]) for l in lp)
-        n_heads = (8,) + tuple(len(l) for l in lp) + (len(prob["params"]["cls"]),)
+        hid_units = (fp0,) + tuple(len(l[0]["a1"]) for l in lp)
+        n_heads = (k0,) + tuple(len(l) for l in lp) + (len(prob["params"]["cls"]),)
     residual = "layers" in prob["params"] and "res" in prob["params"]["layers"][0][0][0]
     model.build(prob["p"], prob["f"], prob["c"], hid_units, n_heads, mp_att_size, device=dev,
                 residual=residual)

@@ -321,6 +321,44 @@ def test_dropout_statistics(dev):
     assert not torch.equal(H[:, 0], H[:, 8])
 
 
+@pytest.mark.parametrize("K,FP", [(16, 4), (4, 16), (2, 32), (1, 64)])
+@pytest.mark.parametrize("drop", [0.0, 0.6])
+def test_other_head_shapes_match_oracle(dev, K, FP, drop):
+    """hid_units=[F'], n_heads=[K,1] with K*F' = 64 but not 8x8: every kernel template
+    (K1 per-head dropout tiles, K2 lane->head maps, score-parameter reductions) against the
+    oracle -- inference, then loss + all gradients with the dropouts on the same hash masks."""
+    from han_amd import rng as hrng
+    n, f, p = 90, 14, 2
+    prob = make_problem(500 + K, n, f, p, 3, [0.06, 0.4], hid_units=[FP], n_heads=(K, 1))
+    model, bp = build_model(prob, dev)
+    assert (model.K, model.FP) == (K, FP)
+    lg, fe, att = ho.hetegat_multi_inference([prob["x"]] * p, 3, n, False, 0.0, 0.0, prob["biases"],
+                                             [FP], [K, 1], prob["params"])
+    x, graphs = gpu_inputs(prob, dev)
+    with torch.no_grad():
+        logits, final_embed, att_val = model.inference([x] * p, 3, n, False, 0.0, 0.0, graphs, [FP], [K, 1])
+    assert np.abs(logits[0].cpu().numpy() - lg[0]).max() < TOL
+    assert np.abs(final_embed.cpu().numpy() - fe).max() < TOL
+    hrng.manual_seed(4242)
+    seeds = [hrng.next_seed() for _ in range(p)]
+    hrng.manual_seed(4242)
+    masks, keep = None, 1.0
+    if drop > 0:
+        keep = rng_ref.keep_prob32(drop)
+        masks = []
+        for q in range(p):
+            rp, ci = ho.bias_to_csr(prob["biases"][q])
+            masks.append({"seq": torch.tensor(rng_ref.seq_mask(seeds[q], n, f, K, drop)),
+                          "coef": torch.tensor(rng_ref.coef_mask_csr(seeds[q], rp, ci, K, drop)),
+                          "fts": torch.tensor(rng_ref.fts_mask(seeds[q], n, 64, drop))})
+    loss_ref, gref, lg_ref = _oracle_grads(prob, bp, masks=masks, keep=keep, dense=False)
+    loss, grads, lgg, _ = _gpu_loss_and_grads(model, prob, dev, attn_drop=drop, ffd_drop=drop)
+    assert np.abs(lgg - lg_ref).max() < 5 * TOL
+    assert abs(loss - loss_ref) < 5e-4
+    for k in ht.PARAM_ORDER:
+        assert rel_err(grads[k], gref[k]) < GTOL, k
+
+
 # ----------------------------------------------------------------------------- K3
 @pytest.mark.parametrize("n,p,a", [(1, 1, 128), (50, 2, 128), (333, 4, 128), (40, 3, 64), (2000, 8, 128),
                                    (77, 5, 64), (3, 16, 128), (1000, 4, 64), (5000, 1, 64), (129, 64, 128)])
