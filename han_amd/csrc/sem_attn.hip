@@ -484,7 +484,34 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_kernel(const float *__r
     __syncthreads();
     const int64_t R = N * P;
     const int64_t ntiles = (R + 15) / 16;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    // The rows of a tile come from HBM and with one wave per SIMD nothing else hides that
+    // latency, so the row-local inputs (M rows, dZ rows, beta) are fetched ONE TILE AHEAD into
+    // registers -- which also pulls the tile into L2 for the strided fragment loads of G1 / G3
+    // (3.47 -> 3.20 ms at SYN-1M).
+    const int64_t tstride = (int64_t)gridDim.x * 4;
+    float4_t mv_n[4], dz_n[4];
+    float bt_n[4];
+    auto fetch_rows = [&](int64_t tile) {
+        const int64_t g0n = tile * 16 + 4 * l4;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t row = g0n + rr;
+            const bool ok = row < R;
+            const int64_t rc = ok ? row : R - 1;
+            mv_n[rr] = *reinterpret_cast<const float4_t *>(M + rc * 64 + 4 * l15);
+            dz_n[rr] = *reinterpret_cast<const float4_t *>(dZ + (rc / P) * 64 + 4 * l15);
+            bt_n[rr] = ok ? beta[rc] : 0.f;        // beta is (N,P) flat == row index
+        }
+    };
+    fetch_rows((int64_t)blockIdx.x * 4 + w);
+    float afrag[16];
+    {
+        const int64_t t0 = (int64_t)blockIdx.x * 4 + w;
+        const int64_t ra = t0 * 16 + l15 < R ? t0 * 16 + l15 : R - 1;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) afrag[ks] = M[ra * 64 + l4 + 4 * ks];
+    }
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += tstride) {
         const int64_t r0 = tile * 16;
         const int64_t g0 = r0 + 4 * l4;           // first row of this lane group
         // ---- d beta, d s inside the lane group (lane = features 4*l15 .. 4*l15+3)
@@ -493,16 +520,13 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_kernel(const float *__r
             float dbt[4];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int64_t row = g0 + rr;
-                const bool ok = row < R;
-                const int64_t rc = ok ? row : R - 1;
-                const float4_t mv = *reinterpret_cast<const float4_t *>(M + rc * 64 + 4 * l15);
-                const float4_t dz = *reinterpret_cast<const float4_t *>(dZ + (rc / P) * 64 + 4 * l15);
+                const float4_t mv = mv_n[rr], dz = dz_n[rr];
                 float d = mv[0] * dz[0] + mv[1] * dz[1] + mv[2] * dz[2] + mv[3] * dz[3];
                 d = han_row16_sum(d);
                 dbt[rr] = d;
-                bt[rr] = ok ? beta[rc] : 0.f;        // beta is (N,P) flat == row index
+                bt[rr] = bt_n[rr];
             }
+            fetch_rows(tile + tstride);      // next tile: in flight under this tile's MFMAs
             if constexpr (P <= 4) {
 #pragma unroll
                 for (int k = 0; k < 4 / P; ++k) {
@@ -525,48 +549,64 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_kernel(const float *__r
         f32x4 acc[TA];
 #pragma unroll
         for (int t = 0; t < TA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        {
-            const int64_t ra = r0 + l15 < R ? r0 + l15 : R - 1;
-            const float *mrow = M + ra * 64 + l4;
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const float a = mrow[4 * ks];
-                const float *wr = W1 + (4 * ks + l4) * WLD1 + l15;
-#pragma unroll
-                for (int t = 0; t < TA; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wr[16 * t], acc[t], 0, 0, 0);
-            }
-        }
-        // ---- dpre in the accumulator layout (row r = 4*l4 + reg, col a = 16t + l15)
+        float dzt[4][4];      // dZ of this tile's rows in the accumulator layout (L2 hits, used by G2)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
+            const int64_t rg = g0 + reg < R ? g0 + reg : R - 1;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) dzt[reg][ft] = dZ[(rg / P) * 64 + 16 * ft + l15];
+        }
+        {
+            float anext[16];      // G1's A fragments of the NEXT tile (as in the forward kernel)
+            {
+                const int64_t rn = (tile + tstride) * 16 + l15;
+                const float *mnext = M + (rn < R ? rn : R - 1) * 64 + l4;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) anext[ks] = mnext[4 * ks];
+            }
+            // G3's A operand: this tile's rows, feature-major per lane (L2 hits)
+            float g3a[4][4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t rg = g0 + reg < R ? g0 + reg : R - 1;     // dpre of a padding row is 0
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) g3a[reg][ft] = M[rg * 64 + l15 + 16 * ft];
+            }
+            // Column tile by column tile: G1(t) -> dpre(t) -> G3(t).  The VALU work of dpre(t)
+            // (tanh, products, LDS store) has no dependence on the MFMAs of G1(t+1), so the
+            // scheduler can run it in their shadow instead of after all of G1.
 #pragma unroll
             for (int t = 0; t < TA; ++t) {
-                const float v = fast_tanh(acc[t][reg] + bcol[t]);
-                const float d = ds[reg] * ucol[t] * (1.f - v * v);
-                du[t] += ds[reg] * v;
-                db[t] += d;
-                acc[t][reg] = d;
-                mydp[(4 * l4 + reg) * WLD2 + 16 * t + l15] = d;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        afrag[ks], W1[(4 * ks + l4) * WLD1 + l15 + 16 * t], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float v = fast_tanh(acc[t][reg] + bcol[t]);
+                    const float d = ds[reg] * ucol[t] * (1.f - v * v);
+                    du[t] += ds[reg] * v;
+                    db[t] += d;
+                    acc[t][reg] = d;
+                    mydp[(4 * l4 + reg) * WLD2 + 16 * t + l15] = d;
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                    for (int ft = 0; ft < 4; ++ft)
+                        dW[ft][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(g3a[reg][ft], acc[t][reg], dW[ft][t], 0, 0, 0);
             }
-        }
-        // ---- G3: dW += M_tile^T . dpre   (k-step `reg` holds rows 4g + reg, g = lane group)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int64_t rg = g0 + reg < R ? g0 + reg : R - 1;     // dpre of a padding row is 0
-            const float *mrow = M + rg * 64 + l15;
-#pragma unroll
-            for (int ft = 0; ft < 4; ++ft) {
-                const float a = mrow[16 * ft];
-#pragma unroll
-                for (int t = 0; t < TA; ++t)
-                    dW[ft][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, acc[t][reg], dW[ft][t], 0, 0, 0);
-            }
+            for (int ks = 0; ks < 16; ++ks) afrag[ks] = anext[ks];
         }
         // ---- G2: dMx = dpre . Womega^T   (A operand from the wave's LDS tile)
+        // the accumulators start at beta * dZ (the direct term of dM); its loads were issued
+        // before G1, so the epilogue is stores only
         f32x4 acc2[4];
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) acc2[ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) acc2[ft][reg] = bt[reg] * dzt[reg][ft];
 #pragma unroll 8
         for (int ks = 0; ks < A / 4; ++ks) {
             const float a = mydp[l15 * WLD2 + 4 * ks + l4];
@@ -580,12 +620,8 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_kernel(const float *__r
         for (int reg = 0; reg < 4; ++reg) {
             const int64_t row = g0 + reg;
             if (row < R) {
-                const int64_t n = row / P;
 #pragma unroll
-                for (int ft = 0; ft < 4; ++ft) {
-                    const int f = 16 * ft + l15;
-                    dM[row * 64 + f] = acc2[ft][reg] + bt[reg] * dZ[n * 64 + f];
-                }
+                for (int ft = 0; ft < 4; ++ft) dM[row * 64 + 16 * ft + l15] = acc2[ft][reg];
             }
         }
     }
