@@ -84,6 +84,48 @@ def test_partition_shards_cover_the_graph():
         NodePartition(10, 3, 2)
 
 
+def test_csr_graph_properties_randomised():
+    """CSRGraph invariants on random graphs: transpose is an involution that keeps the edge
+    multiset (and permutes edge values with it), row_split chunks tile exactly the long rows,
+    to_bias / from_bias round-trip."""
+    from han_amd.graph import CSRGraph
+    rng = np.random.default_rng(7)
+    for trial in range(12):
+        n = int(rng.integers(1, 60))
+        deg = rng.integers(0, 9, size=n)
+        if trial % 3 == 0:
+            deg[rng.integers(0, n)] = 40            # one long row
+        rp = np.concatenate([[0], np.cumsum(deg)])
+        ci = np.concatenate([np.sort(rng.choice(n, size=d, replace=d > n)) for d in deg] + [np.zeros(0, int)])
+        vals = torch.tensor(rng.standard_normal(len(ci)), dtype=torch.float32)
+        g = CSRGraph(torch.tensor(rp), torch.tensor(ci, dtype=torch.int32), n, values=vals)
+        t = g.transpose()
+        assert t.n_rows == n and t.nnz == g.nnz
+        rows = np.repeat(np.arange(n), deg)
+        trows = np.repeat(np.arange(n), t.degrees().numpy())
+        fwd = sorted(zip(rows.tolist(), ci.tolist(), vals.tolist()))
+        bwd = sorted(zip(t.colidx.tolist(), trows.tolist(), t.values.tolist()))
+        assert fwd == bwd
+        assert t.transpose() is g
+        sp = g.row_split(split_deg=16, chunk=8)
+        long_rows = np.nonzero(deg > 16)[0]
+        if len(long_rows) == 0:
+            assert sp is None
+        else:
+            assert sp["long_rows"].tolist() == long_rows.tolist()
+            covered = []
+            for c in range(sp["n_chunks"]):
+                r = int(sp["long_rows"][int(sp["chunk_long"][c])])
+                s0, e0 = int(sp["chunk_start"][c]), int(sp["chunk_end"][c])
+                assert rp[r] <= s0 < e0 <= rp[r + 1] and e0 - s0 <= 8
+                covered += list(range(s0, e0))
+            want = [e for r in long_rows for e in range(rp[r], rp[r + 1])]
+            assert covered == want
+        if g.nnz and len(set(zip(rows.tolist(), ci.tolist()))) == g.nnz:      # no duplicate entries
+            g2 = CSRGraph.from_bias(g.to_bias())
+            assert g2.rowptr.tolist() == list(rp) and g2.colidx.tolist() == list(ci)
+
+
 # ------------------------------------------------------------- backward derivation
 @pytest.mark.parametrize("drop", [0.0, 0.6])
 def test_cpu_backend_gradients_match_oracle(cpu_ops, drop):
@@ -351,6 +393,20 @@ def test_evaluate_and_checkpoint(cpu_ops, tmp_path):
     assert not torch.equal(snap, model.flat)
     tr.load_checkpoint(path)
     assert torch.equal(snap, model.flat) and tr.opt.t == t
+    # device-step-state mode: the checkpointed Adam step count is pushed back to the device word,
+    # so the epoch after a restore repeats the bias correction of the epoch after the save
+    model2, _ = _cpu_model(prob)
+    tr2 = HANTrainer(model2, [xt], _cpu_graphs(prob), torch.tensor(prob["labels"], dtype=torch.int32),
+                     torch.tensor(prob["mask"].astype(np.uint8)), attn_drop=0.0, ffd_drop=0.0, use_graph=True)
+    tr2.epoch(); tr2.epoch()
+    tr2.save_checkpoint(path)
+    tr2.epoch()
+    after = model2.flat.clone()
+    tr2.epoch()
+    tr2.load_checkpoint(path)
+    assert int(tr2.step_state[1]) == 2 == tr2.opt.t
+    tr2.epoch()
+    assert int(tr2.step_state[1]) == 3 and torch.allclose(after, model2.flat, atol=0, rtol=0)
 
 
 @pytest.mark.parametrize("drop,residual", [(0.0, False), (0.6, False), (0.0, True), (0.6, True)])
