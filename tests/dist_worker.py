@@ -29,7 +29,11 @@ def build_problem(dev, n=257, f=24, p=2, c=3, seed=5):
         np.fill_diagonal(a, True)
         rowptr = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(a.sum(1), out=rowptr[1:])
-        graphs.append(CSRGraph.from_arrays(rowptr, np.nonzero(a)[1].astype(np.int32), n, device=dev))
+        g = CSRGraph.from_arrays(rowptr, np.nonzero(a)[1].astype(np.int32), n, device=dev)
+        if os.environ.get("HAN_TEST_WEIGHTED") == "1":   # sp_attn_head values that scale the logits
+            vals = torch.tensor(rng.uniform(-1.0, 2.0, size=g.nnz), dtype=torch.float32, device=dev)
+            g = CSRGraph(g.rowptr, g.colidx, n, values=vals)
+        graphs.append(g)
     labels = torch.tensor(rng.integers(0, c, n), dtype=torch.int32, device=dev)
     u = rng.random(n)
     tm = torch.tensor((u < 0.4).astype(np.uint8), device=dev)

@@ -32,14 +32,17 @@ def test_two_gloo_ranks_match_single_process(tmp_path, drop, port):
     assert np.abs(a["hist"] - b["hist"]).max() < 1e-5
 
 
-def test_halo_exchange_on_a_graph_with_locality(tmp_path):
+@pytest.mark.parametrize("weighted,port", [("0", 29721), ("1", 29731)])
+def test_halo_exchange_on_a_graph_with_locality(tmp_path, weighted, port):
     """Banded graphs: only a few boundary rows are remote, so the trainer plans a halo
     exchange (send lists + all-to-all-v + remapped colidx + global-id RNG keys) instead
-    of the all-gather; results must still equal the single-process run."""
+    of the all-gather; results must still equal the single-process run.  weighted: the
+    graphs carry sp_attn_head edge values, which must follow the rows into the shards,
+    the transposed shards and the remapped halo graphs."""
     one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
-    env = {"HAN_TEST_GRAPH": "band"}
-    _launch(1, 2, 0.6, one, 29721, env)
-    _launch(2, 2, 0.6, two, 29723, env)
+    env = {"HAN_TEST_GRAPH": "band", "HAN_TEST_WEIGHTED": weighted}
+    _launch(1, 2, 0.6, one, port, env)
+    _launch(2, 2, 0.6, two, port + 2, env)
     a, b = np.load(one), np.load(two)
     assert int(b["halo_plans"]) == 4          # 2 meta-paths x (forward, backward) all in halo mode
     assert np.abs(a["flat"] - b["flat"]).max() < 1e-5
