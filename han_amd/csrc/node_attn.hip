@@ -109,8 +109,20 @@ struct RowState {
     }
 };
 
+// sign-extended bit `BIT` of x (0 or -1) as ONE v_bfe_i32: the compiler would otherwise
+// re-canonicalise `x & sext(bit)` into and + compare + select
+template <int BIT>
+__device__ __forceinline__ int han_bit_mask(int x) {
+    int r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(x), "n"(BIT));
+    return r;
+}
+
 // Gather U neighbour rows and fold them into the running softmax state.
-template <int FP, bool TRAIN, int U, bool BF, bool VAL>
+// FAST (training launches with both dropouts on and table index == global id): no uniform
+// branch is left inside the edge loop.  ALLV: all U slots hold real edges (full steps), so
+// the validity selects vanish; the tail of a row runs with U = 1.
+template <int FP, bool TRAIN, int U, bool BF, bool VAL, bool FAST, bool ALLV>
 __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U], const float (&w)[U],
                                               const bool (&valid)[U], const float f1h, const uint32_t gi, const int q, const int head,
                                               const float4_t &a24, const float b2h, const bool drop_c,
@@ -128,7 +140,7 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
         if (VAL) x *= w[u];
         sg[u] = x > 0.f ? 1.f : a.slope;
         if (VAL) sg[u] *= w[u];
-        ev[u] = valid[u] ? han_lrelu(x, a.slope) : HAN_NEG_BIG;          // layers.py:27
+        ev[u] = (ALLV || valid[u]) ? han_lrelu(x, a.slope) : HAN_NEG_BIG;          // layers.py:27
         mc = fmaxf(mc, ev[u]);
     }
     const float sc = __expf(st.m - mc);
@@ -142,26 +154,25 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const float p = valid[u] ? __expf(ev[u] - mc) : 0.f;
+        const float p = (ALLV || valid[u]) ? __expf(ev[u] - mc) : 0.f;
         st.l += p;
         float pd = p;
         if (TRAIN) {
             // The 1/keep factors of both dropouts are applied once per row in write_row,
             // not per edge: here a dropped term is simply zeroed.
-            if (drop_c) {   // attention dropout, layers.py:29-30
-                const uint32_t gj = a.gid ? (uint32_t)a.gid[j[u]] : (uint32_t)j[u];
+            if (FAST || drop_c) {   // attention dropout, layers.py:29-30
+                const uint32_t gj = (!FAST && a.gid) ? (uint32_t)a.gid[j[u]] : (uint32_t)j[u];
                 const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
                                                 gj * (uint32_t)KQ + (uint32_t)(head >> 2));
                 pd = rn.field(head & 3) < a.thr_coef ? p : 0.f;
             }
             // projected-row dropout, layers.py:31-32 (after the score was taken): AND the
             // element with the sign-extended keep bit (one v_bfe_i32 + one v_and per element)
-            if (a.lsb_mask) {
+            if (FAST || a.lsb_mask) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int bits = __float_as_int(hv[u][t]);
-                    const int keep = __builtin_amdgcn_sbfe(bits, BF ? 16 : 0, 1);   // 0 or -1
-                    hv[u][t] = __int_as_float(bits & keep);
+                    hv[u][t] = __int_as_float(bits & han_bit_mask<BF ? 16 : 0>(bits));
                 }
             }
         }
@@ -214,7 +225,10 @@ __device__ __forceinline__ void write_row(const FwdArgs &a, const int64_t row, c
 // applies the two dropouts.
 // (Forcing more waves per SIMD on the TRAIN instantiation with __launch_bounds__ spills
 // 92-180 B/lane to scratch and measured 5-25 % slower in both cache and HBM regimes.)
-template <int FP, bool TRAIN, int RPW, int U, bool BF, bool VAL>
+// SPLIT: a row's edges run as full U-steps + single steps for the tail (fewer VALU instructions;
+// what the VALU-bound instantiations want) instead of masked U-steps (fewer registers: the fp32
+// eval forward keeps 64 VGPRs = 8 waves/SIMD, which is what the HBM-bound regime wants)
+template <int FP, bool TRAIN, int RPW, int U, bool BF, bool VAL, bool FAST, bool SPLIT>
 __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) {
     FwdArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
@@ -248,18 +262,59 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) 
                 const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
                 const int mycol = a.colidx[base + (lane < cnt ? lane : cnt - 1)];
                 const float myval = VAL ? a.edge_val[base + (lane < cnt ? lane : cnt - 1)] : 1.f;
-                for (int it = 0; it * 4 < cnt; it += U) {
+                int it = 0;
+                if constexpr (!SPLIT) {
+                    for (; it * 4 < cnt; it += U) {          // masked steps
+                        int j[U];
+                        float w[U];
+                        bool valid[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int idx = (it + u) * 4 + g;
+                            valid[u] = idx < cnt;
+                            j[u] = __shfl(mycol, idx & 63, 64);
+                            w[u] = VAL ? __shfl(myval, idx & 63, 64) : 1.f;
+                        }
+                        consume_edges<FP, TRAIN, U, BF, VAL, FAST, false>(a, j, w, valid, f1h, gi, q, head, a24,
+                                                                          b2h, drop_c, st);
+                    }
+                }
+                for (; (it + U) * 4 <= cnt; it += U) {       // full steps: every slot is an edge
                     int j[U];
                     float w[U];
                     bool valid[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int idx = (it + u) * 4 + g;
-                        valid[u] = idx < cnt;
-                        j[u] = __shfl(mycol, idx & 63, 64);
-                        w[u] = VAL ? __shfl(myval, idx & 63, 64) : 1.f;
+                        valid[u] = true;
+                        j[u] = __shfl(mycol, idx, 64);
+                        w[u] = VAL ? __shfl(myval, idx, 64) : 1.f;
                     }
-                    consume_edges<FP, TRAIN, U, BF, VAL>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
+                    consume_edges<FP, TRAIN, U, BF, VAL, FAST, true>(a, j, w, valid, f1h, gi, q, head, a24, b2h,
+                                                                     drop_c, st);
+                }
+                if (U > 4 && (it + 4) * 4 <= cnt) {          // long unrolls: one half step before the singles
+                    int j[4];
+                    float w[4];
+                    bool valid[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = (it + u) * 4 + g;
+                        valid[u] = true;
+                        j[u] = __shfl(mycol, idx, 64);
+                        w[u] = VAL ? __shfl(myval, idx, 64) : 1.f;
+                    }
+                    consume_edges<FP, TRAIN, 4, BF, VAL, FAST, true>(a, j, w, valid, f1h, gi, q, head, a24, b2h,
+                                                                     drop_c, st);
+                    it += 4;
+                }
+                for (; it * 4 < cnt; ++it) {                 // tail: single steps of 4 edges
+                    const int idx = it * 4 + g;
+                    const int j[1] = {__shfl(mycol, idx & 63, 64)};
+                    const float w[1] = {VAL ? __shfl(myval, idx & 63, 64) : 1.f};
+                    const bool valid[1] = {idx < cnt};
+                    consume_edges<FP, TRAIN, 1, BF, VAL, FAST, false>(a, j, w, valid, f1h, gi, q, head, a24, b2h,
+                                                                      drop_c, st);
                 }
             }
             st.merge(16);
@@ -284,7 +339,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) 
                     j[u] = (len > 0) ? a.colidx[valid[u] ? s + it + u : s] : 0;
                     w[u] = (VAL && len > 0) ? a.edge_val[valid[u] ? s + it + u : s] : 1.f;
                 }
-                consume_edges<FP, TRAIN, U, BF, VAL>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
+                consume_edges<FP, TRAIN, U, BF, VAL, FAST, false>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
             }
         }
 
@@ -328,7 +383,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_chunk_kernel(const FwdArgs 
                     j[u] = __shfl(mycol, idx & 63, 64);
                     w[u] = VAL ? __shfl(myval, idx & 63, 64) : 1.f;
                 }
-                consume_edges<FP, TRAIN, U, BF, VAL>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
+                consume_edges<FP, TRAIN, U, BF, VAL, false, false>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
             }
         }
         st.merge(16);
@@ -505,7 +560,7 @@ __device__ __forceinline__ SrcRow load_src(const BwdColsArgs &a, const int64_t s
 }
 
 // gather U destinations i of source j and accumulate  acc += alpha~ g_i,  df += dl_ij
-template <int FP, int U, bool BF, bool VAL>
+template <int FP, int U, bool BF, bool VAL, bool FAST, bool ALLV>
 __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)[U], const float (&ew)[U],
                                             const bool (&valid)[U], const SrcRow &sr, const int q, const int head, const bool drop_c,
                                             float (&acc)[4], float &dfacc) {
@@ -524,11 +579,11 @@ __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)
         float sg = x > 0.f ? 1.f : a.slope;
         if (VAL) sg *= ew[u];
         float alpha = __expf(han_lrelu(x, a.slope) - st[u][1]);
-        alpha = valid[u] ? alpha : 0.f;
+        alpha = (ALLV || valid[u]) ? alpha : 0.f;
         float am = 1.f;
-        if (drop_c) {
+        if (FAST || drop_c) {
             const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF,
-                                            (uint32_t)((a.gid ? (int64_t)a.gid[i[u]] : (int64_t)i[u]) + a.dst_offset),
+                                            (uint32_t)(((!FAST && a.gid) ? (int64_t)a.gid[i[u]] : (int64_t)i[u]) + a.dst_offset),
                                             sr.gj * (uint32_t)KQ + (uint32_t)(head >> 2));
             am = rn.field(head & 3) < a.thr_coef ? a.inv_keep_coef : 0.f;
         }
@@ -553,7 +608,7 @@ __device__ __forceinline__ void write_src(const BwdColsArgs &a, const int64_t sr
     if ((4 * q) % FP == 0) a.df2[src * K + head] = dfacc;
 }
 
-template <int FP, int RPW, int U, bool BF, bool VAL>
+template <int FP, int RPW, int U, bool BF, bool VAL, bool FAST>
 __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsArgs a_in) {
     BwdColsArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
@@ -589,18 +644,63 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
             o = __shfl_xor(trips, 32, 64);
             trips = o > trips ? o : trips;
         }
-        for (int64_t it = 0; it < trips; it += U) {
+        int64_t it = 0;
+        if (RPW == 1) {
+            // as in the forward: the destination ids of 64 transposed edges are loaded coalesced
+            // and handed out by shuffle, so no step (least of all a tail step) waits on an index load
+            for (int64_t base = s; base < e; base += 64) {
+                const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
+                const int myrow = a.rowidx[base + (lane < cnt ? lane : cnt - 1)];
+                const float myval = VAL ? a.edge_val[base + (lane < cnt ? lane : cnt - 1)] : 1.f;
+                int st = 0;
+                for (; (st + U) * 4 <= cnt; st += U) {          // full steps: every slot is an edge
+                    int i[U];
+                    float ew[U];
+                    bool valid[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int idx = (st + u) * 4 + g;
+                        valid[u] = true;
+                        i[u] = __shfl(myrow, idx, 64);
+                        ew[u] = VAL ? __shfl(myval, idx, 64) : 1.f;
+                    }
+                    bwd_consume<FP, U, BF, VAL, FAST, true>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+                }
+                if (U > 4 && (st + 4) * 4 <= cnt) {             // long unrolls: one half step before the singles
+                    int i[4];
+                    float ew[4];
+                    bool valid[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = (st + u) * 4 + g;
+                        valid[u] = true;
+                        i[u] = __shfl(myrow, idx, 64);
+                        ew[u] = VAL ? __shfl(myval, idx, 64) : 1.f;
+                    }
+                    bwd_consume<FP, 4, BF, VAL, FAST, true>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+                    st += 4;
+                }
+                for (; st * 4 < cnt; ++st) {                    // tail: single steps of 4 edges
+                    const int idx = st * 4 + g;
+                    const bool valid[1] = {idx < cnt};
+                    const int i[1] = {__shfl(myrow, idx & 63, 64)};
+                    const float ew[1] = {VAL ? __shfl(myval, idx & 63, 64) : 1.f};
+                    bwd_consume<FP, 1, BF, VAL, FAST, false>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+                }
+            }
+        }
+        for (; RPW != 1 && it < trips; it += U) {
             int i[U];
             float ew[U];
             bool valid[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t k = (RPW == 1) ? (it + u) * 4 + g : it + u;
+                const int64_t k = it + u;
                 valid[u] = k < len;
                 i[u] = len > 0 ? a.rowidx[valid[u] ? s + k : s] : 0;
                 ew[u] = (VAL && len > 0) ? a.edge_val[valid[u] ? s + k : s] : 1.f;
             }
-            bwd_consume<FP, U, BF, VAL>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+            bwd_consume<FP, U, BF, VAL, FAST, false>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
         }
         if (RPW == 1) {
 #pragma unroll
@@ -643,7 +743,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsA
                 i[u] = a.rowidx[valid[u] ? s + k : s];
                 ew[u] = VAL ? a.edge_val[valid[u] ? s + k : s] : 1.f;
             }
-            bwd_consume<FP, U, BF, VAL>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+            bwd_consume<FP, U, BF, VAL, false, false>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
         }
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
@@ -849,18 +949,22 @@ bool split_ok(const han_row_split_t *sp) {
 
 template <int FPC, bool BF, bool VAL>
 static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split, hipStream_t st) {
+    // FAST: the training configuration every shipped script uses (both dropouts on, table
+    // index == global id) gets an edge loop without uniform branches
+    const bool fast = train && a.thr_coef < HAN_KEEP_ALL && a.lsb_mask && !a.gid;
     if (low) {
         const int grid = attn_grid((a.N + 3) / 4);
-        if (train) node_attn_fwd_kernel<FPC, true, 4, 2, BF, VAL><<<grid, 256, 0, st>>>(a);
-        else node_attn_fwd_kernel<FPC, false, 4, 2, BF, VAL><<<grid, 256, 0, st>>>(a);
+        if (train) node_attn_fwd_kernel<FPC, true, 4, 2, BF, VAL, false, false><<<grid, 256, 0, st>>>(a);
+        else node_attn_fwd_kernel<FPC, false, 4, 2, BF, VAL, false, false><<<grid, 256, 0, st>>>(a);
     } else {
         const int grid = attn_grid(a.N);
         // bf16 rows are 128 B: the eval forward (and the backward gather) keep 8 steps in flight
         // to cover the HBM latency (measured -6..-12 %); the training forward is VALU-bound
         // (RNG + masks per edge) and gets slower with the longer unroll
         constexpr int UE = BF ? 8 : 4;
-        if (train) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL><<<grid, 256, 0, st>>>(a);
-        else node_attn_fwd_kernel<FPC, false, 1, UE, BF, VAL><<<grid, 256, 0, st>>>(a);
+        if (train && fast) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, true, true><<<grid, 256, 0, st>>>(a);
+        else if (train) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, false, true><<<grid, 256, 0, st>>>(a);
+        else node_attn_fwd_kernel<FPC, false, 1, UE, BF, VAL, false, BF><<<grid, 256, 0, st>>>(a);
     }
     if (has_split) {
         const int cgrid = attn_grid(a.n_chunks);
@@ -877,8 +981,10 @@ static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split,
 
 template <int FPC, bool BF, bool VAL>
 static void launch_bwd_cols_v(const BwdColsArgs &a, bool low, bool has_split, hipStream_t st) {
-    if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF, VAL><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
-    else node_attn_bwd_cols_kernel<FPC, 1, (BF ? 8 : 4), BF, VAL><<<attn_grid(a.NS), 256, 0, st>>>(a);
+    const bool fast = a.thr_coef < HAN_KEEP_ALL && !a.gid;
+    if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF, VAL, false><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
+    else if (fast) node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL, true><<<attn_grid(a.NS), 256, 0, st>>>(a);
+    else node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL, false><<<attn_grid(a.NS), 256, 0, st>>>(a);
     if (has_split) {
         node_attn_bwd_chunk_kernel<FPC, 4, BF, VAL><<<attn_grid(a.n_chunks), 256, 0, st>>>(a);
         node_attn_bwd_finish_kernel<FPC, BF><<<(int)((a.n_long + 15) / 16), 256, 0, st>>>(a);

@@ -42,7 +42,7 @@ def test_rccl_collectives_on_a_one_rank_group(dev, tmp_path):
     _launch(1, 2, 0.6, one, 29621)
     _launch(1, 2, 0.6, forced, 29623, {"HAN_FORCE_COLLECTIVES": "1", "HAN_TEST_BACKEND": "nccl"})
     a, b = np.load(one), np.load(forced)
-    assert np.abs(a["flat"] - b["flat"]).max() < 1e-6
+    assert np.abs(a["flat"] - b["flat"]).max() < 5e-6      # different kernel instantiations (FAST / generic)
     assert np.abs(a["hist"] - b["hist"]).max() < 1e-6
 
 

@@ -15,6 +15,8 @@ from han_amd import ops, synth  # noqa: E402
 
 
 def train_variants(dev, sizes=(1_000_000, 4_000_000)):
+    if os.environ.get("N_ONLY"):
+        sizes = (int(os.environ["N_ONLY"]),)
     """Training kernels (forward with both dropouts, transposed-graph backward) in the
     cache-resident and the HBM-served regime, fp32 and bf16 tables."""
     for n in sizes:
