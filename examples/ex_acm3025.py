@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--epochs", type=int, default=200)
     ap.add_argument("--patience", type=int, default=100)
     ap.add_argument("--graph", action="store_true", help="replay the epoch from a hipGraph")
+    ap.add_argument("--planted", action="store_true",
+                    help="without --mat: a synthetic task WITH structure (communities) instead of the ACM-shaped "
+                         "random-label workload, to watch the model learn")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -42,6 +45,11 @@ def main():
         labels = torch.tensor(y.argmax(1), dtype=torch.int32, device=dev)
         masks = [torch.tensor(m, device=dev) for m in (train_mask, val_mask, test_mask)]
         nb_classes = y.shape[1]
+    elif args.planted:
+        wl = synth.planted_partition(3025, 3, 2, 64, deg_in=8, deg_out=2, noise=1.0, seed=args.seed, device=dev)
+        graphs, xs = wl["graphs"], [wl["x"]] * wl["p"]
+        labels, nb_classes = wl["labels"], wl["c"]
+        masks = [wl["train_mask"], wl["val_mask"], wl["test_mask"]]
     else:
         wl = synth.make_workload("acm-like", device=dev)
         graphs, xs = wl["graphs"], [wl["x"]] * wl["p"]

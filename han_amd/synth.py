@@ -78,6 +78,35 @@ def bernoulli_graph(n: int, density: float, seed: int, device="cpu") -> CSRGraph
     return CSRGraph.from_arrays(rowptr, colidx, n, device=device)
 
 
+def planted_partition(n: int, c: int, p_metapaths: int, f: int, deg_in: int, deg_out: int, noise: float,
+                      seed: int, device="cpu"):
+    """A LEARNABLE synthetic task (the benchmark workloads have random labels): c communities;
+    each meta-path graph links a node to `deg_in` random members of its own community and
+    `deg_out` random other nodes (+ the self-loop); features = community one-hot (first c
+    columns) + Gaussian noise.  Returns dict like make_workload (train 20 % / val 20 % / rest test)."""
+    rng = np.random.default_rng(seed)
+    labels = rng.integers(0, c, n)
+    members = [np.nonzero(labels == k)[0] for k in range(c)]
+    graphs = []
+    for q in range(p_metapaths):
+        rows = []
+        for i in range(n):
+            same = rng.choice(members[labels[i]], size=deg_in)
+            other = rng.integers(0, n, size=deg_out + 3 * q)     # later meta-paths are noisier
+            rows.append(np.unique(np.concatenate([[i], same, other])))
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(r) for r in rows], out=rowptr[1:])
+        graphs.append(CSRGraph.from_arrays(rowptr, np.concatenate(rows).astype(np.int32), n, device=device))
+    x = np.zeros((n, f), dtype=np.float32)
+    x[np.arange(n), labels] = 1.0
+    x += noise * rng.standard_normal((n, f)).astype(np.float32)
+    u = rng.random(n)
+    t = lambda a, dt: torch.as_tensor(a, dtype=dt, device=device)
+    return dict(x=t(x, torch.float32), graphs=graphs, labels=t(labels, torch.int32),
+                train_mask=t(u < 0.2, torch.uint8), val_mask=t((u >= 0.2) & (u < 0.4), torch.uint8),
+                test_mask=t(u >= 0.4, torch.uint8), n=n, f=f, c=c, p=p_metapaths, name="planted")
+
+
 CONFIGS = {
     # name: (N, P, F, C, per-meta-path graph spec)
     "acm-like": dict(n=3025, f=1870, c=3, graphs=[("bernoulli", 29281 / 3025 ** 2),

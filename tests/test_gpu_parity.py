@@ -783,6 +783,34 @@ def test_captured_epoch_replay_matches_eager_and_oracle(dev):
         assert np.abs(getattr(trainers[0].model, k).detach().cpu().numpy() - bpo[k].numpy()).max() < 2e-4, k
 
 
+def test_training_learns_planted_communities(dev):
+    """End-to-end sanity beyond parity: on a synthetic task WITH structure (communities visible
+    in the meta-path graphs, features = noisy community indicators) the reference training
+    recipe (lr 0.005, l2 0.001, dropout 0.6/0.6, early stopping on the val split) must reach a
+    test accuracy far above chance, and the semantic attention must favour the cleaner meta-path."""
+    from han_amd import rng as hrng, synth
+    from han_amd.gat import HeteGAT_multi
+    from han_amd.trainer import HANTrainer
+    torch.manual_seed(0)
+    hrng.manual_seed(5)
+    wl = synth.planted_partition(1500, 4, 2, 32, deg_in=8, deg_out=2, noise=1.0, seed=3, device=dev)
+    model = HeteGAT_multi().build(2, 32, 4, (8,), (8, 1), 128, device=dev)
+    tr = HANTrainer(model, [wl["x"]] * 2, wl["graphs"], wl["labels"], wl["train_mask"], wl["val_mask"],
+                    patience=40, use_graph=True)
+    for epoch in range(200):
+        tl, ta, vl, va = (float(v) for v in tr.epoch())
+        if tr.early_stopping(vl, va):
+            break
+    tr.restore_best()
+    w = 1.0 / int(wl["test_mask"].sum())
+    _, test_acc = tr.eval_step(wl["test_mask"], w)
+    assert float(test_acc) > 0.9, float(test_acc)          # chance is 0.25; measured 0.977
+    with torch.no_grad():
+        _, _, att = model.inference([wl["x"]] * 2, 4, 1500, False, 0.0, 0.0, wl["graphs"], [8], [8, 1])
+    m = att.mean(0)
+    assert float(m[0]) > float(m[1])          # meta-path 0 has fewer cross-community edges
+
+
 # ------------------------------------------------------------------- skewed graphs
 @pytest.mark.parametrize("drop", [0.0, 0.6])
 def test_row_split_for_long_rows_matches_oracle(dev, monkeypatch, drop):
