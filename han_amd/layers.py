@@ -22,7 +22,7 @@ import torch.nn.functional as F_torch
 
 from . import ops, rng
 from .dist import NodePartition
-from .graph import CSRGraph, as_graph
+from .graph import as_graph
 
 D = ops.D
 

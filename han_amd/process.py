@@ -6,7 +6,6 @@ from __future__ import annotations
 
 import numpy as np
 import scipy.sparse as sp
-import torch
 
 from .graph import CSRGraph
 

@@ -17,7 +17,7 @@ from . import layers, ops
 from .base_gattn import TFAdam
 from .dist import NodePartition
 from .gat import HeteGAT_multi
-from .graph import CSRGraph, as_graph
+from .graph import as_graph
 
 
 class HANTrainer:
