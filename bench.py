@@ -100,6 +100,9 @@ def main():
                     help="storage of X and of the H/g gather tables (bf16 = the 10M-node config's "
                          "'bf16 feats'); accumulation is fp32 either way")
     args = ap.parse_args()
+    if os.environ.get("HAN_DEBUG_HANG"):      # dump every thread's Python stack periodically (rehearsal debugging)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["HAN_DEBUG_HANG"]), repeat=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -114,19 +114,25 @@ class NodePartition:
             return work if async_op else out
         src = inp.contiguous().cpu()
         dst = torch.empty(out.shape, dtype=out.dtype)
-        reqs, so, ro = [], 0, 0
+        soff, roff = [0], [0]
         for r in range(self.world):
-            ns, nr = int(send_splits[r]), int(recv_splits[r])
-            if r == self.rank:
-                dst[ro:ro + nr] = src[so:so + ns]
-            else:
-                if ns:
-                    reqs.append(dist.isend(src[so:so + ns].contiguous(), r, group=self.group))
-                if nr:
-                    reqs.append(dist.irecv(dst[ro:ro + nr], r, group=self.group))
-            so, ro = so + ns, ro + nr
-        for q in reqs:
-            q.wait()
+            soff.append(soff[-1] + int(send_splits[r]))
+            roff.append(roff[-1] + int(recv_splits[r]))
+        dst[roff[self.rank]:roff[self.rank + 1]] = src[soff[self.rank]:soff[self.rank + 1]]
+        # pairwise and blocking, peers in increasing order, the lower rank of a pair sends first: the
+        # smallest unfinished pair can always proceed, so no message size can deadlock it (posting
+        # every isend before any recv did, at 4 ranks with multi-MB id lists)
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            for phase in (0, 1):
+                if (phase == 0) == (self.rank < peer):
+                    if soff[peer + 1] > soff[peer]:
+                        dist.send(src[soff[peer]:soff[peer + 1]].contiguous(), peer, group=self.group)
+                elif roff[peer + 1] > roff[peer]:
+                    buf = torch.empty((roff[peer + 1] - roff[peer],) + tuple(dst.shape[1:]), dtype=dst.dtype)
+                    dist.recv(buf, peer, group=self.group)
+                    dst[roff[peer]:roff[peer + 1]] = buf
         out.copy_(dst)
         return None if async_op else out
 

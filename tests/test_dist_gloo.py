@@ -47,3 +47,16 @@ def test_halo_exchange_on_a_graph_with_locality(tmp_path, weighted, port):
     assert int(b["halo_plans"]) == 4          # 2 meta-paths x (forward, backward) all in halo mode
     assert np.abs(a["flat"] - b["flat"]).max() < 1e-5
     assert np.abs(a["hist"] - b["hist"]).max() < 1e-5
+
+
+def test_four_gloo_ranks_uneven_shards(tmp_path):
+    """world_size 4 with N = 257 (shards of 65, 65, 65, 62 rows): the driver also runs 4 and 8
+    ranks.  Halo mode on the banded graphs; must equal the single-process run."""
+    one, four = str(tmp_path / "one.npz"), str(tmp_path / "four.npz")
+    env = {"HAN_TEST_GRAPH": "band"}
+    _launch(1, 2, 0.6, one, 29741, env)
+    _launch(4, 2, 0.6, four, 29743, env)
+    a, b = np.load(one), np.load(four)
+    assert int(b["halo_plans"]) == 4
+    assert np.abs(a["flat"] - b["flat"]).max() < 1e-5
+    assert np.abs(a["hist"] - b["hist"]).max() < 1e-5
