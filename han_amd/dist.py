@@ -63,7 +63,21 @@ class NodePartition:
         if g.n_rows != self.n_global or g.n_cols != self.n_global:
             raise ValueError("shard_graph expects the global square graph")
         rows_local = _row_block(g, self.row_start, self.row_end, self.n_table)
-        cols_local = _row_block(g.transpose(), self.row_start, self.row_end, self.n_table)
+        # the transposed shard from this rank's share of the edges only (edges whose source column is
+        # local): an E/G-element stable sort instead of transposing the whole graph on every rank
+        dev = g.device
+        col = g.colidx
+        sel = torch.nonzero((col >= self.row_start) & (col < self.row_end)).flatten()
+        rows_all = torch.repeat_interleave(torch.arange(g.n_rows, device=dev, dtype=torch.int32), g.degrees())
+        src = (col[sel] - self.row_start).long()
+        order = torch.sort(src, stable=True).indices          # destinations stay ascending per source
+        rowidx = rows_all[sel][order].contiguous()
+        del rows_all
+        counts = torch.bincount(src, minlength=self.n_local)
+        colptr = torch.zeros(self.n_local + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=colptr[1:])
+        vals = g.values[sel][order].contiguous() if g.values is not None else None
+        cols_local = CSRGraph(colptr, rowidx, self.n_table, validate=False, values=vals)
         return rows_local, cols_local
 
     def local_rows(self, t: torch.Tensor) -> torch.Tensor:
