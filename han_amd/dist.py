@@ -184,7 +184,10 @@ class HaloPlan:
         self.part = part
         dev = g_local.device
         shard, rank, world = part.shard, part.rank, part.world
-        needed = torch.unique(g_local.colidx.long())                       # sorted global ids
+        seen = torch.zeros(part.n_table, dtype=torch.bool, device=dev)       # bitmap instead of a sort-based unique
+        seen[g_local.colidx.long()] = True
+        needed = torch.nonzero(seen).flatten()                             # sorted global ids
+        del seen
         owner = needed // shard
         remote = needed[owner != rank]
         recv_counts = torch.bincount(owner[owner != rank], minlength=world)
