@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _launch(world, epochs, drop, out, port, extra_env=None):
-    env = dict(os.environ, OMP_NUM_THREADS="2", **(extra_env or {}))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r),
                                str(world), "cpu", str(epochs), str(drop), out, str(port), "1"],
                               env=env, cwd=ROOT) for r in range(world)]
@@ -58,5 +59,18 @@ def test_four_gloo_ranks_uneven_shards(tmp_path):
     _launch(4, 2, 0.6, four, 29743, env)
     a, b = np.load(one), np.load(four)
     assert int(b["halo_plans"]) == 4
+    assert np.abs(a["flat"] - b["flat"]).max() < 1e-5
+    assert np.abs(a["hist"] - b["hist"]).max() < 1e-5
+
+
+def test_eight_gloo_ranks_mixed_exchange_modes(tmp_path):
+    """world_size 8 (the driver's largest run; shards of 33 ... 26 rows): the sparse meta-path
+    plans a halo exchange, the dense one falls back to the all-gather; must equal the
+    single-process run."""
+    one, eight = str(tmp_path / "one.npz"), str(tmp_path / "eight.npz")
+    _launch(1, 2, 0.6, one, 29761, {"OMP_NUM_THREADS": "1"})
+    _launch(8, 2, 0.6, eight, 29763, {"OMP_NUM_THREADS": "1"})
+    a, b = np.load(one), np.load(eight)
+    assert 0 < int(b["halo_plans"]) < 4
     assert np.abs(a["flat"] - b["flat"]).max() < 1e-5
     assert np.abs(a["hist"] - b["hist"]).max() < 1e-5
