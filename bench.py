@@ -78,8 +78,17 @@ def cpu_baseline(workload_name, n_full, sample_n, seed=1234):
         if time.perf_counter() - t0 > 30.0:
             break
     dt = (time.perf_counter() - t0) / reps
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": (1.0 / dt) * sample_n / n_full, "unit": "epochs/s", "cores": torch.get_num_threads(),
-            "kind": "port",
+            "kind": "port", "host": {"cpu_model": model, "os_cpu_count": os.cpu_count(),
+                                     "torch_threads": torch.get_num_threads()},
             "sample": f"{workload_name} shape at N={sample_n} (deg/F/P unchanged), {reps} epochs of "
                       f"{dt:.2f} s, scaled by {sample_n}/{n_full}; torch-CPU fp32 CSR restatement "
                       f"of the reference (not TensorFlow)"}
