@@ -302,6 +302,43 @@ def test_dropout_forward_backward_match_oracle_with_same_masks(dev, n, f, p, den
         assert rel_err(grads[k], gref[k]) < GTOL, k
 
 
+@pytest.mark.parametrize("in_drop,coef_drop", [(0.0, 0.6), (0.6, 0.0), (0.3, 0.5)])
+def test_unequal_dropout_rates_match_oracle(dev, in_drop, coef_drop):
+    """ffd_drop != attn_drop (the reference passes them separately, models/gat.py:43-45): the
+    generic training instantiations of K2 (only one of the dropouts on, or different keep
+    rates) against the oracle fed the same hash masks."""
+    from han_amd import rng as hrng
+    n, f, p = 80, 10, 2
+    prob = make_problem(91, n, f, p, 3, [0.05, 0.4])
+    model, bp = build_model(prob, dev)
+    hrng.manual_seed(31)
+    seeds = [hrng.next_seed() for _ in range(p)]
+    hrng.manual_seed(31)
+    masks = []
+    for q in range(p):
+        rp, ci = ho.bias_to_csr(prob["biases"][q])
+        mk = {}
+        if in_drop > 0:
+            mk["seq"] = torch.tensor(rng_ref.seq_mask(seeds[q], n, f, 8, in_drop))
+            mk["fts"] = torch.tensor(rng_ref.fts_mask(seeds[q], n, 64, in_drop))
+        if coef_drop > 0:
+            mk["coef"] = torch.tensor(rng_ref.coef_mask_csr(seeds[q], rp, ci, 8, coef_drop))
+        masks.append(mk)
+    bpo = {k: v.clone().requires_grad_(True) for k, v in bp.items()}
+    graphs = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]
+    keep_in = rng_ref.keep_prob32(in_drop) if in_drop > 0 else 1.0
+    keep_coef = rng_ref.keep_prob32(coef_drop) if coef_drop > 0 else 1.0
+    logits, _, _ = ht.hetegat_forward([torch.tensor(prob["x"][0])] * p, graphs, bpo, keep_in=keep_in,
+                                      keep_coef=keep_coef, masks=masks, dense=False)
+    loss_ref = ht.masked_softmax_cross_entropy(logits, torch.tensor(prob["onehot"]), torch.tensor(prob["mask"]))
+    loss_ref.backward()
+    loss, grads, lg, _ = _gpu_loss_and_grads(model, prob, dev, attn_drop=coef_drop, ffd_drop=in_drop)
+    assert np.abs(lg - logits.detach().numpy()).max() < 5 * TOL
+    assert abs(loss - float(loss_ref)) < 5e-4
+    for k in ht.PARAM_ORDER:
+        assert rel_err(grads[k], bpo[k].grad.numpy()) < GTOL, k
+
+
 def test_dropout_statistics(dev):
     """Keep rate of each stream ~ 0.4 and mean-preserving scaling (1/keep)."""
     from han_amd import ops
