@@ -238,8 +238,10 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "full-graph train epochs/sec (1 epoch = fwd+bwd+Adam step + eval forward), "
-                      "8-head HAN; node-attn HBM GB/s in roofline",
+            # BASELINE.json's metric, verbatim; `value` is its epochs/s part, the node-attn GB/s part is `roofline`
+            "metric": "full-graph train epochs/sec + node-attn HBM GB/s, 8-head HAN at 1/2/4/8 GPUs",
+            "metric_note": "value = train epochs/s (1 epoch = fwd+bwd+Adam step with dropout 0.6/0.6 + one eval "
+                           "forward, ex_acm3025.py:171-218); node-attn GB/s = roofline.achieved",
             "value": round(args.steps / dt, 4), "unit": "epochs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
