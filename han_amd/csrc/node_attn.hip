@@ -476,9 +476,13 @@ __global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsAr
         for (int t = 0; t < 4; ++t) {
             const float da = (a.activation == HAN_ACT_ELU && p4[t] <= 0.f) ? __expf(p4[t]) : 1.f;
             g4[t] = d4[t] * da;
+            dc[t] += g4[t];                             // dc = sum_i g_i: row-local, exact g
+            // bf16 g table: every consumer (the transposed-graph pass) sees the ROUNDED g, so the
+            // row-local sums s_i and df1_i are formed from the rounded value too -- otherwise
+            // sum_j dl_ij (gathered side) and df1_i (this side) disagree by the rounding of g
+            if (BF) g4[t] = __uint_as_float(han_f32_to_bf16_bits(g4[t]) << 16);
             sp += g4[t] * (p4[t] - c4[t] - r4[t]);      // g . (the aggregate alone)
             dp += g4[t] * ap4[t];
-            dc[t] += g4[t];
         }
         sp = head_sum<FP>(sp);
         dp = head_sum<FP>(dp);

@@ -17,6 +17,7 @@ ACT_IDENTITY = 0
 ACT_ELU = 1
 LEAKY_SLOPE = 0.2          # tf.nn.leaky_relu default (utils/layers.py:27)
 D = 64                     # K * F' of this build
+STATS_ROW_BYTES = 128      # per destination row: the (f1, lse, s, 0) record of each of the K heads (bench.py byte model)
 
 _workspaces: dict = {}
 

@@ -105,11 +105,43 @@ def node_attention_dense(x, bias_mat, W, a1, b1, a2, b2, c, keep_in=1.0, keep_co
     return torch.cat(outs, dim=-1)
 
 
+class _StoreBF16(torch.autograd.Function):
+    """The bf16 storage mode of the HIP path, restated (it has no counterpart in the reference, which is
+    fp32 throughout): a projected row is rounded to bf16 (nearest-even) when K1 stores it and, in training,
+    the LOWEST mantissa bit of each element is overwritten with its projected-row-dropout keep bit
+    (han_amd/csrc/project.hip); every consumer reads that stored value.  Straight-through gradient."""
+
+    @staticmethod
+    def forward(ctx, h, keepbits):
+        b = h.to(torch.float32).to(torch.bfloat16).view(torch.int16)
+        if keepbits is not None:
+            b = (b & -2) | keepbits.to(torch.int16)
+        return b.view(torch.bfloat16).to(h.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _RoundGradBF16(torch.autograd.Function):
+    """Identity whose incoming gradient is rounded to bf16: the backward's g = dOut * act' table is
+    stored in bf16 and both halves of the K2 backward read the stored value (node_attn.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.float32).to(torch.bfloat16).to(g.dtype)
+
+
 def node_attention_csr(x, rowptr, colidx, W, a1, b1, a2, b2, c, keep_in=1.0, keep_coef=1.0,
-                       masks=None, adj_vals=None, Wr=None, br=None):
+                       masks=None, adj_vals=None, Wr=None, br=None, table_bf16=False):
     """All K heads of one meta-path over CSR neighbours only -- what
     sp_attn_head (utils/layers.py:85-127) computes; heads batched.
     masks: 'seq' (K,N,F), 'coef' (E,K), 'fts' (N,D).
+    table_bf16: emulate the bf16 storage of the H / g tables (see _StoreBF16, _RoundGradBF16).
     """
     N = x.shape[0]
     K, Fp = a1.shape
@@ -122,6 +154,8 @@ def node_attention_csr(x, rowptr, colidx, W, a1, b1, a2, b2, c, keep_in=1.0, kee
                        for k in range(K)], dim=1)                       # :87-90 per head
     else:
         h = x @ W                                                       # :90
+    if table_bf16:
+        h = _StoreBF16.apply(h, masks['fts'] if (masks is not None and 'fts' in masks) else None)
     hk = h.view(N, K, Fp)
     f1 = (hk * a1[None]).sum(-1) + b1[None]                             # :93  (N,K)
     f2 = (hk * a2[None]).sum(-1) + b2[None]                             # :94
@@ -141,6 +175,8 @@ def node_attention_csr(x, rowptr, colidx, W, a1, b1, a2, b2, c, keep_in=1.0, kee
         h = h / keep_in * masks['fts']                                  # :107-108
     msg = coefs[:, :, None] * h.view(N, K, Fp)[cols]                    # (E,K,F')
     vals = torch.zeros((N, K, Fp), dtype=h.dtype).index_add(0, rows, msg)   # :113
+    if table_bf16:
+        vals = _RoundGradBF16.apply(vals)
     ret = vals.reshape(N, D) + c                                        # :118
     if Wr is not None:                                                  # :121-123
         if masks is not None and 'seq' in masks:
@@ -159,7 +195,7 @@ def semantic_attention(m, w_omega, b_omega, u_omega):
     return (m * alphas[..., None]).sum(1), alphas
 
 
-def hetegat_forward(x_list, graphs, bp, keep_in=1.0, keep_coef=1.0, masks=None, dense=False):
+def hetegat_forward(x_list, graphs, bp, keep_in=1.0, keep_coef=1.0, masks=None, dense=False, table_bf16=False):
     """models/gat.py:34-77 with hid_units=[F'], batched heads.
     x_list[p] (N,F); graphs[p] = bias_mat (N,N) if dense else (rowptr, colidx).
     Returns logits (N,C), final_embed (N,D), att_val (N,P)."""
@@ -171,7 +207,7 @@ def hetegat_forward(x_list, graphs, bp, keep_in=1.0, keep_coef=1.0, masks=None, 
             e = node_attention_dense(x, g, *args, keep_in=keep_in, keep_coef=keep_coef, masks=mk)
         else:
             e = node_attention_csr(x, g[0], g[1], *args, keep_in=keep_in, keep_coef=keep_coef,
-                                   masks=mk)
+                                   masks=mk, table_bf16=table_bf16)
         for i in range(1, n_extra_layers(bp) + 1):                      # gat.py:48-57
             sfx = f'_{i}'
             largs = tuple(bp[nm + sfx][p] for nm in ('W', 'a1', 'b1', 'a2', 'b2', 'c'))

@@ -27,7 +27,13 @@ def main():
         detail[tag] = {"FETCH_SIZE_KB_mean": fetch, "WRITE_SIZE_KB_mean": write,
                        "launches": [len(d["FETCH_SIZE"]), len(d["WRITE_SIZE"])],
                        "hbm_bytes_per_launch": int((2 * fetch + write) * 1024)}
-    out = {"workload": "syn-1m", "n_gpus": 1, "round": 1,
+    import datetime
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("han_amd/csrc/node_attn.hip", "han_amd/csrc/han_common.h"):     # == bench.py _src_sha()
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    out = {"workload": "syn-1m", "n_gpus": 1, "round": 2, "date": datetime.date.today().isoformat(),
+           "kernel_src_sha": h.hexdigest()[:16],
            "kernel": "node_attn_fwd_kernel<8,false,1,4> (K2 forward, eval)",
            "hbm_bytes_per_launch": detail["k2_fwd_eval"]["hbm_bytes_per_launch"],
            "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 B; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies "
