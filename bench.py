@@ -157,9 +157,9 @@ def hbm_regime_probe(dev, n, table_dtype, steps, warmup=2, deg=50):
         _, saved = ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=0.6, fts_drop=0.6,
                                      seed=1000 + it)
         pre, lse, aggp, tsum = saved
-        gg, stats, df1, _ = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, table_dtype=tdt)
-        ops.node_attn_bwd_cols(gt, gg, stats, H, f2, df1, a1, a2, coef_drop=0.6, fts_drop=0.6, seed=1000 + it)
-        del saved, pre, lse, aggp, tsum, gg, stats, df1
+        gs, df1, _ = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, table_dtype=tdt)
+        ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, coef_drop=0.6, fts_drop=0.6, seed=1000 + it)
+        del saved, pre, lse, aggp, tsum, gs, df1
     torch.cuda.synchronize()
     timing, ops.K2_TIMING = ops.K2_TIMING, None
     roofs, _ = k2_rooflines(timing, 2 if table_dtype == "bf16" else 4,
@@ -326,31 +326,33 @@ def main():
     from han_amd.trainer import HANTrainer
 
     rng.manual_seed(2024)
-    wl = synth.make_workload(args.workload, device=dev, n_override=args.nodes or None)
+    cfg_n = args.nodes or synth.CONFIGS[args.workload]["n"]
+    part = NodePartition(cfg_n, rank, world) if use_dist else None
+    # under a partition every rank generates ONLY its own rows (features, labels, masks, graph rows
+    # with global column ids): setup memory is global/world + the exchange tables, by construction
+    wl = synth.make_workload(args.workload, device=dev, n_override=args.nodes or None,
+                             rows=(part.row_start, part.row_end) if part is not None else None)
     n, p = wl["n"], wl["p"]
-    part = NodePartition(n, rank, world) if use_dist else None
     gen = torch.Generator().manual_seed(0)
     tdt = torch.bfloat16 if args.table_dtype == "bf16" else torch.float32
     model = HeteGAT_multi().build(p, wl["f"], wl["c"], (8,), (8, 1), 128, device=dev, generator=gen,
                                   table_dtype=tdt)
     if tdt == torch.bfloat16:
         wl["x"] = wl["x"].to(torch.bfloat16)
-
-    def loc(t):
-        return part.local_rows(t).contiguous() if part is not None else t
-
-    x_local = loc(wl["x"])
-    e_global = sum(g.nnz for g in wl["graphs"])
-    trainer = HANTrainer(model, [x_local] * p, wl["graphs"], loc(wl["labels"]), loc(wl["train_mask"]),
-                         loc(wl["val_mask"]), lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
-                         part=part, use_graph=args.graph and part is None)
+    e_local = torch.tensor([float(sum(g.nnz for g in wl["graphs"]))], dtype=torch.float64)
+    if part is not None:
+        e_local = e_local.to(dev) if dist.get_backend() == "nccl" else e_local
+        dist.all_reduce(e_local)
+    e_global = int(e_local.item())
+    trainer = HANTrainer(model, [wl["x"]] * p, wl["graphs"], wl["labels"], wl["train_mask"],
+                         wl["val_mask"], lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
+                         part=part, use_graph=args.graph and part is None, graphs_local=part is not None)
     exchange = None
     if part is not None:
         plans = model.halo_plans[0]
         exchange = ["halo %.1f%% of the remote rows" % (100.0 * pl.halo_fraction) if pl is not None else "all-gather"
                     for pl in plans]
-    if part is not None:
-        wl["graphs"] = None          # the global graphs are no longer needed on this rank
+    wl["graphs"] = None
     torch.cuda.synchronize()
 
     def barrier():

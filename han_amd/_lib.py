@@ -45,9 +45,10 @@ SIGNATURES = {
     "han_node_attn_coefs": (c_int, [P, P, P, P, P, P, P, c_int, I64, I64, c_int, c_int, c_float, c_float,
                                     c_uint64, P, I64, P]),
     "han_node_attn_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
-    "han_node_attn_bwd_rows": (c_int, [P, I64, P, P, P, P, P, P, P, P, c_int, P, P, P, P, c_size_t, I64,
+    "han_gs_row_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "han_node_attn_bwd_rows": (c_int, [P, I64, P, P, P, P, P, P, P, P, c_int, P, P, P, c_size_t, I64,
                                        c_int, c_int, c_int, P]),
-    "han_node_attn_bwd_cols": (c_int, [P, P, P, P, P, P, P, c_int, P, P, P, P, P, P, I64, I64, c_int, c_int,
+    "han_node_attn_bwd_cols": (c_int, [P, P, P, P, P, P, c_int, P, P, P, P, P, P, I64, I64, c_int, c_int,
                                        c_float, c_float, c_float, c_uint64, P, I64, I64, P, P]),
     "han_score_param_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
     "han_score_param_bwd": (c_int, [P, c_int, P, P, P, P, P, P, P, c_size_t, I64, c_int, c_int, P]),
@@ -64,7 +65,7 @@ SIGNATURES = {
     "han_bias_fill_csr": (c_int, [P, I64, I64, P, P, P]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

@@ -79,6 +79,37 @@ struct FwdArgs {
     float *split_ws;
 };
 
+// Backward tables: ONE fused row per destination i, [ g_i : D elements (fp32 or bf16) | (f1, lse, s, 0) x K : fp32 ],
+// padded to whole 128-B lines (fp32, K = 8: 256 + 128 = 384 B = 3 lines; bf16: 128 + 128 = 256 B), so that a
+// node partition moves ONE table per meta-path in the backward (one collective, one pack) instead of two.
+template <int FP, bool BF>
+struct GsRow {
+    static constexpr int K = HAN_D / FP;
+    static constexpr int g_bytes = HAN_D * (BF ? 2 : 4);
+    static constexpr int bytes = ((g_bytes + 16 * K + 127) / 128) * 128;
+};
+
+template <int FP, bool BF>
+__device__ __forceinline__ float4_t gs_load_g4(const void *gs, int64_t row, int q) {
+    const char *base = reinterpret_cast<const char *>(gs) + row * GsRow<FP, BF>::bytes;
+    if (BF) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(base + 8 * q);
+        float4_t v;
+        v[0] = __uint_as_float(w.x << 16);
+        v[1] = __uint_as_float(w.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(w.y << 16);
+        v[3] = __uint_as_float(w.y & 0xFFFF0000u);
+        return v;
+    }
+    return *reinterpret_cast<const float4_t *>(base + 16 * q);
+}
+
+template <int FP, bool BF>
+__device__ __forceinline__ float4_t gs_load_stats(const void *gs, int64_t row, int head) {
+    return *reinterpret_cast<const float4_t *>(reinterpret_cast<const char *>(gs) + row * GsRow<FP, BF>::bytes +
+                                               GsRow<FP, BF>::g_bytes + 16 * head);
+}
+
 constexpr int kFwdChunkStride = 192;   // floats per chunk: acc[64] | accp[64] | m[K] | l[K] | tl[K]
 constexpr int kBwdChunkStride = 80;    // acc[64] | df2[K]
 
@@ -447,8 +478,8 @@ struct BwdRowsArgs {
     int64_t dout_stride;
     const float *pre, *aggp, *tsum, *f1, *lse, *c;
     const float *res;   // residual term that was added to pre (or null)
-    void *g;       // fp32 or bf16 table
-    float *stats, *df1;
+    void *gs;      // fused [g | stats] rows (GsRow), g in fp32 or bf16
+    float *df1;
     float *slab;   // [gridDim.x][64] partial sums of g (for dc)
     int64_t N;
     int activation;
@@ -486,7 +517,15 @@ __global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsAr
         }
         sp = head_sum<FP>(sp);
         dp = head_sum<FP>(dp);
-        han_store_row4<BF>(a.g, row, q, g4);
+        char *grow = reinterpret_cast<char *>(a.gs) + row * GsRow<FP, BF>::bytes;
+        if (BF) {
+            uint2 w;
+            w.x = (__float_as_uint(g4[0]) >> 16) | (__float_as_uint(g4[1]) & 0xFFFF0000u);   // already rounded
+            w.y = (__float_as_uint(g4[2]) >> 16) | (__float_as_uint(g4[3]) & 0xFFFF0000u);
+            *reinterpret_cast<uint2 *>(grow + 8 * q) = w;
+        } else {
+            *reinterpret_cast<float4_t *>(grow + 16 * q) = g4;
+        }
         if ((4 * q) % FP == 0) {
             const float ts = a.tsum[row * K + head];
             a.df1[row * K + head] = dp - sp * ts;
@@ -495,7 +534,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsAr
             st[1] = a.lse[row * K + head];
             st[2] = sp;
             st[3] = 0.f;
-            *reinterpret_cast<float4_t *>(a.stats + (row * K + head) * 4) = st;
+            *reinterpret_cast<float4_t *>(grow + GsRow<FP, BF>::g_bytes + 16 * head) = st;
         }
     }
     // block reduction of dc over the 16 groups
@@ -518,9 +557,9 @@ struct BwdColsArgs {
     const int64_t *colptr;
     const int32_t *rowidx;
     const float *edge_val;   // adjacency values in transposed-graph order, or null (binary)
-    const void *g, *H;   // fp32 or bf16 tables
-    const int32_t *gid;  // global id of each row of the g / stats tables, or null
-    const float *stats, *f2, *df1, *a1, *a2;
+    const void *gs, *H;   // fused [g | stats] rows of the destinations (GsRow); H: fp32 or bf16 local rows
+    const int32_t *gid;  // global id of each row of the gs table, or null
+    const float *f2, *df1, *a1, *a2;
     int lsb_mask;
     float *dH, *df2;
     int64_t NS;
@@ -573,8 +612,8 @@ __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)
     float4_t gv[U], st[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        gv[u] = han_load_row4<BF>(a.g, (int64_t)i[u], q);
-        st[u] = *reinterpret_cast<const float4_t *>(a.stats + ((int64_t)i[u] * K + head) * 4);
+        gv[u] = gs_load_g4<FP, BF>(a.gs, (int64_t)i[u], q);
+        st[u] = gs_load_stats<FP, BF>(a.gs, (int64_t)i[u], head);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1064,6 +1103,12 @@ extern "C" size_t han_row_split_workspace(int64_t n_chunks) {
     return (size_t)(n_chunks > 0 ? n_chunks : 0) * kFwdChunkStride * sizeof(float);
 }
 
+extern "C" size_t han_gs_row_bytes(int K, int FP, int table_dtype) {
+    if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return 0;
+    const size_t g_bytes = (size_t)HAN_D * (table_dtype == HAN_DTYPE_BF16 ? 2 : 4);
+    return ((g_bytes + 16 * (size_t)K + 127) / 128) * 128;
+}
+
 extern "C" size_t han_node_attn_bwd_workspace(int64_t N, int K, int FP) {
     (void)N; (void)K; (void)FP;
     return (size_t)kReduceBlocks * 64 * sizeof(float);
@@ -1071,12 +1116,11 @@ extern "C" size_t han_node_attn_bwd_workspace(int64_t N, int K, int FP) {
 
 extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *pre,
                                       const float *aggp, const float *tsum, const float *f1,
-                                      const float *lse, const float *c, const float *res, void *g,
-                                      int table_dtype,
-                                      float *stats, float *df1, float *dc, void *workspace,
+                                      const float *lse, const float *c, const float *res, void *gs,
+                                      int table_dtype, float *df1, float *dc, void *workspace,
                                       size_t workspace_bytes, int64_t N, int K, int FP, int activation,
                                       void *stream) {
-    if (!dOut || !pre || !aggp || !tsum || !f1 || !lse || !c || !g || !stats || !df1 || !dc || !workspace ||
+    if (!dOut || !pre || !aggp || !tsum || !f1 || !lse || !c || !gs || !df1 || !dc || !workspace ||
         N < 0 || dout_stride < HAN_D)
         return HAN_E_BADARG;
     if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
@@ -1084,7 +1128,7 @@ extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, co
     hipStream_t st = (hipStream_t)stream;
     BwdRowsArgs a;
     a.dOut = dOut; a.dout_stride = dout_stride; a.pre = pre; a.aggp = aggp; a.tsum = tsum;
-    a.f1 = f1; a.lse = lse; a.c = c; a.res = res; a.g = g; a.stats = stats; a.df1 = df1;
+    a.f1 = f1; a.lse = lse; a.c = c; a.res = res; a.gs = gs; a.df1 = df1;
     a.slab = (float *)workspace; a.N = N; a.activation = activation;
     const int grid = han_grid_for(N, 16, kReduceBlocks);
     if (table_dtype == HAN_DTYPE_BF16) {
@@ -1099,22 +1143,21 @@ extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, co
 }
 
 extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const float *edge_val,
-                                      const void *g,
-                                      const float *stats, const int32_t *table_gid, const void *H,
+                                      const void *gs, const int32_t *table_gid, const void *H,
                                       int table_dtype, const float *f2,
                                       const float *df1, const float *a1, const float *a2,
                                       float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                                       float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev,
                                       int64_t src_offset, int64_t dst_offset, const han_row_split_t *split,
                                       void *stream) {
-    if (!colptr || (!rowidx && E > 0) || !g || !stats || !H || !f2 || !df1 || !a1 || !a2 || !dH || !df2 || NS < 0 || E < 0)
+    if (!colptr || (!rowidx && E > 0) || !gs || !H || !f2 || !df1 || !a1 || !a2 || !dH || !df2 || NS < 0 || E < 0)
         return HAN_E_BADARG;
     if (!split_ok(split)) return HAN_E_BADARG;
     if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
     if (NS == 0) return 0;
     BwdColsArgs a;
-    a.colptr = colptr; a.rowidx = rowidx; a.edge_val = edge_val; a.g = g; a.stats = stats; a.gid = table_gid; a.H = H; a.lsb_mask = fts_drop > 0.f; a.f2 = f2;
+    a.colptr = colptr; a.rowidx = rowidx; a.edge_val = edge_val; a.gs = gs; a.gid = table_gid; a.H = H; a.lsb_mask = fts_drop > 0.f; a.f2 = f2;
     a.df1 = df1; a.a1 = a1; a.a2 = a2; a.dH = dH; a.df2 = df2; a.NS = NS; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;

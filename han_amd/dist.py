@@ -53,31 +53,91 @@ class NodePartition:
         # HAN_FORCE_COLLECTIVES=1 runs the collectives even on a 1-rank group (used to
         # exercise the RCCL calls on a single-GPU box)
         self.active = self.world > 1 or os.environ.get("HAN_FORCE_COLLECTIVES") == "1"
+        self._bufs: dict = {}       # exchange tables, allocated once per (tag, shape, dtype) and reused every step
+
+    def buffer(self, tag, shape, dtype, device) -> torch.Tensor:
+        """Persistent exchange buffer.  `tag` names the use (direction, layer, meta-path): a buffer is
+        rewritten by the next exchange with the same tag, after its consumer kernel was queued."""
+        if tag is None:
+            return torch.empty(shape, dtype=dtype, device=device)
+        key = (tag, tuple(shape), dtype, str(device))
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self._bufs[key] = t
+        return t
 
     # ---- graph sharding -------------------------------------------------------
     def shard_graph(self, g: CSRGraph) -> tuple[CSRGraph, CSRGraph]:
-        """Global CSR (n_global x n_global) -> (rows_local, cols_local):
-        rows_local: CSR of this rank's destination rows, colidx = global ids;
-        cols_local: transposed graph restricted to this rank's source rows,
-        its colidx = global destination ids."""
+        """Global CSR (n_global x n_global) -> (rows_local, cols_local), see shard_local_graph.
+        Convenience for callers that hold the whole graph (small data sets, tests): only this
+        rank's row block is touched; at scale every rank builds or loads its own rows and calls
+        shard_local_graph directly, so that no rank ever holds the global graph."""
         if g.n_rows != self.n_global or g.n_cols != self.n_global:
             raise ValueError("shard_graph expects the global square graph")
         rows_local = _row_block(g, self.row_start, self.row_end, self.n_table)
-        # the transposed shard from this rank's share of the edges only (edges whose source column is
-        # local): an E/G-element stable sort instead of transposing the whole graph on every rank
+        # the transposed shard straight from the global graph, no collective: the edges whose source
+        # column is local, their destination rows recovered from rowptr by binary search, one
+        # stable sort of E/G elements
         dev = g.device
         col = g.colidx
         sel = torch.nonzero((col >= self.row_start) & (col < self.row_end)).flatten()
-        rows_all = torch.repeat_interleave(torch.arange(g.n_rows, device=dev, dtype=torch.int32), g.degrees())
+        dst = (torch.searchsorted(g.rowptr, sel, right=True) - 1).to(torch.int32)
         src = (col[sel] - self.row_start).long()
         order = torch.sort(src, stable=True).indices          # destinations stay ascending per source
-        rowidx = rows_all[sel][order].contiguous()
-        del rows_all
+        rowidx = dst[order].contiguous()
         counts = torch.bincount(src, minlength=self.n_local)
         colptr = torch.zeros(self.n_local + 1, dtype=torch.int64, device=dev)
         torch.cumsum(counts, 0, out=colptr[1:])
         vals = g.values[sel][order].contiguous() if g.values is not None else None
-        cols_local = CSRGraph(colptr, rowidx, self.n_table, validate=False, values=vals)
+        return rows_local, CSRGraph(colptr, rowidx, self.n_table, validate=False, values=vals)
+
+    def shard_local_graph(self, rows_local: CSRGraph) -> tuple[CSRGraph, CSRGraph]:
+        """rows_local: CSR of THIS rank's destination rows [row_start, row_end) with GLOBAL column ids.
+        Returns (rows_local, cols_local):
+        rows_local: the same rows as a table-indexing graph (n_cols = world * shard);
+        cols_local: the transposed graph restricted to this rank's source rows -- for every local
+        source j the global destination ids i in ascending order -- built from an all-to-all-v of
+        the edges (each edge (i, j) travels once, to the owner of j) and an E/G-element stable sort.
+        Collective: every rank must call it for the same meta-path in the same order."""
+        if rows_local.n_rows != self.n_local:
+            raise ValueError(f"expected this rank's {self.n_local} rows, got {rows_local.n_rows}")
+        dev = rows_local.device
+        rows_local = CSRGraph(rows_local.rowptr, rows_local.colidx, self.n_table, validate=False,
+                              values=rows_local.values)
+        col = rows_local.colidx
+        if col.numel() and (int(col.min()) < 0 or int(col.max()) >= self.n_global):
+            raise ValueError("rows_local.colidx must hold global node ids")
+        dst = torch.repeat_interleave(torch.arange(self.row_start, self.row_end, device=dev, dtype=torch.int32),
+                                      rows_local.degrees())
+        owner = torch.div(col, self.shard, rounding_mode="floor").long()
+        order = torch.sort(owner, stable=True).indices          # grouped by owner, local edge order kept
+        send_counts = torch.bincount(owner, minlength=self.world)
+        del owner
+        payload = torch.stack([dst[order], col[order]], dim=1).contiguous()     # (E_local, 2) int32
+        del dst
+        recv_counts = self.all_to_all_v(send_counts.new_empty(self.world), send_counts, [1] * self.world,
+                                        [1] * self.world)
+        send_splits = [int(c) for c in send_counts.tolist()]
+        recv_splits = [int(c) for c in recv_counts.tolist()]
+        edges = payload.new_empty((sum(recv_splits), 2))
+        self.all_to_all_v(edges, payload, recv_splits, send_splits)
+        del payload
+        vals = None
+        if rows_local.values is not None:
+            vals = rows_local.values.new_empty(sum(recv_splits))
+            self.all_to_all_v(vals, rows_local.values[order].contiguous(), recv_splits, send_splits)
+        del order
+        # arrivals are ordered by sender rank (ascending row blocks) and, within a sender, by its CSR
+        # order (ascending destination): a stable sort by source leaves each source's destinations ascending
+        src = (edges[:, 1] - self.row_start).long()
+        order2 = torch.sort(src, stable=True).indices
+        rowidx = edges[:, 0][order2].contiguous()
+        counts = torch.bincount(src, minlength=self.n_local)
+        colptr = torch.zeros(self.n_local + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=colptr[1:])
+        cols_local = CSRGraph(colptr, rowidx, self.n_table, validate=False,
+                              values=vals[order2].contiguous() if vals is not None else None)
         return rows_local, cols_local
 
     def local_rows(self, t: torch.Tensor) -> torch.Tensor:
@@ -92,28 +152,30 @@ class NodePartition:
         (padding of the last shard) hold zeros and are never indexed."""
         return self.all_gather_rows_async(local).wait()
 
-    def all_gather_rows_async(self, local: torch.Tensor) -> "GatheredTable":
+    def all_gather_rows_async(self, local: torch.Tensor, tag=None) -> "GatheredTable":
         """Start the all-gather and return a handle; `.wait()` yields the table.
         Under RCCL the collective runs on the communicator's stream (after the
         producer kernels already queued on the current stream) and overlaps with
-        whatever is launched before `.wait()`; under gloo it completes here."""
+        whatever is launched before `.wait()`; under gloo it completes here.
+        tag: reuse the persistent table of that name instead of allocating one per step."""
         if not self.active:
             return GatheredTable(local, None)
         tail = tuple(local.shape[1:])
         if local.shape[0] != self.shard:
-            padded = local.new_zeros((self.shard,) + tail)
+            padded = self.buffer(None if tag is None else (tag, "pad"), (self.shard,) + tail, local.dtype, local.device)
             padded[:local.shape[0]] = local
+            padded[local.shape[0]:] = 0
         else:
             padded = local.contiguous()
-        table = local.new_empty((self.n_table,) + tail)
+        table = self.buffer(tag, (self.n_table,) + tail, local.dtype, local.device)
         if self._backend() == "nccl":
             work = dist.all_gather_into_tensor(table, padded, group=self.group, async_op=True)
             return GatheredTable(table, work, keep=padded)
-        # gloo (CPU rehearsal / single-GPU multi-process tests): stage through host
-        src = padded.cpu()
+        # gloo (CPU rehearsal / single-GPU multi-process tests): stage through host, as raw bytes
+        src = padded.cpu().contiguous().view(torch.uint8)
         parts = [torch.empty_like(src) for _ in range(self.world)]
         dist.all_gather(parts, src, group=self.group)
-        table.copy_(torch.cat(parts, 0))
+        table.copy_(torch.cat(parts, 0).view(table.dtype).view(table.shape))
         return GatheredTable(table, None)
 
     def all_to_all_v(self, out: torch.Tensor, inp: torch.Tensor, recv_splits, send_splits, async_op=False):
@@ -126,8 +188,11 @@ class NodePartition:
             work = dist.all_to_all_single(out, inp.contiguous(), list(recv_splits), list(send_splits),
                                           group=self.group, async_op=async_op)
             return work if async_op else out
+        raw = out.dtype == torch.bfloat16 and inp.dim() >= 2        # gloo point-to-point: move bf16 rows as bytes
         src = inp.contiguous().cpu()
         dst = torch.empty(out.shape, dtype=out.dtype)
+        if raw:
+            src, dst = src.view(torch.uint8), dst.view(torch.uint8)
         soff, roff = [0], [0]
         for r in range(self.world):
             soff.append(soff[-1] + int(send_splits[r]))
@@ -147,7 +212,7 @@ class NodePartition:
                     buf = torch.empty((roff[peer + 1] - roff[peer],) + tuple(dst.shape[1:]), dtype=dst.dtype)
                     dist.recv(buf, peer, group=self.group)
                     dst[roff[peer]:roff[peer + 1]] = buf
-        out.copy_(dst)
+        out.copy_(dst.view(out.dtype) if raw else dst)
         return None if async_op else out
 
     def plan_exchange(self, g_local: CSRGraph, max_halo_fraction: float = 0.6):
@@ -214,14 +279,17 @@ class HaloPlan:
     def halo_fraction(self) -> float:
         return self.n_halo / max(self.remote_rows_total, 1)
 
-    def exchange_async(self, local: torch.Tensor) -> "GatheredTable":
+    def exchange_async(self, local: torch.Tensor, tag=None) -> "GatheredTable":
         """local (n_local, ...) -> [local | halo] table (n_local + n_halo, ...)."""
         tail = tuple(local.shape[1:])
-        table = local.new_empty((self.n_local + self.n_halo,) + tail)
+        part = self.part
+        table = part.buffer(tag, (self.n_local + self.n_halo,) + tail, local.dtype, local.device)
         table[:self.n_local] = local
-        packed = local.index_select(0, self.send_idx)
-        work = self.part.all_to_all_v(table[self.n_local:], packed, self.recv_splits, self.send_splits,
-                                      async_op=True)
+        packed = part.buffer(None if tag is None else (tag, "pack"), (self.send_idx.numel(),) + tail,
+                             local.dtype, local.device)
+        torch.index_select(local, 0, self.send_idx, out=packed)
+        work = part.all_to_all_v(table[self.n_local:], packed, self.recv_splits, self.send_splits,
+                                 async_op=True)
         return GatheredTable(table, work, keep=packed)
 
 

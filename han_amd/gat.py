@@ -207,7 +207,7 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         def cfg(layer=0, **kw):
             return {"train": train, "in_drop": float(ffd_drop), "coef_drop": float(attn_drop),
                     "seeds": seeds(layer), "seed_dev": self.step_seed_dev if train else None,
-                    "act": act_code, "part": self.partition, "graphs_t": graphs_t,
+                    "act": act_code, "part": self.partition, "graphs_t": graphs_t, "layer": layer,
                     "table_dtype": self.table_dtype, "plans_f": self.halo_plans[0],
                     "plans_b": self.halo_plans[1], **kw}
         M = layers.NodeLevelAttention.apply(None, self.W, self.a1, self.b1, self.a2, self.b2, self.c,

@@ -101,7 +101,8 @@ class NodeLevelAttention(torch.autograd.Function):
             plan = plans_f[p] if plans_f is not None else None
             handle = None
             if multi:      # halo rows only (HaloPlan) or the whole shard (all-gather)
-                handle = plan.exchange_async(H) if plan is not None else part.all_gather_rows_async(H)
+                tag = ("f", cfg.get("layer", 0), p)       # persistent exchange table of this (layer, meta-path)
+                handle = plan.exchange_async(H, tag) if plan is not None else part.all_gather_rows_async(H, tag)
             if cfg.get("coef_sink") is not None:
                 if multi:
                     raise NotImplementedError("return_coef is not provided under a node partition")
@@ -174,11 +175,11 @@ class NodeLevelAttention(torch.autograd.Function):
         dres_in = []
         for p in range(P):      # row-local halves first; their tables go out while we continue
             H, f1, f2, pre, lse, aggp, tsum, R = ctx.saved_per_p[p]
-            g, stats, df1, dcp = ops.node_attn_bwd_rows(dM[:, p, :], pre, aggp, tsum, f1, lse, c[p],
-                                                        activation=cfg["act"], K=K, FP=FP,
-                                                        table_dtype=H.dtype, res=R, dc_out=dc[p])
+            gs, df1, dcp = ops.node_attn_bwd_rows(dM[:, p, :], pre, aggp, tsum, f1, lse, c[p],
+                                                  activation=cfg["act"], K=K, FP=FP,
+                                                  table_dtype=H.dtype, res=R, dc_out=dc[p])
             if Wr is not None:      # residual: d(pre) = g flows into Wr, br and the input
-                g32 = g if g.dtype == torch.float32 else g.to(torch.float32)
+                g32 = ops.gs_views(gs, K, FP, H.dtype)[0].to(torch.float32).contiguous()
                 seed_p = int(cfg["seeds"][p])
                 dbr[p] = dcp
                 ops.project_bwd(xs[p], g32, K, FP, in_drop=ctx.in_drop, seed=seed_p,
@@ -190,17 +191,17 @@ class NodeLevelAttention(torch.autograd.Function):
             if multi:
                 plan = plans_b[p] if plans_b is not None else None
                 ex = plan.exchange_async if plan is not None else part.all_gather_rows_async
-                rows.append((ex(g), ex(stats), df1))
+                rows.append((ex(gs, ("b", cfg.get("layer", 0), p)), df1))   # ONE fused [g | stats] table on the wire
             else:
-                rows.append((g, stats, df1))
+                rows.append((gs, df1))
         for p in range(P):
             H, f1, f2, pre, lse, aggp, tsum, R = ctx.saved_per_p[p]
             seed = int(cfg["seeds"][p])
-            g_h, st_h, df1 = rows[p]
-            g_tab, stats_tab = (g_h.wait(), st_h.wait()) if multi else (g_h, st_h)
+            gs_h, df1 = rows[p]
+            gs_tab = gs_h.wait() if multi else gs_h
             plan = plans_b[p] if plans_b is not None else None
-            dH, df2 = ops.node_attn_bwd_cols(plan.graph if plan is not None else graphs_t[p], g_tab,
-                                             stats_tab, H, f2, df1, a1[p], a2[p],
+            dH, df2 = ops.node_attn_bwd_cols(plan.graph if plan is not None else graphs_t[p], gs_tab,
+                                             H, f2, df1, a1[p], a2[p],
                                              coef_drop=ctx.coef_drop, fts_drop=ctx.in_drop, seed=seed,
                                              src_offset=row_offset, dst_offset=0,
                                              table_gid=plan.gid if plan is not None else None,

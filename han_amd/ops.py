@@ -17,7 +17,7 @@ ACT_IDENTITY = 0
 ACT_ELU = 1
 LEAKY_SLOPE = 0.2          # tf.nn.leaky_relu default (utils/layers.py:27)
 D = 64                     # K * F' of this build
-STATS_ROW_BYTES = 128      # per destination row: the (f1, lse, s, 0) record of each of the K heads (bench.py byte model)
+STATS_ROW_BYTES = 128      # per destination row: the (f1, lse, s, 0) records of the K = 8 heads inside the fused gs row (bench.py byte model)
 
 _workspaces: dict = {}
 
@@ -298,10 +298,28 @@ def node_attn_coefs(graph: CSRGraph, f1, f2, coef_drop=0.0, seed=0, row_offset=0
     return coef
 
 
+def gs_row_bytes(K=8, FP=8, table_dtype=torch.float32) -> int:
+    """Bytes of one fused backward row [g | (f1, lse, s, 0) x K] (han_gs_row_bytes)."""
+    n = int(_lib.load().han_gs_row_bytes(K, FP, DTYPE_CODE[table_dtype]))
+    if n == 0:
+        raise NotImplementedError(f"no fused backward row for K={K}, FP={FP}, {table_dtype}")
+    return n
+
+
+def gs_views(gs, K=8, FP=8, table_dtype=torch.float32):
+    """(g (N,D) table_dtype, stats (N,K,4) fp32) views of a fused backward table (N, row_bytes) uint8."""
+    gb = D * (2 if table_dtype == torch.bfloat16 else 4)
+    g = gs[:, :gb].view(table_dtype)
+    stats = gs[:, gb:gb + 16 * K].view(torch.float32).unflatten(1, (K, 4))
+    return g, stats
+
+
 def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=8, FP=8,
-                       table_dtype=torch.float32, res=None, dc_out=None):
+                       table_dtype=torch.float32, res=None, dc_out=None, gs_out=None):
     """Row-local half of the K2 backward.  dOut (N,D) view (unit inner stride).
-    Returns g (N,D), stats (N,K,4), df1 (N,K), dc (D,) [written to dc_out when given]."""
+    Returns gs (N, row_bytes) uint8 -- the fused table [g | (f1, lse, s, 0) x K] the transposed-graph
+    pass gathers from (gs_views() splits it) --, df1 (N,K), dc (D,) [written to dc_out when given].
+    gs_out: optional preallocated destination (e.g. the local block of an exchange table)."""
     lib = _lib.load()
     _check_heads(K, FP)
     N = pre.shape[0]
@@ -312,24 +330,28 @@ def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=
     for t, n, s in ((pre, "pre", (N, D)), (aggp, "aggp", (N, D)), (tsum, "tsum", (N, K)),
                     (f1, "f1", (N, K)), (lse, "lse", (N, K)), (c, "c", (D,))):
         _chk(t, n, s, device=dev)
-    g = torch.empty((N, D), dtype=table_dtype, device=dev)
-    stats = torch.empty((N, K, 4), dtype=torch.float32, device=dev)
+    rb = gs_row_bytes(K, FP, table_dtype)
+    if gs_out is None:      # rows padded to whole lines: keep the padding bytes defined
+        padded = rb != D * (2 if table_dtype == torch.bfloat16 else 4) + 16 * K
+        gs = (torch.zeros if padded else torch.empty)((N, rb), dtype=torch.uint8, device=dev)
+    else:
+        gs = _chk(gs_out, "gs_out", (N, rb), dtype=torch.uint8, device=dev)
     df1 = torch.empty((N, K), dtype=torch.float32, device=dev)
     dc = _out(dc_out, "dc_out", (D,), dev)
     ws = _ws(lib.han_node_attn_bwd_workspace(N, K, FP), dev, "rows")
     _lib.check(lib.han_node_attn_bwd_rows(
         dOut.data_ptr(), dOut.stride(0) if N > 1 else D, pre.data_ptr(), aggp.data_ptr(),
         tsum.data_ptr(), f1.data_ptr(), lse.data_ptr(), c.data_ptr(),
-        res.data_ptr() if res is not None else None, g.data_ptr(),
-        DTYPE_CODE[table_dtype], stats.data_ptr(), df1.data_ptr(), dc.data_ptr(), ws.data_ptr(), ws.numel(), N, K, FP,
+        res.data_ptr() if res is not None else None, gs.data_ptr(),
+        DTYPE_CODE[table_dtype], df1.data_ptr(), dc.data_ptr(), ws.data_ptr(), ws.numel(), N, K, FP,
         int(activation), _stream()), "han_node_attn_bwd_rows")
-    return g, stats, df1, dc
+    return gs, df1, dc
 
 
-def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=0.0,
+def node_attn_bwd_cols(graph_t: CSRGraph, gs_tab, H, f2, df1, a1, a2, coef_drop=0.0,
                        fts_drop=0.0, seed=0, src_offset=0, dst_offset=0, table_gid=None, seed_dev=None):
     """Transposed-graph half of the K2 backward.  graph_t rows = local sources j,
-    its colidx = destinations i indexing g_tab (NT,D) / stats_tab (NT,K,4).
+    its colidx = destinations i indexing the fused table gs_tab (NT, row_bytes) uint8.
     H (NS,D) undropped local rows (keep bits in bit 0 when fts_drop > 0),
     f2/df1 (NS,K).  Returns dH (NS,D), df2 (NS,K)."""
     lib = _lib.load()
@@ -339,8 +361,7 @@ def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, 
     dev = H.device
     _chk(H, "H", (NS, D), dtype=H.dtype)
     tcode = _dtype_code(H, "H")
-    _chk(g_tab, "g", (graph_t.n_cols, D), device=dev, dtype=H.dtype)
-    _chk(stats_tab, "stats", (graph_t.n_cols, K, 4), device=dev)
+    _chk(gs_tab, "gs", (graph_t.n_cols, gs_row_bytes(K, FP, H.dtype)), device=dev, dtype=torch.uint8)
     if table_gid is not None:
         _chk(table_gid, "table_gid", (graph_t.n_cols,), dtype=torch.int32, device=dev)
     _chk(f2, "f2", (NS, K), device=dev)
@@ -357,8 +378,8 @@ def node_attn_bwd_cols(graph_t: CSRGraph, g_tab, stats_tab, H, f2, df1, a1, a2, 
         ev0.record()
     _lib.check(lib.han_node_attn_bwd_cols(
         graph_t.rowptr.data_ptr(), graph_t.colidx.data_ptr(),
-        graph_t.values.data_ptr() if graph_t.values is not None else None, g_tab.data_ptr(),
-        stats_tab.data_ptr(), table_gid.data_ptr() if table_gid is not None else None, H.data_ptr(),
+        graph_t.values.data_ptr() if graph_t.values is not None else None, gs_tab.data_ptr(),
+        table_gid.data_ptr() if table_gid is not None else None, H.data_ptr(),
         tcode, f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
         NS, graph_t.nnz, K, FP, LEAKY_SLOPE, _check_drop(coef_drop, "coef_drop"), fts_drop,
         int(seed), _dev_word(seed_dev), int(src_offset), int(dst_offset),

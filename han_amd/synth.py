@@ -12,57 +12,98 @@ import torch
 from .graph import CSRGraph
 
 
-def random_regular_graph(n: int, deg: int, seed: int, device="cpu", symmetric=False) -> CSRGraph:
+ROW_BLOCK = 1 << 16      # generation granule: every block of rows has its own generator seed
+
+
+def _block_generator(seed: int, stream: int, block: int, device) -> torch.Generator:
+    """Generator of row block `block` of random stream `stream`: what a block holds does not depend on
+    which rows the caller asks for, so a rank of a node partition generates exactly its own rows
+    (the global graph / feature matrix never exists on any rank) and N ranks together hold, bit for
+    bit, what one process generates."""
+    g = torch.Generator(device=device)
+    g.manual_seed((int(seed) * 1_000_003 + int(stream)) * 2_097_169 + int(block))
+    return g
+
+
+def _row_range(n, rows):
+    r0, r1 = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+    if not (0 <= r0 <= r1 <= n):
+        raise ValueError(f"rows {rows} outside [0, {n}]")
+    return r0, r1
+
+
+def _blocks(r0, r1):
+    """(block id, first row, last row + 1, slice within the block) for the blocks overlapping [r0, r1)."""
+    for b in range(r0 // ROW_BLOCK, (r1 + ROW_BLOCK - 1) // ROW_BLOCK if r1 > r0 else r0 // ROW_BLOCK):
+        lo, hi = b * ROW_BLOCK, (b + 1) * ROW_BLOCK
+        yield b, max(lo, r0) - lo, min(hi, r1) - lo
+
+
+def random_regular_graph(n: int, deg: int, seed: int, device="cpu", symmetric=False, rows=None) -> CSRGraph:
     """Each row: the self-loop + (deg-1) uniformly random neighbours (duplicates
     of the self-loop or of each other are possible at rate ~deg^2/n and are kept:
     the kernels treat a repeated neighbour as a repeated term, as a multigraph).
-    Generated on `device` with torch so that 5e7-edge graphs take seconds."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    nb = torch.randint(0, n, (n, deg - 1), generator=g, device=device, dtype=torch.int32)
-    self_ids = torch.arange(n, device=device, dtype=torch.int32)[:, None]
-    cols = torch.cat([self_ids, nb], dim=1)
-    del nb
-    cols = torch.sort(cols, dim=1).values
-    rowptr = torch.arange(0, n * deg + 1, deg, device=device, dtype=torch.int64)
-    graph = CSRGraph(rowptr, cols.reshape(-1).contiguous(), n, validate=False)
+    Generated on `device` with torch so that 5e7-edge graphs take seconds.
+    rows = (r0, r1): only those destination rows (colidx stays global, n_cols = n)."""
     if symmetric:
         raise NotImplementedError
-    return graph
+    r0, r1 = _row_range(n, rows)
+    parts = []
+    for b, lo, hi in _blocks(r0, r1):
+        nb_rows = min(ROW_BLOCK, n - b * ROW_BLOCK)
+        nb = torch.randint(0, n, (nb_rows, deg - 1), generator=_block_generator(seed, 1, b, device), device=device,
+                           dtype=torch.int32)[lo:hi]
+        ids = torch.arange(b * ROW_BLOCK + lo, b * ROW_BLOCK + hi, device=device, dtype=torch.int32)[:, None]
+        parts.append(torch.sort(torch.cat([ids, nb], dim=1), dim=1).values.reshape(-1))
+        del nb
+    cols = torch.cat(parts) if parts else torch.empty(0, dtype=torch.int32, device=device)
+    rowptr = torch.arange(0, (r1 - r0) * deg + 1, deg, device=device, dtype=torch.int64)
+    return CSRGraph(rowptr, cols.contiguous(), n, validate=False)
 
 
-def banded_graph(n: int, deg: int, window: int, seed: int, device="cpu") -> CSRGraph:
+def banded_graph(n: int, deg: int, window: int, seed: int, device="cpu", rows=None) -> CSRGraph:
     """Graph with locality (what a partitioner leaves of a real meta-path graph): row i has
     its self-loop + (deg-1) neighbours uniform in [i-window, i+window] (wrapping).  Under a
     contiguous node partition only ~2*window remote rows per rank are referenced, so the
     halo exchange (dist.HaloPlan) replaces the all-gather."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    off = torch.randint(-window, window + 1, (n, deg - 1), generator=g, device=device, dtype=torch.int32)
-    ids = torch.arange(n, device=device, dtype=torch.int32)[:, None]
-    cols = torch.cat([ids, torch.remainder(ids + off, n)], dim=1)
-    del off
-    cols = torch.sort(cols, dim=1).values
-    rowptr = torch.arange(0, n * deg + 1, deg, device=device, dtype=torch.int64)
-    return CSRGraph(rowptr, cols.reshape(-1).contiguous(), n, validate=False)
+    r0, r1 = _row_range(n, rows)
+    parts = []
+    for b, lo, hi in _blocks(r0, r1):
+        nb_rows = min(ROW_BLOCK, n - b * ROW_BLOCK)
+        off = torch.randint(-window, window + 1, (nb_rows, deg - 1), generator=_block_generator(seed, 2, b, device),
+                            device=device, dtype=torch.int32)[lo:hi]
+        ids = torch.arange(b * ROW_BLOCK + lo, b * ROW_BLOCK + hi, device=device, dtype=torch.int32)[:, None]
+        parts.append(torch.sort(torch.cat([ids, torch.remainder(ids + off, n)], dim=1), dim=1).values.reshape(-1))
+        del off
+    cols = torch.cat(parts) if parts else torch.empty(0, dtype=torch.int32, device=device)
+    rowptr = torch.arange(0, (r1 - r0) * deg + 1, deg, device=device, dtype=torch.int64)
+    return CSRGraph(rowptr, cols.contiguous(), n, validate=False)
 
 
-def powerlaw_graph(n: int, nnz: int, alpha: float, seed: int, device="cpu") -> CSRGraph:
+def powerlaw_graph(n: int, nnz: int, alpha: float, seed: int, device="cpu", rows=None) -> CSRGraph:
     """Skewed variant: row degrees ~ Zipf-like with exponent alpha, scaled to
-    about `nnz` edges, every row keeps its self-loop; neighbours uniform."""
+    about `nnz` edges, every row keeps its self-loop; neighbours uniform.  (The degree vector is
+    drawn for all n rows on the host -- n numbers --, the edges only for the requested rows.)"""
+    r0, r1 = _row_range(n, rows)
     rng = np.random.default_rng(seed)
     w = rng.pareto(alpha - 1.0, size=n) + 1.0
     deg = np.maximum(1, np.floor(w / w.sum() * nnz)).astype(np.int64)
     deg = np.minimum(deg, n)
-    rowptr = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum(deg, out=rowptr[1:])
-    e = int(rowptr[-1])
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    cols = torch.randint(0, n, (e,), generator=g, device=device, dtype=torch.int32)
-    rp = torch.as_tensor(rowptr, device=device)
-    cols[rp[:-1]] = torch.arange(n, device=device, dtype=torch.int32)   # self-loop first
-    return CSRGraph(rp, cols, n, validate=False)
+    rowptr_g = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr_g[1:])
+    parts = []
+    for b, lo, hi in _blocks(r0, r1):
+        b0 = b * ROW_BLOCK
+        b1 = min(b0 + ROW_BLOCK, n)
+        e_blk = int(rowptr_g[b1] - rowptr_g[b0])
+        c = torch.randint(0, n, (e_blk,), generator=_block_generator(seed, 3, b, device), device=device,
+                          dtype=torch.int32)
+        parts.append(c[int(rowptr_g[b0 + lo] - rowptr_g[b0]):int(rowptr_g[b0 + hi] - rowptr_g[b0])])
+    cols = torch.cat(parts) if parts else torch.empty(0, dtype=torch.int32, device=device)
+    rp = torch.as_tensor(rowptr_g[r0:r1 + 1] - rowptr_g[r0], device=device)
+    if r1 > r0:
+        cols[rp[:-1]] = torch.arange(r0, r1, device=device, dtype=torch.int32)   # self-loop first
+    return CSRGraph(rp, cols.contiguous(), n, validate=False)
 
 
 def bernoulli_graph(n: int, density: float, seed: int, device="cpu") -> CSRGraph:
@@ -125,31 +166,44 @@ CONFIGS = {
 }
 
 
-def make_graph(spec, n, seed, device):
+def make_graph(spec, n, seed, device, rows=None):
     kind = spec[0]
     if kind == "regular":
-        return random_regular_graph(n, spec[1], seed, device)
+        return random_regular_graph(n, spec[1], seed, device, rows=rows)
     if kind == "powerlaw":
-        return powerlaw_graph(n, spec[1], spec[2], seed, device)
+        return powerlaw_graph(n, spec[1], spec[2], seed, device, rows=rows)
     if kind == "banded":
-        return banded_graph(n, spec[1], min(spec[2], max(n // 4, 1)), seed, device)
+        return banded_graph(n, spec[1], min(spec[2], max(n // 4, 1)), seed, device, rows=rows)
     if kind == "bernoulli":
-        return bernoulli_graph(n, spec[1], seed, device)
+        g = bernoulli_graph(n, spec[1], seed, device)
+        if rows is None:
+            return g
+        from .dist import _row_block
+        return _row_block(g, int(rows[0]), int(rows[1]), n)
     raise ValueError(kind)
 
 
-def make_workload(name: str, device="cpu", seed: int = 1234, n_override: int | None = None):
+def make_workload(name: str, device="cpu", seed: int = 1234, n_override: int | None = None, rows=None):
     """Returns dict(x (N,F) fp32, graphs [P CSRGraph], labels int32 (N,),
-    train_mask / val_mask uint8 (N,), n, f, c, p)."""
+    train_mask / val_mask uint8 (N,), n, f, c, p).
+    rows = (r0, r1): generate ONLY those rows of every tensor and graph (a rank's shard of a node
+    partition; graphs keep global column ids); block-seeded, so the shards of N ranks concatenate
+    to exactly what rows=None generates."""
     cfg = CONFIGS[name]
     n = int(n_override) if n_override else cfg["n"]
-    graphs = [make_graph(s, n, seed + p, device) for p, s in enumerate(cfg["graphs"])]
-    g = torch.Generator(device=device)
-    g.manual_seed(7)
-    x = torch.randn((n, cfg["f"]), generator=g, device=device, dtype=torch.float32)
-    labels = torch.randint(0, cfg["c"], (n,), generator=g, device=device, dtype=torch.int32)
-    u = torch.rand((n,), generator=g, device=device)
+    r0, r1 = _row_range(n, rows)
+    graphs = [make_graph(s, n, seed + p, device, rows=rows) for p, s in enumerate(cfg["graphs"])]
+    xs, ls, us = [], [], []
+    for b, lo, hi in _blocks(r0, r1):
+        nb_rows = min(ROW_BLOCK, n - b * ROW_BLOCK)
+        g = _block_generator(7, 0, b, device)
+        xs.append(torch.randn((nb_rows, cfg["f"]), generator=g, device=device, dtype=torch.float32)[lo:hi])
+        ls.append(torch.randint(0, cfg["c"], (nb_rows,), generator=g, device=device, dtype=torch.int32)[lo:hi])
+        us.append(torch.rand((nb_rows,), generator=g, device=device)[lo:hi])
+    x = torch.cat(xs) if xs else torch.empty((0, cfg["f"]), device=device)
+    labels = torch.cat(ls) if ls else torch.empty(0, dtype=torch.int32, device=device)
+    u = torch.cat(us) if us else torch.empty(0, device=device)
     train_mask = (u < 0.10).to(torch.uint8)
     val_mask = ((u >= 0.10) & (u < 0.20)).to(torch.uint8)
     return dict(x=x, graphs=graphs, labels=labels, train_mask=train_mask, val_mask=val_mask,
-                n=n, f=cfg["f"], c=cfg["c"], p=len(graphs), name=name)
+                n=n, f=cfg["f"], c=cfg["c"], p=len(graphs), name=name, rows=(r0, r1))

@@ -24,10 +24,13 @@ class HANTrainer:
     def __init__(self, model: HeteGAT_multi, xs, graphs, labels, train_mask, val_mask=None,
                  lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
                  part: NodePartition | None = None, patience=100, max_halo_fraction=0.6,
-                 use_graph=False):
+                 use_graph=False, graphs_local=False):
         """xs: list of P (N_local,F) feature tensors (this rank's rows);
-        graphs: list of P CSRGraph (or dense masks / CSR tuples) -- the GLOBAL graphs when `part` is given
-        (they are sharded here), else the local==global graphs;
+        graphs: list of P CSRGraph (or dense masks / CSR tuples).  Under a partition (`part`) either
+        the GLOBAL graphs (graphs_local=False: each rank keeps its row block; small data sets) or --
+        graphs_local=True, the scalable form -- THIS RANK'S destination rows [row_start, row_end) with
+        global column ids, so that no rank ever holds a global graph; the transposed shards are then
+        built with an all-to-all-v of the edges (NodePartition.shard_local_graph);
         labels int32 (N_local,) class ids; masks uint8/bool (N_local,).
         use_graph: capture one whole epoch (train step + eval forward, ~60 launches) into a
         hipGraph on its second call and replay it afterwards -- for the launch-bound small
@@ -44,7 +47,8 @@ class HANTrainer:
         self.xs = [x.contiguous() for x in xs]
         graphs = [as_graph(g, dev) for g in graphs]     # dense masks / (rowptr, colidx) accepted
         if self.part is not None:
-            sharded = [self.part.shard_graph(g) for g in graphs]
+            sharded = [self.part.shard_local_graph(g) if graphs_local else self.part.shard_graph(g)
+                       for g in graphs]
             self.graphs = [s[0] for s in sharded]
             self.graphs_t = [s[1] for s in sharded]
             # halo exchange where the graph has locality, all-gather where it has none

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HAN_ABI_VERSION 1
+#define HAN_ABI_VERSION 2
 
 #define HAN_E_BADARG   (-1)   /* null pointer, negative size, inconsistent shape.  The forward
                               * entry points return 0 at once for N == 0 (empty tensors may
@@ -148,27 +148,32 @@ int han_node_attn_coefs(const int64_t *rowptr, const int32_t *colidx, const floa
                         int mean_heads, int64_t N, int64_t E, int K, int FP, float slope,
                         float coef_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset, void *stream);
 
+/* Backward tables: ONE fused row per destination i,
+ *   [ g_i : D elements of table_dtype | (f1_i, lse_i, s_i, 0)[k] : 4 fp32 per head k ]
+ * padded to whole 128-B lines; han_gs_row_bytes() gives the row size (K = 8, F' = 8: 384 B with
+ * fp32 g, 256 B with bf16 g).  Under a node partition this is the ONLY table the backward moves
+ * per meta-path (one collective instead of one for g and one for the statistics).            */
+size_t han_gs_row_bytes(int K, int FP, int table_dtype);
+
 /* Backward, step 1 (row-local): from dOut (N,D; row stride dout_stride) and
  * the saved pre/aggp/tsum/f1/lse compute
- *   g = dOut * act'(pre)                    -> g (N,D)
+ *   g = dOut * act'(pre)   (rounded to table_dtype; the sums below use the rounded value)
  *   s_i[k] = g_i[k] . (pre_i - c)[k]
  *   df1_i[k] = g_i[k] . aggp_i[k] - s_i[k] * tsum_i[k]        -> df1 (N,K)
- *   stats_i[k] = (f1, lse, s, 0)                            -> stats (N,K,4)
- *   dc += sum_i g_i  (written, not accumulated)              -> dc (D)
+ *   gs row i = [ g_i | (f1, lse, s, 0)[k] ]                    -> gs (N rows of han_gs_row_bytes())
+ *   dc += sum_i g_i  (written, not accumulated; unrounded g)  -> dc (D)
  * workspace: han_node_attn_bwd_workspace() bytes.                          */
 size_t han_node_attn_bwd_workspace(int64_t N, int K, int FP);
 int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *pre,
                            const float *aggp, const float *tsum, const float *f1,
-                           const float *lse, const float *c, const float *res, void *g,
-                           int table_dtype,
-                           float *stats, float *df1, float *dc, void *workspace,
+                           const float *lse, const float *c, const float *res, void *gs,
+                           int table_dtype, float *df1, float *dc, void *workspace,
                            size_t workspace_bytes, int64_t N, int K, int FP, int activation,
                            void *stream);
 
 /* Backward, step 2 (gather over the TRANSPOSED graph, no float atomics):
  * colptr (NS+1) / rowidx (E) list, for each source row j owned by this call,
- * the destination rows i (indices into the NT-row tables g (NT,D) and
- * stats (NT,K,4)).  Produces for each source j
+ * the destination rows i (indices into the NT-row fused table gs).  Produces for each source j
  *   df2_j[k] = sum_i dl_ij,   dH_j = mH_j/keep * sum_i drop(alpha_ij) g_i
  *                                     + df1_j a1 + df2_j a2
  * H (keep bits in bit 0 when fts_drop > 0), f2, df1 are the NS local source rows;
@@ -177,8 +182,7 @@ int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *
  * keys (must match the forward).  edge_val (E) or NULL: the forward's adjacency
  * values permuted into the transposed graph's order.                         */
 int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const float *edge_val,
-                           const void *g,
-                           const float *stats, const int32_t *table_gid, const void *H,
+                           const void *gs, const int32_t *table_gid, const void *H,
                            int table_dtype, const float *f2,
                            const float *df1, const float *a1, const float *a2,
                            float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,

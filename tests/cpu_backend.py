@@ -33,7 +33,6 @@ def _rows_of(graph):
 
 def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_offset=0,
                 table_dtype=torch.float32, seed_dev=None):
-    assert table_dtype == torch.float32, "the CPU stand-in covers fp32 tables only"
     seed = _eff(seed, seed_dev)
     N, F = X.shape
     K, FP = a1.shape
@@ -45,9 +44,12 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
     else:
         H = x @ w
     H = H.to(torch.float32)
+    it = torch.int32
+    if table_dtype == torch.bfloat16:       # bf16 storage: round to nearest even, keep bit = bit 0 of the bf16
+        H, it = H.to(torch.bfloat16), torch.int16
     if fts_drop > 0:      # keep bits ride in mantissa bit 0 (han_project_fwd contract)
-        bits = torch.tensor(rng_ref.fts_mask(seed, N, D, fts_drop, row_offset)).to(torch.int32)
-        H = ((H.view(torch.int32) & ~1) | bits).view(torch.float32)
+        bits = torch.tensor(rng_ref.fts_mask(seed, N, D, fts_drop, row_offset)).to(it)
+        H = ((H.view(it) & ~1) | bits).view(H.dtype)
     hk = _f64(H).view(N, K, FP)
     f1 = (hk * _f64(a1)[None]).sum(-1) + _f64(b1)
     f2 = (hk * _f64(a2)[None]).sum(-1) + _f64(b2)
@@ -116,7 +118,7 @@ def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset,
     hd = h
     if fts_drop > 0:
         keepf = rng_ref.keep_prob32(fts_drop)
-        bits = (H_tab.view(torch.int32) & 1).to(torch.float64)
+        bits = (H_tab.view(torch.int16 if H_tab.dtype == torch.bfloat16 else torch.int32) & 1).to(torch.float64)
         hd = h * bits / keepf
     return rows, cols, alpha, am, sg, lse, hd
 
@@ -148,25 +150,45 @@ def node_attn_fwd(graph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=
     return out, saved
 
 
+def _gs_row_bytes(K, table_dtype=torch.float32):
+    gb = D * (2 if table_dtype == torch.bfloat16 else 4)
+    return ((gb + 16 * K + 127) // 128) * 128
+
+
+def gs_row_bytes(K=8, FP=8, table_dtype=torch.float32):
+    return _gs_row_bytes(K, table_dtype)
+
+
+def gs_views(gs, K=8, FP=8, table_dtype=torch.float32):
+    gb = D * (2 if table_dtype == torch.bfloat16 else 4)
+    return gs[:, :gb].view(table_dtype), gs[:, gb:gb + 16 * K].view(torch.float32).unflatten(1, (K, 4))
+
+
 def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=1, K=8, FP=8,
-                       table_dtype=torch.float32, res=None, dc_out=None):
+                       table_dtype=torch.float32, res=None, dc_out=None, gs_out=None):
     N = pre.shape[0]
     p = _f64(pre)
     da = torch.where(p <= 0, torch.exp(p), torch.ones_like(p)) if activation == 1 else torch.ones_like(p)
     g = _f64(dOut) * da
+    dc = g.sum(0)
+    g = _f64(g.to(torch.float32).to(table_dtype))     # the stored g is what both backward halves use
     agg = p - _f64(c) - (_f64(res) if res is not None else 0.0)
     s = (g * agg).view(N, K, FP).sum(-1)
     dp = (g * _f64(aggp)).view(N, K, FP).sum(-1)
     df1 = dp - s * _f64(tsum)
     stats = torch.stack([_f64(f1), _f64(lse), s, torch.zeros_like(s)], dim=-1)
-    return (g.to(torch.float32), stats.to(torch.float32).contiguous(), df1.to(torch.float32),
-            _put(dc_out, g.sum(0).to(torch.float32)))
+    gs = gs_out if gs_out is not None else torch.zeros((N, _gs_row_bytes(K, table_dtype)), dtype=torch.uint8)
+    gv, sv = gs_views(gs, K, FP, table_dtype)
+    gv.copy_(g.to(table_dtype))
+    sv.copy_(stats.to(torch.float32))
+    return gs, df1.to(torch.float32), _put(dc_out, dc.to(torch.float32))
 
 
-def node_attn_bwd_cols(graph_t, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=0.0, fts_drop=0.0,
+def node_attn_bwd_cols(graph_t, gs_tab, H, f2, df1, a1, a2, coef_drop=0.0, fts_drop=0.0,
                        seed=0, src_offset=0, dst_offset=0, table_gid=None, seed_dev=None):
     seed = _eff(seed, seed_dev)
     K, FP = a1.shape
+    g_tab, stats_tab = gs_views(gs_tab, K, FP, H.dtype)
     NS = graph_t.n_rows
     src = _rows_of(graph_t)                       # local source j per transposed edge
     dst = graph_t.colidx.long()                   # destination i (table index)
@@ -184,9 +206,10 @@ def node_attn_bwd_cols(graph_t, g_tab, stats_tab, H, f2, df1, a1, a2, coef_drop=
     h64 = _f64(H)
     mk = torch.ones_like(h64)
     if fts_drop > 0:
-        mk = (H.view(torch.int32) & 1).to(torch.float64) / rng_ref.keep_prob32(fts_drop)
+        mk = (H.view(torch.int16 if H.dtype == torch.bfloat16 else torch.int32) & 1).to(torch.float64) \
+            / rng_ref.keep_prob32(fts_drop)
     hd = (h64 * mk).view(NS, K, FP)
-    gk = _f64(g_tab).view(-1, K, FP)[dst]                          # (E,K,FP)
+    gk = _f64(g_tab).reshape(-1, K, FP)[dst]                       # (E,K,FP)
     dot = (gk * hd[src]).sum(-1)
     dl = alpha * sg * (am * dot - st[dst, :, 2])
     df2 = torch.zeros((NS, K), dtype=torch.float64).index_add(0, src, dl)
@@ -258,6 +281,7 @@ def l2_half_sumsq(param):
 
 
 _NAMES = ("project_fwd", "project_bwd", "project_bwd_input", "node_attn_fwd", "node_attn_bwd_rows", "node_attn_bwd_cols",
+          "gs_row_bytes", "gs_views",
           "score_param_bwd", "sem_attn_fwd", "sem_attn_bwd", "classifier_loss", "adam_step",
           "l2_half_sumsq")
 

@@ -63,11 +63,21 @@ def run(rank, world, device, epochs, drop, out_path, port, use_cpu_backend):
     x, graphs, labels, tm, vm, (n, f, p, c) = build_problem(dev)
     hrng.manual_seed(77)
     gen = torch.Generator().manual_seed(3)
-    model = HeteGAT_multi().build(p, f, c, device=dev, generator=gen)
+    bf16 = os.environ.get("HAN_TEST_BF16") == "1"            # configs[4] storage: X, H and g tables in bf16
+    model = HeteGAT_multi().build(p, f, c, device=dev, generator=gen,
+                                  table_dtype=torch.bfloat16 if bf16 else torch.float32)
+    if bf16:
+        x = x.to(torch.bfloat16)
     part = NodePartition(n, rank, world) if (world > 1 or forced) else None
     loc = (lambda t: part.local_rows(t).contiguous()) if part is not None else (lambda t: t)
+    local = part is not None and os.environ.get("HAN_TEST_LOCAL") == "1"
+    if local:      # the scalable form: a rank only ever sees its own destination rows (global column ids)
+        from han_amd.dist import _row_block
+        graphs = [_row_block(g, part.row_start, part.row_end, n) for g in graphs]
+    # HAN_TEST_ALLGATHER=1: a negative halo threshold sends every meta-path down the all-gather path
     tr = HANTrainer(model, [loc(x)] * p, graphs, loc(labels), loc(tm), loc(vm), attn_drop=drop,
-                    ffd_drop=drop, part=part)
+                    ffd_drop=drop, part=part, graphs_local=local,
+                    max_halo_fraction=-1.0 if os.environ.get("HAN_TEST_ALLGATHER") == "1" else 0.6)
     hist = []
     for _ in range(epochs):
         hist.append(tr.reduce_metrics(*tr.epoch()))

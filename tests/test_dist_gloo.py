@@ -74,3 +74,34 @@ def test_eight_gloo_ranks_mixed_exchange_modes(tmp_path):
     assert 0 < int(b["halo_plans"]) < 4
     assert np.abs(a["flat"] - b["flat"]).max() < 1e-5
     assert np.abs(a["hist"] - b["hist"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("bf16,port", [("0", 29781), ("1", 29791)])
+def test_eight_gloo_ranks_all_gather_everywhere_from_local_rows(tmp_path, bf16, port):
+    """world_size 8, N = 257 (uneven shards), every meta-path forced onto the ALL-GATHER path (what the
+    uniformly random SYN-1M / SYN-10M graphs use), every rank holding only its OWN graph rows
+    (NodePartition.shard_local_graph: transposed shards from an all-to-all-v of the edges) and -- bf16 --
+    the configs[4] storage (bf16 X / H tables, fused bf16 [g | stats] rows on the wire).  Must equal the
+    single-process run on the global graph."""
+    one, eight = str(tmp_path / "one.npz"), str(tmp_path / "eight.npz")
+    env = {"OMP_NUM_THREADS": "1", "HAN_TEST_ALLGATHER": "1", "HAN_TEST_LOCAL": "1", "HAN_TEST_BF16": bf16}
+    _launch(1, 2, 0.6, one, port, env)
+    _launch(8, 2, 0.6, eight, port + 2, env)
+    a, b = np.load(one), np.load(eight)
+    assert int(b["halo_plans"]) == 0
+    tol = 1e-5 if bf16 == "0" else 2e-4      # bf16: a sum-order difference can flip one stored rounding
+    assert np.abs(a["flat"] - b["flat"]).max() < tol
+    assert np.abs(a["hist"] - b["hist"]).max() < tol
+
+
+def test_two_gloo_ranks_local_rows_halo_weighted(tmp_path):
+    """Rank-local rows + halo plans + sp_attn_head edge values: the values must travel with the edges
+    through the all-to-all-v that builds the transposed shards."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    env = {"HAN_TEST_GRAPH": "band", "HAN_TEST_WEIGHTED": "1", "HAN_TEST_LOCAL": "1"}
+    _launch(1, 2, 0.6, one, 29801, env)
+    _launch(2, 2, 0.6, two, 29803, env)
+    a, b = np.load(one), np.load(two)
+    assert int(b["halo_plans"]) == 4
+    assert np.abs(a["flat"] - b["flat"]).max() < 1e-5
+    assert np.abs(a["hist"] - b["hist"]).max() < 1e-5

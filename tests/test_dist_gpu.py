@@ -57,3 +57,19 @@ def test_halo_exchange_two_ranks_real_kernels(dev, tmp_path):
     assert int(b["halo_plans"]) == 4
     assert np.abs(a["flat"] - b["flat"]).max() < 2e-5
     assert np.abs(a["hist"] - b["hist"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("bf16", ["0", "1"])
+def test_local_rows_all_gather_two_ranks_real_kernels(dev, tmp_path, bf16):
+    """Every rank holds only its own graph rows (transposed shards from the edge all-to-all-v), every
+    meta-path on the all-gather path, fp32 and the configs[4] bf16 storage (fused bf16 [g | stats] rows
+    and bf16 H tables on the wire), with dropout, on the real kernels; equals the single-process run."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    env = {"HAN_TEST_ALLGATHER": "1", "HAN_TEST_LOCAL": "1", "HAN_TEST_BF16": bf16}
+    _launch(1, 3, 0.6, one, 29641, env)
+    _launch(2, 3, 0.6, two, 29643, env)
+    a, b = np.load(one), np.load(two)
+    assert int(b["halo_plans"]) == 0
+    tol = 2e-5 if bf16 == "0" else 5e-4
+    assert np.abs(a["flat"] - b["flat"]).max() < tol
+    assert np.abs(a["hist"] - b["hist"]).max() < tol

@@ -954,8 +954,9 @@ def test_syn1m_size_independent_properties(dev):
     _, saved = ops.node_attn_fwd(g, H1, zero8, z, torch.zeros(8, device=dev), c, train=True)
     pre, lse, aggp, tsum = saved
     dOut = torch.randn((n, 64), device=dev, generator=gen)
-    gg, stats, df1, dc = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, zero8, lse, c)
-    dH, df2 = ops.node_attn_bwd_cols(g.transpose(), gg, stats, H1, zero8, df1, z, z)
+    gs, df1, dc = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, zero8, lse, c)
+    gg, stats = ops.gs_views(gs)
+    dH, df2 = ops.node_attn_bwd_cols(g.transpose(), gs, H1, zero8, df1, z, z)
     assert abs(float(dH.double().sum()) - float(gg.double().sum())) < 1e-3 * float(gg.double().abs().sum()) ** 0.5 + 1.0
     assert float((dc.double() - gg.double().sum(0)).abs().max()) < 5e-2
 
@@ -1027,17 +1028,14 @@ def test_bf16_mode_forward_backward(dev, drop, P):
         assert rel_err(getattr(model, k).grad.cpu().numpy(), gq[k]) < 1e-2, k
     # (b) against the plain float64 oracle: the price of bf16 storage itself (~0.4 % per stored element,
     # ~1.2 % in training where the lowest mantissa bit carries the keep bit -- an effective 6-bit
-    # mantissa).  The cancellation-dominated score gradients (a1, b1, b2: sums of softmax-gradient terms
-    # that nearly cancel) are compared on the scale of the projection gradient they feed into.
+    # mantissa).  Informational bound; (a) is the parity statement.  The score gradients (a1, b1, b2)
+    # are sums of softmax-gradient terms that nearly cancel, so storage noise shows up larger there
+    # (measured: up to 10 % of the largest element at P = 8 with dropout, 1-3 % elsewhere).
     assert rel_err(logits.cpu().numpy(), lg_ref) < 4e-2
     assert abs(float(loss) - loss_ref) < 4e-2 * max(1.0, abs(loss_ref))
-    wscale = np.abs(gref["W"]).max()
     for k in ht.PARAM_ORDER:
         got = getattr(model, k).grad.cpu().numpy()
-        if k in ("a1", "b1", "b2"):
-            assert np.abs(got - gref[k]).max() < 6e-2 * max(np.abs(gref[k]).max(), 0.1 * wscale), k
-        else:
-            assert rel_err(got, gref[k]) < 6e-2, k
+        assert rel_err(got, gref[k]) < (0.2 if k in ("a1", "b1", "b2") else 6e-2), k
 
 
 def _bf16_to_f64(t):
@@ -1137,13 +1135,14 @@ def test_syn10m_bf16_table_full_size(dev):
     # (6) backward at full size: row-local half, then the transposed-graph gather
     a1 = torch.randn((8, 8), device=dev, generator=gen) * 0.5
     dOut = torch.randint(-4, 5, (n, 64), device=dev, generator=gen).float()     # exact in the bf16 g table
-    gg, stats, df1, dc = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ops.ACT_IDENTITY,
-                                                table_dtype=bf)
+    gs, df1, dc = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ops.ACT_IDENTITY,
+                                         table_dtype=bf)
+    gg, stats = ops.gs_views(gs, 8, 8, bf)
     assert torch.equal(gg.float(), dOut)
     gt = g.transpose()
     f2 = (Hr.float().view(n, 8, 8) * a2[None]).sum(-1) + b2[None]
-    dH, df2 = ops.node_attn_bwd_cols(gt, gg, stats, Hr, f2, df1, a1, a2, coef_drop=drop, fts_drop=drop, seed=seed)
-    dHb, df2b = ops.node_attn_bwd_cols(gt, gg, stats, Hr, f2, df1, a1, a2, coef_drop=drop, fts_drop=drop, seed=seed)
+    dH, df2 = ops.node_attn_bwd_cols(gt, gs, Hr, f2, df1, a1, a2, coef_drop=drop, fts_drop=drop, seed=seed)
+    dHb, df2b = ops.node_attn_bwd_cols(gt, gs, Hr, f2, df1, a1, a2, coef_drop=drop, fts_drop=drop, seed=seed)
     assert torch.equal(dH, dHb) and torch.equal(df2, df2b)
     del dHb, df2b
     # sampled source rows j against the formulas of SURVEY.md 8a "Backward":
@@ -1170,13 +1169,14 @@ def test_syn10m_bf16_table_full_size(dev):
         dH_ref = acc * kb / keep + df1[j].cpu().numpy().astype(np.float64)[:, None] * a1n + df2_ref[:, None] * a2n
         assert np.abs(df2[j].cpu().numpy() - df2_ref).max() < 2e-3 * max(1.0, np.abs(df2_ref).max())
         assert np.abs(dH[j].cpu().numpy().reshape(8, 8) - dH_ref).max() < 2e-3 * max(1.0, np.abs(dH_ref).max())
-    del dH, df2, stats, gg
+    del dH, df2, stats, gg, gs
     # (7) sum_j dH_j = sum_i g_i under uniform attention, no dropout (a = 0, f1 = 0)
     zero8 = torch.zeros((n, 8), device=dev)
     _, saved = ops.node_attn_fwd(g, H1, zero8, z8, torch.zeros(8, device=dev), c, train=True)
     pre, lse, aggp, tsum = saved
-    gg, stats, df1, dc = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, zero8, lse, c, table_dtype=bf)
-    dH, _ = ops.node_attn_bwd_cols(gt, gg, stats, H1, zero8, df1, z8, z8)
+    gs, df1, dc = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, zero8, lse, c, table_dtype=bf)
+    gg, _ = ops.gs_views(gs, 8, 8, bf)
+    dH, _ = ops.node_attn_bwd_cols(gt, gs, H1, zero8, df1, z8, z8)
     tot = float(gg.double().abs().sum())
     assert abs(float(dH.double().sum()) - float(gg.double().sum())) < 1e-6 * tot + 1.0
     assert float((dc.double() - gg.double().sum(0)).abs().max()) < 1e-6 * tot / 64 + 1.0

@@ -44,12 +44,12 @@ def train_variants(dev, sizes=(1_000_000, 4_000_000)):
             tt = timeit(lambda: ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=0.6,
                                                   fts_drop=0.6, seed=3))
             _, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=0.6, fts_drop=0.6, seed=3)
-            gg, stats, df1, dc = ops.node_attn_bwd_rows(dOut, sv[0], sv[2], sv[3], f1, sv[1], c, table_dtype=tdt)
-            tb = timeit(lambda: ops.node_attn_bwd_cols(gt, gg, stats, H, f2, df1, a1, a2, coef_drop=0.6,
+            gs, df1, dc = ops.node_attn_bwd_rows(dOut, sv[0], sv[2], sv[3], f1, sv[1], c, table_dtype=tdt)
+            tb = timeit(lambda: ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, coef_drop=0.6,
                                                        fts_drop=0.6, seed=3))
             print(json.dumps({"N": n, "tables": tag, "fwd_eval_ms": round(te, 3), "fwd_train_ms": round(tt, 3),
                               "bwd_cols_ms": round(tb, 3)}), flush=True)
-            del H, gg, stats, sv
+            del H, gs, sv
         del g, gt
         torch.cuda.empty_cache()
 

@@ -66,11 +66,11 @@ def main():
             _, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=0.6, fts_drop=0.6, seed=3)
             pre, lse, aggp, tsum = sv
             dOut = rnd(n, 64)
-            gg, stats, df1, dc = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, table_dtype=tdt)
+            gs, df1, dc = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, table_dtype=tdt)
             t = timeit(lambda: ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, table_dtype=tdt))
             print(json.dumps({"kernel": f"k2 bwd rows {tag}", "ms": round(t, 4)}))
             for cd in (0.0, 0.6):
-                t = timeit(lambda: ops.node_attn_bwd_cols(gt, gg, stats, H, f2, df1, a1, a2, coef_drop=cd,
+                t = timeit(lambda: ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, coef_drop=cd,
                                                           fts_drop=0.6, seed=3))
                 print(json.dumps({"kernel": f"k2 bwd cols {tag} coef_drop={cd}", "ms": round(t, 4)}))
         del g, gt, X, H

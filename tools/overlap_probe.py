@@ -34,8 +34,8 @@ def main():
     def k2t(): ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=0.6, fts_drop=0.6, seed=7)
     def k2e(): ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out)
     _, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=0.6, fts_drop=0.6, seed=7)
-    gg, stats, df1, _ = ops.node_attn_bwd_rows(dH, sv[0], sv[2], sv[3], f1, sv[1], c)
-    def k2b(): ops.node_attn_bwd_cols(gt, gg, stats, H, f2, df1, a1, a2, coef_drop=0.6, fts_drop=0.6, seed=7)
+    gs, df1, _ = ops.node_attn_bwd_rows(dH, sv[0], sv[2], sv[3], f1, sv[1], c)
+    def k2b(): ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, coef_drop=0.6, fts_drop=0.6, seed=7)
 
     def wall(fn, reps=5):
         fn(); torch.cuda.synchronize()
