@@ -27,15 +27,19 @@ struct ClsArgs {
 
 // CM = compile-time bound on the class count (4, 8 or 16): every per-class loop is
 // unrolled to CM, so small C does not pay for 16 shuffle reductions per row.
-template <bool BWD, int CM>
+// NV = float4 column groups per lane: the embedding width is D = 64*NV (lane q of a 16-lane
+// group owns columns 64v + 4q .. 4q+3, v < NV); NV = 2 serves the 128-wide embeddings.
+template <bool BWD, int CM, int NV>
 __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
-    __shared__ float Wm[64 * MAXC];
+    constexpr int D = 64 * NV;
+    constexpr int NT = 4 * NV;        // features per lane
+    __shared__ float Wm[D * MAXC];
     __shared__ float bm[MAXC];
     const int C = a.C;
     const float invh = 1.f / (float)a.HC;
-    for (int i = threadIdx.x; i < 64 * C; i += 256) {
+    for (int i = threadIdx.x; i < D * C; i += 256) {
         float s = 0.f;
-        for (int h = 0; h < a.HC; ++h) s += a.Wc[(int64_t)h * 64 * C + i];
+        for (int h = 0; h < a.HC; ++h) s += a.Wc[(int64_t)h * D * C + i];
         Wm[i] = s * invh;
     }
     if (threadIdx.x < C) {
@@ -47,31 +51,38 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
     const int q = threadIdx.x & 15;
     const int64_t grp0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int64_t ngrp = (int64_t)gridDim.x * 16;
-    float dW[4][CM];
+    float dW[NT][CM];
     float dbacc[CM];
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
         dbacc[c] = 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dW[t][c] = 0.f;
+        for (int t = 0; t < NT; ++t) dW[t][c] = 0.f;
     }
     float loss_acc = 0.f, acc_acc = 0.f;
-    // this lane's 4 rows of the averaged classifier matrix and the biases, in registers
-    float wq[4][CM], bq[CM];
+    // this lane's rows of the averaged classifier matrix and the biases, in registers;
+    // feature of slot t: 64*(t/4) + 4*q + t%4
+    float wq[NT][CM], bq[CM];
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
         bq[c] = c < C ? bm[c] : 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) wq[t][c] = c < C ? Wm[(4 * q + t) * C + c] : 0.f;
+        for (int t = 0; t < NT; ++t) wq[t][c] = c < C ? Wm[(64 * (t >> 2) + 4 * q + (t & 3)) * C + c] : 0.f;
     }
     for (int64_t row = grp0; row < a.N; row += ngrp) {
-        const float4_t z4 = *reinterpret_cast<const float4_t *>(a.Z + row * 64 + 4 * q);
+        float z[NT];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4_t z4 = *reinterpret_cast<const float4_t *>(a.Z + row * D + 64 * v + 4 * q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) z[4 * v + t] = z4[t];
+        }
         float lg[CM];
 #pragma unroll
         for (int c = 0; c < CM; ++c) {
             float s = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) s += z4[t] * wq[t][c];
+            for (int t = 0; t < NT; ++t) s += z[t] * wq[t][c];
             s = han_row16_sum(s);
             lg[c] = c < C ? s + bq[c] : HAN_NEG_BIG;
         }
@@ -101,26 +112,34 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
         if (BWD) {
             const float inv = 1.f / se;
             float dl[CM];
-            float4_t dz = {0.f, 0.f, 0.f, 0.f};
+            float dz[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) dz[t] = 0.f;
 #pragma unroll
             for (int c = 0; c < CM; ++c) {
                 dl[c] = c < C ? w * (__expf(lg[c] - mx) * inv - (c == lab ? 1.f : 0.f)) : 0.f;
                 if (c < C) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < NT; ++t) {
                         dz[t] += dl[c] * wq[t][c];
-                        dW[t][c] += z4[t] * dl[c];
+                        dW[t][c] += z[t] * dl[c];
                     }
                     if (q == 0) dbacc[c] += dl[c];
                 }
             }
-            *reinterpret_cast<float4_t *>(a.dZ + row * 64 + 4 * q) = dz;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float4_t o;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = dz[4 * v + t];
+                *reinterpret_cast<float4_t *>(a.dZ + row * D + 64 * v + 4 * q) = o;
+            }
         }
     }
     // block reduction: 16 groups -> one slab row.  Serialise the groups through
     // Wm-sized scratch (one group adds at a time; 16 barriers, once per block).
     __syncthreads();
-    float *scr = Wm;                  // [64*C]
+    float *scr = Wm;                  // [D*C]
     __shared__ float sc2[MAXC + 2];   // db | loss | acc
     const int grp = threadIdx.x >> 4;
     for (int r = 0; r < 16; ++r) {
@@ -130,8 +149,8 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
                 for (int c = 0; c < CM; ++c) {
                     if (c < C) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int idx = (4 * q + t) * C + c;
+                        for (int t = 0; t < NT; ++t) {
+                            const int idx = (64 * (t >> 2) + 4 * q + (t & 3)) * C + c;
                             scr[idx] = (r == 0 ? 0.f : scr[idx]) + dW[t][c];
                         }
                         if (q == 0) sc2[c] = (r == 0 ? 0.f : sc2[c]) + dbacc[c];
@@ -145,14 +164,28 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
         }
         __syncthreads();
     }
-    const int width = 64 * C + C + 2;
+    const int width = D * C + C + 2;
     float *out = a.slab + (int64_t)blockIdx.x * width;
     for (int i = threadIdx.x; i < width; i += 256) {
         float v;
-        if (i < 64 * C) v = BWD ? scr[i] : 0.f;
-        else if (i < 64 * C + C) v = BWD ? sc2[i - 64 * C] : 0.f;
-        else v = sc2[MAXC + (i - 64 * C - C)];
+        if (i < D * C) v = BWD ? scr[i] : 0.f;
+        else if (i < D * C + C) v = BWD ? sc2[i - D * C] : 0.f;
+        else v = sc2[MAXC + (i - D * C - C)];
         out[i] = v;
+    }
+}
+
+template <int NV>
+static void launch_classifier(const ClsArgs &a, bool bwd, int grid, hipStream_t st) {
+    if (a.C <= 4) {
+        if (bwd) classifier_kernel<true, 4, NV><<<grid, 256, 0, st>>>(a);
+        else classifier_kernel<false, 4, NV><<<grid, 256, 0, st>>>(a);
+    } else if (a.C <= 8) {
+        if (bwd) classifier_kernel<true, 8, NV><<<grid, 256, 0, st>>>(a);
+        else classifier_kernel<false, 8, NV><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (bwd) classifier_kernel<true, 16, NV><<<grid, 256, 0, st>>>(a);
+        else classifier_kernel<false, 16, NV><<<grid, 256, 0, st>>>(a);
     }
 }
 
@@ -225,8 +258,8 @@ __global__ __launch_bounds__(256) void bias_fill_kernel(const float *bias, int64
 }  // namespace
 
 extern "C" size_t han_classifier_workspace(int64_t N, int D, int C, int HC) {
-    (void)N; (void)D; (void)HC;
-    return (size_t)kClsBlocks * (size_t)(64 * C + C + 2) * sizeof(float);
+    (void)N; (void)HC;
+    return (size_t)kClsBlocks * (size_t)(D * C + C + 2) * sizeof(float);
 }
 
 extern "C" int han_classifier_loss(const float *Z, const float *Wc, const float *bc, const int32_t *labels,
@@ -235,7 +268,7 @@ extern "C" int han_classifier_loss(const float *Z, const float *Wc, const float 
                                    int64_t N, int D, int C, int HC, void *stream) {
     if (!Z || !Wc || !bc || !labels || !mask || !logits || !loss_acc || !workspace || N < 0 || HC <= 0)
         return HAN_E_BADARG;
-    if (D != HAN_D || C < 1 || C > MAXC) return HAN_E_UNSUPPORTED;
+    if ((D != 64 && D != 128) || C < 1 || C > MAXC) return HAN_E_UNSUPPORTED;
     const bool bwd = dZ != nullptr;
     if (bwd && (!dWc || !dbc)) return HAN_E_BADARG;
     if (workspace_bytes < han_classifier_workspace(N, D, C, HC)) return HAN_E_WORKSPACE;
@@ -244,31 +277,23 @@ extern "C" int han_classifier_loss(const float *Z, const float *Wc, const float 
     a.Z = Z; a.Wc = Wc; a.bc = bc; a.labels = labels; a.mask = mask; a.row_weight = row_weight;
     a.logits = logits; a.dZ = dZ; a.slab = (float *)workspace; a.N = N; a.C = C; a.HC = HC;
     const int grid = han_grid_for(N > 0 ? N : 1, 16, kClsBlocks);
-    if (C <= 4) {
-        if (bwd) classifier_kernel<true, 4><<<grid, 256, 0, st>>>(a);
-        else classifier_kernel<false, 4><<<grid, 256, 0, st>>>(a);
-    } else if (C <= 8) {
-        if (bwd) classifier_kernel<true, 8><<<grid, 256, 0, st>>>(a);
-        else classifier_kernel<false, 8><<<grid, 256, 0, st>>>(a);
-    } else {
-        if (bwd) classifier_kernel<true, 16><<<grid, 256, 0, st>>>(a);
-        else classifier_kernel<false, 16><<<grid, 256, 0, st>>>(a);
-    }
+    if (D == 128) launch_classifier<2>(a, bwd, grid, st);
+    else launch_classifier<1>(a, bwd, grid, st);
     HAN_CHECK_LAUNCH();
-    const int width = 64 * C + C + 2;
+    const int width = D * C + C + 2;
     // loss / accuracy (the last two slab columns), then the head gradients: every
     // head receives the same (1/HC)-scaled gradient (models/gat.py:72 averages them)
     const float *slab = (const float *)workspace;
-    hipError_t e = han_reduce_slabs(slab + 64 * C + C, grid, width, 2, han_reduce_to(loss_acc, 2), st);
+    hipError_t e = han_reduce_slabs(slab + D * C + C, grid, width, 2, han_reduce_to(loss_acc, 2), st);
     if (e != hipSuccess) return (int)e;
     if (bwd) {
-        HanReduceOut ow = han_reduce_to(dWc, 64 * C);
-        ow.scale = 1.f / (float)HC; ow.rep = HC; ow.rep_stride = (int64_t)64 * C;
-        e = han_reduce_slabs(slab, grid, width, 64 * C, ow, st);
+        HanReduceOut ow = han_reduce_to(dWc, D * C);
+        ow.scale = 1.f / (float)HC; ow.rep = HC; ow.rep_stride = (int64_t)D * C;
+        e = han_reduce_slabs(slab, grid, width, D * C, ow, st);
         if (e != hipSuccess) return (int)e;
         HanReduceOut ob = han_reduce_to(dbc, C);
         ob.scale = 1.f / (float)HC; ob.rep = HC; ob.rep_stride = C;
-        e = han_reduce_slabs(slab + 64 * C, grid, width, C, ob, st);
+        e = han_reduce_slabs(slab + D * C, grid, width, C, ob, st);
         if (e != hipSuccess) return (int)e;
     }
     return 0;

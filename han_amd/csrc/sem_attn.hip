@@ -662,6 +662,271 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_kernel(const float *__r
     for (int i = threadIdx.x; i < 64 * A + 2 * A; i += 256) out[i] = red[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wider embeddings: D = 128 (e.g. hid_units = [16] with 8 heads, models/gat.py:42-57 leaves both
+// free).  The block-level kernels above with the feature width as a template parameter
+// (D = 16*DT); the D = 64 kernels stay as they are.  The backward keeps D*AS/64 dW accumulators
+// per lane, so at D = 128 it runs over the attention space in slices of AS = 64 columns
+// (one launch per slice; slices after the first ADD their dM contribution).
+// ---------------------------------------------------------------------------------------------
+template <int CA, int DT>
+__global__ __launch_bounds__(256) void sem_attn_fwd_gen_kernel(const float *__restrict__ M, const float *Wg,
+                                                               const float *bw, const float *uw, float *Z,
+                                                               float *beta, int64_t N, int P) {
+    constexpr int D = 16 * DT;
+    constexpr int NF = D / 64;       // features per lane in the lane = feature phases
+    constexpr int A = 64 * CA;
+    constexpr int TA = A / 16;
+    constexpr int WLD = A + 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Wl = smem;                 // [D][WLD]
+    float *sc = smem + D * WLD;       // [2][ROWS]
+    for (int i = threadIdx.x; i < D * A; i += 256) Wl[(i / A) * WLD + (i % A)] = Wg[i];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    float bcol[TA], ucol[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        bcol[t] = bw[16 * t + l15];
+        ucol[t] = uw[16 * t + l15];
+    }
+    __syncthreads();
+    const int NB = ROWS / P;
+    const int64_t nchunks = (N + NB - 1) / NB;
+    int buf = 0;
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x, buf ^= 1) {
+        const int64_t node0 = ch * NB;
+        const int nodes = (int)((N - node0) < NB ? (N - node0) : NB);
+        const int rows = nodes * P;
+        const int64_t row0 = node0 * P;
+        {
+            const int lr = 16 * w + l15;
+            const float *mrow = M + (row0 + (lr < rows ? lr : rows - 1)) * D + l4;
+            f32x4 acc[TA];
+#pragma unroll
+            for (int t = 0; t < TA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int ks = 0; ks < D / 4; ++ks) {
+                const float a = mrow[4 * ks];
+                const float *wr = Wl + (4 * ks + l4) * WLD + l15;
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wr[16 * t], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < TA; ++t) s += fast_tanh(acc[t][reg] + bcol[t]) * ucol[t];
+                s = han_row16_sum(s);
+                if (l15 == 0) sc[buf * ROWS + 16 * w + 4 * l4 + reg] = s;
+            }
+        }
+        __syncthreads();
+        for (int nd = w; nd < nodes; nd += 4) {
+            const int64_t n = node0 + nd;
+            float zacc[NF], mrun = HAN_NEG_BIG, lrun = 0.f, sreg = 0.f;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) zacc[f] = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const float s = sc[buf * ROWS + nd * P + p];
+                if (lane == p) sreg = s;
+                const float mn = fmaxf(mrun, s);
+                const float scl = __expf(mrun - mn), pe = __expf(s - mn);
+                lrun = lrun * scl + pe;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) zacc[f] = zacc[f] * scl + pe * M[(n * P + p) * D + lane + 64 * f];
+                mrun = mn;
+            }
+            const float inv = 1.f / lrun;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) Z[n * D + lane + 64 * f] = zacc[f] * inv;
+            if (lane < P) beta[n * P + lane] = __expf(sreg - mrun) * inv;
+        }
+    }
+}
+
+// slab row per block: [D*A] dW | [A] db | [A] du   (A = the FULL attention width; this launch owns
+// the columns [a_off, a_off + 64))
+template <int DT>
+__global__ __launch_bounds__(256) void sem_attn_bwd_gen_kernel(const float *__restrict__ M, const float *Wg,
+                                                               const float *bw, const float *uw,
+                                                               const float *beta, const float *dZ, float *dM,
+                                                               float *slab, int64_t N, int P, int A, int a_off) {
+    constexpr int D = 16 * DT;
+    constexpr int NF = D / 64;
+    constexpr int AS = 64;           // columns of the attention space per launch
+    constexpr int TA = AS / 16;
+    constexpr int WLD1 = AS + 16;
+    constexpr int WLD2 = AS + 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *W1 = smem;                         // [D][WLD1]
+    float *W2 = W1 + D * WLD1;                // [D][WLD2]
+    float *dp = W2 + D * WLD2;                // [4 waves][16][WLD2]
+    float *dsb = dp + 4 * 16 * WLD2;          // [2][ROWS]
+    float *btb = dsb + 2 * ROWS;              // [2][ROWS]
+    for (int i = threadIdx.x; i < D * AS; i += 256) {
+        const float v = Wg[(int64_t)(i / AS) * A + a_off + (i % AS)];
+        W1[(i / AS) * WLD1 + (i % AS)] = v;
+        W2[(i / AS) * WLD2 + (i % AS)] = v;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    float bcol[TA], ucol[TA], du[TA], db[TA];
+    f32x4 dW[DT][TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        bcol[t] = bw[a_off + 16 * t + l15];
+        ucol[t] = uw[a_off + 16 * t + l15];
+        du[t] = 0.f;
+        db[t] = 0.f;
+#pragma unroll
+        for (int ft = 0; ft < DT; ++ft) dW[ft][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float *mydp = dp + w * 16 * WLD2;
+    __syncthreads();
+    const int NB = ROWS / P;
+    const int64_t nchunks = (N + NB - 1) / NB;
+    int buf = 0;
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x, buf ^= 1) {
+        const int64_t node0 = ch * NB;
+        const int nodes = (int)((N - node0) < NB ? (N - node0) : NB);
+        const int rows = nodes * P;
+        const int64_t row0 = node0 * P;
+        float *dsr = dsb + buf * ROWS, *btr = btb + buf * ROWS;
+        if (threadIdx.x < ROWS && threadIdx.x >= rows) {
+            dsr[threadIdx.x] = 0.f;
+            btr[threadIdx.x] = 0.f;
+        }
+        for (int nd = w; nd < nodes; nd += 4) {
+            const int64_t n = node0 + nd;
+            float dz[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) dz[f] = dZ[n * D + lane + 64 * f];
+            const float breg = lane < P ? beta[n * P + lane] : 0.f;
+            float dbreg = 0.f;
+            for (int p = 0; p < P; ++p) {
+                float part = 0.f;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) part += dz[f] * M[(n * P + p) * D + lane + 64 * f];
+                const float d = han_wave_sum(part);
+                if (lane == p) dbreg = d;
+            }
+            const float S = han_wave_sum(breg * dbreg);
+            if (lane < P) {
+                dsr[nd * P + lane] = breg * (dbreg - S);
+                btr[nd * P + lane] = breg;
+            }
+        }
+        __syncthreads();
+        f32x4 acc[TA];
+#pragma unroll
+        for (int t = 0; t < TA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            const int lr = 16 * w + l15;
+            const float *mrow = M + (row0 + (lr < rows ? lr : rows - 1)) * D + l4;
+#pragma unroll 8
+            for (int ks = 0; ks < D / 4; ++ks) {
+                const float a = mrow[4 * ks];
+                const float *wr = W1 + (4 * ks + l4) * WLD1 + l15;
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wr[16 * t], acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float ds = dsr[16 * w + 4 * l4 + reg];
+#pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                const float v = fast_tanh(acc[t][reg] + bcol[t]);
+                const float d = ds * ucol[t] * (1.f - v * v);
+                du[t] += ds * v;
+                db[t] += d;
+                acc[t][reg] = d;
+                mydp[(4 * l4 + reg) * WLD2 + 16 * t + l15] = d;
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int lr = 16 * w + 4 * l4 + reg;
+            const float *mrow = M + (row0 + (lr < rows ? lr : rows - 1)) * D + l15;
+#pragma unroll
+            for (int ft = 0; ft < DT; ++ft) {
+                const float a = mrow[16 * ft];
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+                    dW[ft][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, acc[t][reg], dW[ft][t], 0, 0, 0);
+            }
+        }
+        f32x4 acc2[DT];
+#pragma unroll
+        for (int ft = 0; ft < DT; ++ft) acc2[ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int ks = 0; ks < AS / 4; ++ks) {
+            const float a = mydp[l15 * WLD2 + 4 * ks + l4];
+#pragma unroll
+            for (int ft = 0; ft < DT; ++ft) {
+                const float b = W2[(16 * ft + l15) * WLD2 + 4 * ks + l4];
+                acc2[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc2[ft], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int lr = 16 * w + 4 * l4 + reg;
+            if (lr < rows) {
+                const int64_t n = node0 + lr / P;
+                const float bt = btr[lr];
+#pragma unroll
+                for (int ft = 0; ft < DT; ++ft) {
+                    const int f = 16 * ft + l15;
+                    float *dst = dM + (row0 + lr) * D + f;
+                    if (a_off == 0) *dst = acc2[ft][reg] + bt * dZ[n * D + f];
+                    else *dst += acc2[ft][reg];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            du[t] += __shfl_xor(du[t], o, 64);
+            db[t] += __shfl_xor(db[t], o, 64);
+        }
+    }
+    __syncthreads();
+    float *red = smem;   // [D*AS] dW | [AS] db | [AS] du  (fits inside W1 + W2)
+    for (int ww = 0; ww < 4; ++ww) {
+        if (w == ww) {
+#pragma unroll
+            for (int ft = 0; ft < DT; ++ft)
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int idx = (16 * ft + 4 * l4 + reg) * AS + 16 * t + l15;
+                        red[idx] = (ww == 0 ? 0.f : red[idx]) + dW[ft][t][reg];
+                    }
+            if (l4 == 0) {
+#pragma unroll
+                for (int t = 0; t < TA; ++t) {
+                    const int idx = D * AS + 16 * t + l15;
+                    red[idx] = (ww == 0 ? 0.f : red[idx]) + db[t];
+                    red[idx + AS] = (ww == 0 ? 0.f : red[idx + AS]) + du[t];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *out = slab + (int64_t)blockIdx.x * ((int64_t)D * A + 2 * A);
+    for (int i = threadIdx.x; i < D * AS; i += 256) out[(int64_t)(i / AS) * A + a_off + (i % AS)] = red[i];
+    for (int i = threadIdx.x; i < AS; i += 256) {
+        out[(int64_t)D * A + a_off + i] = red[D * AS + i];
+        out[(int64_t)D * A + A + a_off + i] = red[D * AS + AS + i];
+    }
+}
+
 constexpr int kSemBwdBlocks = 256;   // one 4-wave block per CU (104 KB of LDS at A = 128)
 
 template <int CA>
@@ -736,6 +1001,37 @@ int launch_bwd(const float *M, const float *w, const float *b, const float *u, c
     return 0;
 }
 
+template <int CA, int DT>
+int launch_fwd_gen(const float *M, const float *w, const float *b, const float *u, float *Z, float *beta,
+                   int64_t N, int P, hipStream_t st) {
+    const size_t lds = (size_t)(16 * DT * (64 * CA + 16) + 2 * ROWS) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void *)sem_attn_fwd_gen_kernel<CA, DT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    const int grid = han_grid_for(N, ROWS / P, 256 * 2);
+    sem_attn_fwd_gen_kernel<CA, DT><<<grid, 256, lds, st>>>(M, w, b, u, Z, beta, N, P);
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int DT>
+int launch_bwd_gen(const float *M, const float *w, const float *b, const float *u, const float *beta,
+                   const float *dZ, float *dM, float *slab, int64_t N, int P, int A, int *grid_out,
+                   hipStream_t st) {
+    constexpr int D = 16 * DT;
+    const size_t lds = (size_t)(D * (64 + 16) + D * (64 + 2) + 4 * 16 * (64 + 2) + 4 * ROWS) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void *)sem_attn_bwd_gen_kernel<DT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    const int grid = han_grid_for(N > 0 ? N : 1, ROWS / P, kSemBwdBlocks);
+    *grid_out = grid;
+    for (int a_off = 0; a_off < A; a_off += 64) {      // same grid every pass: a block's slab row fills up slice by slice
+        sem_attn_bwd_gen_kernel<DT><<<grid, 256, lds, st>>>(M, w, b, u, beta, dZ, dM, slab, N, P, A, a_off);
+        HAN_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int han_sem_attn_fwd(const float *M, const float *w_omega, const float *b_omega,
@@ -743,16 +1039,20 @@ extern "C" int han_sem_attn_fwd(const float *M, const float *w_omega, const floa
                                 void *stream) {
     if (N == 0) return 0;   // nothing to do; row pointers of empty tensors may be null
     if (!M || !w_omega || !b_omega || !u_omega || !Z || !beta || N < 0 || P <= 0) return HAN_E_BADARG;
-    if (D != HAN_D || P > 64 || (A != 64 && A != 128)) return HAN_E_UNSUPPORTED;
+    if ((D != 64 && D != 128) || P > 64 || (A != 64 && A != 128)) return HAN_E_UNSUPPORTED;
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (D == 128) {
+        if (A == 64) return launch_fwd_gen<1, 8>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
+        return launch_fwd_gen<2, 8>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
+    }
     if (A == 64) return launch_fwd<1>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
     return launch_fwd<2>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
 }
 
 extern "C" size_t han_sem_attn_bwd_workspace(int64_t N, int P, int D, int A) {
-    (void)N; (void)P; (void)D;
-    return (size_t)kSemBwdBlocks * (size_t)(64 * A + 2 * A) * sizeof(float);
+    (void)N; (void)P;
+    return (size_t)kSemBwdBlocks * (size_t)(D * A + 2 * A) * sizeof(float);
 }
 
 extern "C" int han_sem_attn_bwd(const float *M, const float *w_omega, const float *b_omega,
@@ -762,19 +1062,21 @@ extern "C" int han_sem_attn_bwd(const float *M, const float *w_omega, const floa
     if (!M || !w_omega || !b_omega || !u_omega || !beta || !dZ || !dM || !dw_omega || !db_omega || !du_omega ||
         !workspace || N < 0 || P <= 0)
         return HAN_E_BADARG;
-    if (D != HAN_D || P > 64 || (A != 64 && A != 128)) return HAN_E_UNSUPPORTED;
+    if ((D != 64 && D != 128) || P > 64 || (A != 64 && A != 128)) return HAN_E_UNSUPPORTED;
     if (workspace_bytes < han_sem_attn_bwd_workspace(N, P, D, A)) return HAN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *slab = (float *)workspace;
     int grid = 0;
-    int rc = (A == 64)
+    int rc;
+    if (D == 128) rc = launch_bwd_gen<8>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, A, &grid, st);
+    else rc = (A == 64)
                  ? launch_bwd<1>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, &grid, st)
                  : launch_bwd<2>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, &grid, st);
     if (rc != 0) return rc;
-    const int width = 64 * A + 2 * A;
+    const int width = D * A + 2 * A;
     HanReduceOut o = han_reduce_to(dw_omega, width);
     o.ptr[1] = db_omega; o.ptr[2] = du_omega;
-    o.seg_end[0] = 64 * A; o.seg_end[1] = 64 * A + A; o.seg_end[2] = width;
+    o.seg_end[0] = D * A; o.seg_end[1] = D * A + A; o.seg_end[2] = width;
     o.nseg = 3;
     hipError_t e = han_reduce_slabs(slab, grid, width, width, o, st);
     if (e != hipSuccess) return (int)e;

@@ -39,19 +39,39 @@ class _ClassOrInstance:
         return functools.partial(self.fn, obj)
 
 
+GROUP = ops.D        # the K1 / K2 kernels process heads in groups whose concatenated width is 64 columns
+MAX_WIDTH = 128      # widest concatenated layer output (K * F') the K3 / classifier kernels take
+FP_SIZES = (4, 8, 16, 32, 64)
+
+
+def _pad_width(d: int) -> int:
+    """Embedding width as the K3 / classifier kernels see it: zero-padded to 64 or 128 columns."""
+    return GROUP * ((d + GROUP - 1) // GROUP)
+
+
+def _head_groups(K: int, FP: int):
+    """Heads [k0, k1) per kernel launch group: 64 // FP heads (64 columns) each; the last group may be short."""
+    kg = GROUP // FP
+    return [(k0, min(k0 + kg, K)) for k0 in range(0, K, kg)]
+
+
 # name -> shape builder; order == flat layout == gradient all-reduce layout.
 # `extra` = [(K_i, FP_i)] for the node-attention layers i >= 1 (models/gat.py:48-57):
-# their variables are named W_i, a1_i, ... and sit right after layer 0's.
+# their variables are named W_i, a1_i, ... and sit right after layer 0's.  Every width is the
+# reference's own: layer i has K_i * FP_i output columns, whatever that product is.
 def _param_shapes(P, F, K, FP, A, C, HC, extra=(), residual=False):
-    shapes = [("W", (P, F, D)), ("a1", (P, K, FP)), ("b1", (P, K)), ("a2", (P, K, FP)),
-              ("b2", (P, K)), ("c", (P, D))]
+    d_prev = K * FP
+    shapes = [("W", (P, F, d_prev)), ("a1", (P, K, FP)), ("b1", (P, K)), ("a2", (P, K, FP)),
+              ("b2", (P, K)), ("c", (P, d_prev))]
     for i, (Ki, FPi) in enumerate(extra, start=1):
-        shapes += [(f"W_{i}", (P, D, D)), (f"a1_{i}", (P, Ki, FPi)), (f"b1_{i}", (P, Ki)),
-                   (f"a2_{i}", (P, Ki, FPi)), (f"b2_{i}", (P, Ki)), (f"c_{i}", (P, D))]
-        if residual and FPi != D:      # utils/layers.py:38-40: conv1d(seq, F', 1) per head
-            shapes += [(f"Wr_{i}", (P, D, D)), (f"br_{i}", (P, D))]
-    return shapes + [("w_omega", (D, A)), ("b_omega", (A,)), ("u_omega", (A,)),
-                     ("Wc", (HC, D, C)), ("bc", (HC, C))]
+        d_i = Ki * FPi
+        shapes += [(f"W_{i}", (P, d_prev, d_i)), (f"a1_{i}", (P, Ki, FPi)), (f"b1_{i}", (P, Ki)),
+                   (f"a2_{i}", (P, Ki, FPi)), (f"b2_{i}", (P, Ki)), (f"c_{i}", (P, d_i))]
+        if residual and FPi != d_prev:      # utils/layers.py:38-40: conv1d(seq, F', 1) per head
+            shapes += [(f"Wr_{i}", (P, d_prev, d_i)), (f"br_{i}", (P, d_i))]
+        d_prev = d_i
+    return shapes + [("w_omega", (d_prev, A)), ("b_omega", (A,)), ("u_omega", (A,)),
+                     ("Wc", (HC, d_prev, C)), ("bc", (HC, C))]
 
 
 class HeteGAT_multi(BaseGAttN, torch.nn.Module):
@@ -93,15 +113,22 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
             raise ValueError("n_heads needs one entry per hidden layer plus the output entry "
                              "(ex_acm3025.py:27)")
         K, FP, HC = int(n_heads[0]), int(hid_units[0]), int(n_heads[-1])
-        ops._check_heads(K, FP)
         self.extra = [(int(n_heads[i]), int(hid_units[i])) for i in range(1, len(hid_units))]
         # residual only ever reaches the layers >= 1 (models/gat.py:43-45 hard-codes False for
         # layer 0) and only acts when the input width differs from the head width
         self.residual = bool(residual)
-        for Ki, FPi in self.extra:            # every layer's concatenated width is 64 in this build
-            ops._check_heads(Ki, FPi)
-        if mp_att_size not in (64, 128):
-            raise NotImplementedError("mp_att_size must be 64 or 128 in this build")
+        for Ki, FPi in [(K, FP)] + self.extra:
+            # any number of heads; head widths are the lane-mapped sizes of the K2 kernels; a layer's
+            # concatenated width K*F' is served in 64-column head groups (K1/K2) and, for the last
+            # layer, zero-padded to 64 or 128 columns for K3 / the classifier
+            if FPi not in FP_SIZES or Ki < 1:
+                raise NotImplementedError(f"hid_units entries must be one of {FP_SIZES} (got {FPi}) with n_heads >= 1")
+        k_last, fp_last = ([(K, FP)] + self.extra)[-1]
+        if k_last * fp_last > MAX_WIDTH:
+            raise NotImplementedError(f"the last layer's n_heads * hid_units = {k_last * fp_last} exceeds "
+                                      f"{MAX_WIDTH} columns")
+        if not (1 <= mp_att_size <= 128):
+            raise NotImplementedError("mp_att_size must be in [1, 128] in this build")
         if not (1 <= nb_classes <= 16):
             raise NotImplementedError("nb_classes must be in [1,16] in this build")
         dev = torch.device(device) if device is not None else (self._device or torch.device("cuda:0"))
@@ -135,21 +162,46 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         uni(self.W, math.sqrt(6.0 / (self.F + FP)))          # conv1d kernel (1,F,F')
         uni(self.a1, math.sqrt(6.0 / (FP + 1)))              # conv1d kernel (1,F',1)
         uni(self.a2, math.sqrt(6.0 / (FP + 1)))
+        d_prev = K * FP
         for i, (Ki, FPi) in enumerate(self.extra, start=1):
-            uni(getattr(self, f"W_{i}"), math.sqrt(6.0 / (D + FPi)))
+            uni(getattr(self, f"W_{i}"), math.sqrt(6.0 / (d_prev + FPi)))
             uni(getattr(self, f"a1_{i}"), math.sqrt(6.0 / (FPi + 1)))
             uni(getattr(self, f"a2_{i}"), math.sqrt(6.0 / (FPi + 1)))
-            if self.residual and FPi != D:
-                uni(getattr(self, f"Wr_{i}"), math.sqrt(6.0 / (D + FPi)))
+            if self.residual and FPi != d_prev:
+                uni(getattr(self, f"Wr_{i}"), math.sqrt(6.0 / (d_prev + FPi)))
+            d_prev = Ki * FPi
+        self.D_out = d_prev                                  # width of final_embed (models/gat.py:61)
         nrm(self.w_omega, 0.1)                               # utils/layers.py:145-147
         nrm(self.b_omega, 0.1)
         nrm(self.u_omega, 0.1)
-        uni(self.Wc, math.sqrt(6.0 / (D + self.C)))          # tf.layers.dense kernel
+        uni(self.Wc, math.sqrt(6.0 / (d_prev + self.C)))     # tf.layers.dense kernel
         self._built = True
         return self
 
     def trainable(self):
         return [self._views[n] for n, _ in self.param_shapes()]
+
+    def _apply(self, fn, recurse=True):
+        """nn.Module.to()/.cuda()/.float()...: move the FLAT buffers and re-create every parameter as a
+        view of the moved buffer.  (The stock _apply would hand each parameter its own copy, silently
+        detaching it from `flat`: Adam would then update a buffer the forward no longer reads.)"""
+        if not self._built:
+            return super()._apply(fn, recurse)
+        new_flat = fn(self.flat)
+        if new_flat.dtype != torch.float32:
+            raise TypeError("han_amd parameters are float32 (the kernels read fp32 parameters); "
+                            "bf16 storage is selected with build(table_dtype=torch.bfloat16)")
+        new_grad = fn(self.flat_grad)
+        self._buffers["flat"], self._buffers["flat_grad"] = new_flat, new_grad
+        off = 0
+        for name, shp in self.param_shapes():
+            n = math.prod(shp)
+            v = self._views[name]
+            v.data = new_flat[off:off + n].view(shp)
+            v.grad = new_grad[off:off + n].view(shp)
+            off += n
+        self._graph_cache.clear()
+        return self
 
     def param_shapes(self):
         return _param_shapes(self.P, self.F, self.K, self.FP, self.A, self.C, self.HC, self.extra,
@@ -190,34 +242,115 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
             out.append(hit[1])
         return out
 
-    def node_level(self, xs, graphs, attn_drop, ffd_drop, train, act_code, graphs_t=None, coef_sink=None):
-        """models/gat.py:39-60: every node-attention layer of every meta-path -> M (N,P,64).
+    def node_level(self, xs, graphs, attn_drop, ffd_drop, train, act_code, graphs_t=None, coef_sink=None,
+                   post=None):
+        """models/gat.py:39-60: every node-attention layer of every meta-path -> M (N,P,K*F').
         coef_sink: a list that receives, per meta-path, the head-mean coefficients of the
-        FIRST layer (models/gat.py:143-172), or None."""
+        FIRST layer (models/gat.py:143-172), or None.
+        post: an arbitrary `activation` callable (models/gat.py:36 takes any): the kernels then emit
+        the pre-activation (act_code = identity) and torch applies `post` -- per head, on
+        (N,P,K,F') so that an activation acting on the last axis sees what the reference's
+        per-head (1,N,F') tensor gives it -- with its own autograd."""
+        P = len(graphs)
+
+        def act(M, K, FP):
+            if post is None:
+                return M
+            return post(M.reshape(M.shape[0], M.shape[1], K, FP)).reshape(M.shape)
+
         def seeds(layer):
             if not train:
-                return (0,) * len(graphs)
+                return (0,) * P
             if self.step_seed_dev is None:
                 return tuple(rng.next_seed() for _ in graphs)
-            key = (layer, len(graphs))
+            key = (layer, P)
             if key not in self._fixed_seeds:
                 self._fixed_seeds[key] = tuple(rng.next_seed() for _ in graphs)
             return self._fixed_seeds[key]
 
-        def cfg(layer=0, **kw):
+        def cfg(layer, sd, **kw):
             return {"train": train, "in_drop": float(ffd_drop), "coef_drop": float(attn_drop),
-                    "seeds": seeds(layer), "seed_dev": self.step_seed_dev if train else None,
+                    "seeds": sd, "seed_dev": self.step_seed_dev if train else None,
                     "act": act_code, "part": self.partition, "graphs_t": graphs_t, "layer": layer,
                     "table_dtype": self.table_dtype, "plans_f": self.halo_plans[0],
                     "plans_b": self.halo_plans[1], **kw}
-        M = layers.NodeLevelAttention.apply(None, self.W, self.a1, self.b1, self.a2, self.b2, self.c,
-                                            None, None, tuple(xs), tuple(graphs),
-                                            cfg(coef_sink=coef_sink, coef_mean=True))
-        for i in range(1, len(self.extra) + 1):                                 # gat.py:48-57
-            g = lambda n: getattr(self, f"{n}_{i}", None)
-            M = layers.NodeLevelAttention.apply(M, g("W"), g("a1"), g("b1"), g("a2"), g("b2"), g("c"),
-                                                g("Wr"), g("br"), None, tuple(graphs), cfg(i))
+
+        def layer_fwd(layer, Xin, xs_, K, FP, sink):
+            """One node-attention layer: its K heads run through the 64-column K1/K2 kernels in groups of
+            64 // F' heads.  A group that is not full (K*F' not a multiple of 64) is completed with
+            zero-weight heads, whose output columns are exactly 0 and are cut off again; group g draws
+            its dropout masks from seed + g, head index = index inside the group."""
+            sfx = "" if layer == 0 else f"_{layer}"
+            g = lambda n: getattr(self, n + sfx, None)
+            W, a1, b1, a2, b2, c, Wr, br = (g(n) for n in ("W", "a1", "b1", "a2", "b2", "c", "Wr", "br"))
+            sd = seeds(layer)
+            groups = _head_groups(K, FP)
+            if len(groups) == 1 and K * FP == GROUP:      # the reference shapes: no slicing, direct gradients
+                return layers.NodeLevelAttention.apply(Xin, W, a1, b1, a2, b2, c, Wr, br, xs_, tuple(graphs),
+                                                       cfg(layer, sd, coef_sink=sink, coef_mean=True))
+            kg = GROUP // FP
+            outs, coef_acc = [], None
+            for gi, (k0, k1) in enumerate(groups):
+                nh, cols = k1 - k0, slice(k0 * FP, k1 * FP)
+                padc = GROUP - nh * FP
+
+                def pc(t):            # pad the column (last) axis to 64
+                    return F_torch.pad(t[..., cols], (0, padc)).contiguous()
+
+                def ph(t, per_head):  # pad the head axis (dim 1) to kg heads
+                    t = t[:, k0:k1]
+                    pad = (0, 0, 0, kg - nh) if per_head else (0, kg - nh)
+                    return F_torch.pad(t, pad).contiguous()
+                gsink = [] if sink is not None else None
+                Mg = layers.NodeLevelAttention.apply(
+                    Xin, pc(W), ph(a1, True), ph(b1, False), ph(a2, True), ph(b2, False), pc(c),
+                    pc(Wr) if Wr is not None else None, pc(br) if br is not None else None, xs_, tuple(graphs),
+                    cfg(layer, tuple((s_ + gi) & ((1 << 64) - 1) for s_ in sd), coef_sink=gsink, coef_mean=False,
+                        group=gi))
+                outs.append(Mg[:, :, :nh * FP])
+                if sink is not None:      # (E, kg) per meta-path -> sum over the real heads
+                    part = [v[:, :nh].sum(1) for v in gsink]
+                    coef_acc = part if coef_acc is None else [x + y for x, y in zip(coef_acc, part)]
+            if sink is not None:
+                sink.extend(v / K for v in coef_acc)
+            return torch.cat(outs, dim=2) if len(outs) > 1 else outs[0].contiguous()
+
+        M = act(layer_fwd(0, None, tuple(xs), self.K, self.FP, coef_sink), self.K, self.FP)
+        for i, (Ki, FPi) in enumerate(self.extra, start=1):                     # gat.py:48-57
+            M = act(layer_fwd(i, M, None, Ki, FPi, None), Ki, FPi)
         return M
+
+    def semantic(self, M):
+        """models/gat.py:61-63: SimpleAttLayer over the stacked meta-path embeddings M (N,P,D_out) ->
+        (final_embed (N,D_out), att_val (N,P)).  K3 takes 64- or 128-wide rows and a 64- or 128-wide
+        attention space: other sizes are zero-padded (padded columns of w_omega / u_omega contribute
+        tanh(.) * 0 = 0 to the scores and the padded embedding columns are 0), which is exact."""
+        d, a = M.shape[2], self.A
+        dm, am = _pad_width(d), (64 if a <= 64 else 128)
+        if dm == d and am == a:
+            return layers.SemanticAttention.apply(M, self.w_omega, self.b_omega, self.u_omega)
+        Z, att = layers.SemanticAttention.apply(
+            F_torch.pad(M, (0, dm - d)), F_torch.pad(self.w_omega, (0, am - a, 0, dm - d)),
+            F_torch.pad(self.b_omega, (0, am - a)), F_torch.pad(self.u_omega, (0, am - a)))
+        return Z[:, :d], att
+
+    def _padded_classifier(self, Z):
+        d = Z.shape[1]
+        dm = _pad_width(d)
+        if dm == d:
+            return Z, self.Wc
+        return F_torch.pad(Z, (0, dm - d)), F_torch.pad(self.Wc, (0, 0, 0, dm - d))
+
+    def classify(self, Z):
+        """models/gat.py:65-72: logits (N,C) = mean over the output heads of Z Wc[h] + bc[h]."""
+        Zp, Wp = self._padded_classifier(Z)
+        return layers.classifier(Zp, Wp, self.bc)
+
+    def classifier_loss(self, Z, labels, mask, weight):
+        """Fused classifier + masked softmax cross-entropy + accuracy (the trainer's step):
+        returns (loss, accuracy, logits)."""
+        Zp, Wp = self._padded_classifier(Z)
+        return layers.ClassifierLoss.apply(Zp, Wp, self.bc, labels, mask, weight)
 
     @_ClassOrInstance
     def inference(self, inputs_list, nb_classes, nb_nodes, training, attn_drop, ffd_drop,
@@ -252,20 +385,17 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         for x, g in zip(xs, graphs):
             if g.n_rows != x.shape[0]:
                 raise ValueError(f"graph has {g.n_rows} rows, features have {x.shape[0]}")
-        code, post = layers._act_code(activation)
-        if post is not None:
-            raise NotImplementedError("only ELU / identity activations run inside the kernels")
+        code, post = layers._act_code(activation)     # ELU / identity run in the K2 epilogue, anything else in torch
         train = torch.is_grad_enabled() and self.W.requires_grad
         attn_drop, ffd_drop = float(attn_drop), float(ffd_drop)
         if not train and (attn_drop > 0 or ffd_drop > 0):
             raise ValueError("dropout > 0 needs gradients enabled (training step)")
-        M = self.node_level(xs, graphs, attn_drop, ffd_drop, train, code, coef_sink=coef_sink)  # gat.py:39-60
+        M = self.node_level(xs, graphs, attn_drop, ffd_drop, train, code, coef_sink=coef_sink, post=post)  # gat.py:39-60
         if coef_sink is not None:
             coef_sink[:] = [torch.sparse_csr_tensor(g.rowptr, g.colidx.long(), v, (g.n_rows, g.n_cols))
                             for g, v in zip(graphs, coef_sink)]
-        final_embed, att_val = layers.SemanticAttention.apply(M, self.w_omega,     # gat.py:61-63
-                                                              self.b_omega, self.u_omega)
-        logits = layers.classifier(final_embed, self.Wc, self.bc)                  # gat.py:65-72
+        final_embed, att_val = self.semantic(M)                                    # gat.py:61-63
+        logits = self.classify(final_embed)                                        # gat.py:65-72
         return logits[None], final_embed, att_val                                  # gat.py:76-77
 
     def forward(self, inputs_list, bias_mat_list, attn_drop=0.0, ffd_drop=0.0):

@@ -101,7 +101,7 @@ class NodeLevelAttention(torch.autograd.Function):
             plan = plans_f[p] if plans_f is not None else None
             handle = None
             if multi:      # halo rows only (HaloPlan) or the whole shard (all-gather)
-                tag = ("f", cfg.get("layer", 0), p)       # persistent exchange table of this (layer, meta-path)
+                tag = ("f", cfg.get("layer", 0), cfg.get("group", 0), p)   # persistent exchange table of this (layer, head group, meta-path)
                 handle = plan.exchange_async(H, tag) if plan is not None else part.all_gather_rows_async(H, tag)
             if cfg.get("coef_sink") is not None:
                 if multi:
@@ -191,7 +191,7 @@ class NodeLevelAttention(torch.autograd.Function):
             if multi:
                 plan = plans_b[p] if plans_b is not None else None
                 ex = plan.exchange_async if plan is not None else part.all_gather_rows_async
-                rows.append((ex(gs, ("b", cfg.get("layer", 0), p)), df1))   # ONE fused [g | stats] table on the wire
+                rows.append((ex(gs, ("b", cfg.get("layer", 0), cfg.get("group", 0), p)), df1))   # ONE fused [g | stats] table on the wire
             else:
                 rows.append((gs, df1))
         for p in range(P):

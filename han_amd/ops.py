@@ -20,6 +20,7 @@ D = 64                     # K * F' of this build
 STATS_ROW_BYTES = 128      # per destination row: the (f1, lse, s, 0) records of the K = 8 heads inside the fused gs row (bench.py byte model)
 
 _workspaces: dict = {}
+_retired_workspaces: list = []      # superseded buffers stay alive: a captured hipGraph may have baked their pointers in
 
 # Optional timing hook (bench.py): a list to which node_attn_fwd / node_attn_bwd_cols
 # append (tag, start_event, end_event, N, E) recorded on the launch stream.
@@ -48,11 +49,18 @@ def _stream():
 
 
 def _ws(nbytes: int, device, tag: str = "") -> torch.Tensor:
-    """Grow-only scratch buffer per (device, tag)."""
+    """Grow-only scratch buffer per (device, tag).  A buffer that has to grow is REPLACED, and the old
+    one is kept alive for the life of the process (never returned to the caching allocator): an epoch
+    captured into a hipGraph (HANTrainer(use_graph=True)) replays with the raw pointers it saw, and a
+    later, larger request for the same tag must not free memory such a graph still reads and writes.
+    Growth is geometric, so the retired buffers of a tag add up to less than its current one."""
     key = (str(device), tag)
     t = _workspaces.get(key)
     if t is None or t.numel() < nbytes:
-        t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if t is not None:
+            _retired_workspaces.append(t)
+        t = torch.empty(max(int(nbytes), 1 << 20, 2 * (t.numel() if t is not None else 0)), dtype=torch.uint8,
+                        device=device)
         _workspaces[key] = t
     return t
 
@@ -418,18 +426,18 @@ def sem_attn_fwd(M, w_omega, b_omega, u_omega):
     """utils/layers.py:152-159.  M (N,P,D) -> Z (N,D), beta (N,P)."""
     lib = _lib.load()
     _chk(M, "M")
-    if M.dim() != 3 or M.shape[2] != D:
-        raise ValueError(f"M: expected (N,P,{D}), got {tuple(M.shape)}")
-    N, P, _ = M.shape
+    if M.dim() != 3 or M.shape[2] not in (64, 128):
+        raise ValueError(f"M: expected (N,P,64) or (N,P,128), got {tuple(M.shape)}")
+    N, P, Dm = M.shape
     A = w_omega.shape[1]
     dev = M.device
-    _chk(w_omega, "w_omega", (D, A), device=dev)
+    _chk(w_omega, "w_omega", (Dm, A), device=dev)
     _chk(b_omega, "b_omega", (A,), device=dev)
     _chk(u_omega, "u_omega", (A,), device=dev)
-    Z = torch.empty((N, D), dtype=torch.float32, device=dev)
+    Z = torch.empty((N, Dm), dtype=torch.float32, device=dev)
     beta = torch.empty((N, P), dtype=torch.float32, device=dev)
     _lib.check(lib.han_sem_attn_fwd(M.data_ptr(), w_omega.data_ptr(), b_omega.data_ptr(),
-                                    u_omega.data_ptr(), Z.data_ptr(), beta.data_ptr(), N, P, D, A,
+                                    u_omega.data_ptr(), Z.data_ptr(), beta.data_ptr(), N, P, Dm, A,
                                     _stream()), "han_sem_attn_fwd")
     return Z, beta
 
@@ -437,22 +445,22 @@ def sem_attn_fwd(M, w_omega, b_omega, u_omega):
 def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ, out=None):
     """dM, dw, db, du [the last three written to the tensors of `out` when given]."""
     lib = _lib.load()
-    N, P, _ = M.shape
+    N, P, Dm = M.shape
     A = w_omega.shape[1]
     dev = M.device
-    _chk(M, "M", (N, P, D))
+    _chk(M, "M", (N, P, Dm))
     _chk(beta, "beta", (N, P), device=dev)
-    _chk(dZ, "dZ", (N, D), device=dev)
+    _chk(dZ, "dZ", (N, Dm), device=dev)
     dM = torch.empty_like(M)
     o = out if out is not None else (None,) * 3
     dw = _out(o[0], "dw", tuple(w_omega.shape), dev)
     db = _out(o[1], "db", tuple(b_omega.shape), dev)
     du = _out(o[2], "du", tuple(u_omega.shape), dev)
-    ws = _ws(lib.han_sem_attn_bwd_workspace(N, P, D, A), dev, "sem")
+    ws = _ws(lib.han_sem_attn_bwd_workspace(N, P, Dm, A), dev, "sem")
     _lib.check(lib.han_sem_attn_bwd(
         M.data_ptr(), w_omega.data_ptr(), b_omega.data_ptr(), u_omega.data_ptr(), beta.data_ptr(),
         dZ.data_ptr(), dM.data_ptr(), dw.data_ptr(), db.data_ptr(), du.data_ptr(), ws.data_ptr(),
-        ws.numel(), N, P, D, A, _stream()), "han_sem_attn_bwd")
+        ws.numel(), N, P, Dm, A, _stream()), "han_sem_attn_bwd")
     return dM, dw, db, du
 
 
@@ -466,9 +474,11 @@ def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False, grad_ou
     _chk(Z, "Z")
     N = Z.shape[0]
     dev = Z.device
-    HC, _, C = Wc.shape
-    _chk(Z, "Z", (N, D))
-    _chk(Wc, "Wc", (HC, D, C), device=dev)
+    HC, Dm, C = Wc.shape
+    if Dm not in (64, 128):
+        raise ValueError(f"Wc: the embedding width must be 64 or 128 (zero-pad it), got {Dm}")
+    _chk(Z, "Z", (N, Dm))
+    _chk(Wc, "Wc", (HC, Dm, C), device=dev)
     _chk(bc, "bc", (HC, C), device=dev)
     _chk(labels, "labels", (N,), dtype=torch.int32, device=dev)
     _chk(mask, "mask", (N,), dtype=torch.uint8, device=dev)
@@ -477,17 +487,17 @@ def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False, grad_ou
     grads = None
     ptrs = (None, None, None)
     if backward:
-        dZ = torch.empty((N, D), dtype=torch.float32, device=dev)
+        dZ = torch.empty((N, Dm), dtype=torch.float32, device=dev)
         go = grad_out if grad_out is not None else (None, None)
         dWc = _out(go[0], "dWc", tuple(Wc.shape), dev)
         dbc = _out(go[1], "dbc", tuple(bc.shape), dev)
         grads = (dZ, dWc, dbc)
         ptrs = (dZ.data_ptr(), dWc.data_ptr(), dbc.data_ptr())
-    ws = _ws(lib.han_classifier_workspace(N, D, C, HC), dev, "cls")
+    ws = _ws(lib.han_classifier_workspace(N, Dm, C, HC), dev, "cls")
     _lib.check(lib.han_classifier_loss(
         Z.data_ptr(), Wc.data_ptr(), bc.data_ptr(), labels.data_ptr(), mask.data_ptr(),
         float(row_weight), logits.data_ptr(), loss_acc.data_ptr(), ptrs[0], ptrs[1], ptrs[2],
-        ws.data_ptr(), ws.numel(), N, D, C, HC, _stream()), "han_classifier_loss")
+        ws.data_ptr(), ws.numel(), N, Dm, C, HC, _stream()), "han_classifier_loss")
     return logits, loss_acc, grads
 
 

@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import torch
 
-from . import layers, ops
+from . import layers, ops, rng
 from .base_gattn import TFAdam
 from .dist import NodePartition
 from .gat import HeteGAT_multi
@@ -98,8 +98,8 @@ class HANTrainer:
             M = m.node_level(self.xs, self.graphs, self.attn_drop if train else 0.0,
                              self.ffd_drop if train else 0.0, train, ops.ACT_ELU,
                              graphs_t=self.graphs_t)
-            Z, _ = layers.SemanticAttention.apply(M, m.w_omega, m.b_omega, m.u_omega)
-            loss, acc, _ = layers.ClassifierLoss.apply(Z, m.Wc, m.bc, self.labels, mask, weight)
+            Z, _ = m.semantic(M)
+            loss, acc, _ = m.classifier_loss(Z, self.labels, mask, weight)
         return loss, acc
 
     def train_step(self):
@@ -180,23 +180,46 @@ class HANTrainer:
         self.curr_step += 1
         return self.curr_step == self.patience
 
+    def _signature(self):
+        m = self.model
+        return {"param_shapes": [(n, list(s)) for n, s in m.param_shapes()], "residual": bool(m.residual),
+                "table_dtype": str(m.table_dtype), "use_graph": self.use_graph}
+
     def save_checkpoint(self, path):
-        """saver.save(sess, checkpt_file) (ex_acm3025.py:229) -- plus the optimiser
-        state, which the reference does not keep."""
-        torch.save({"flat": self.model.flat.detach().cpu(), "opt": {
-            "t": self.opt.t, "m": self.opt.m.cpu(), "v": self.opt.v.cpu()},
-            "shape": (self.model.P, self.model.F, self.model.K, self.model.FP, self.model.A,
-                      self.model.C, self.model.HC)}, path)
+        """saver.save(sess, checkpt_file) (ex_acm3025.py:229) -- plus what the reference does not keep
+        and a bit-exact resume needs: the optimiser state, the dropout seed stream (host counter, or the
+        device step word of a captured epoch), and the early-stopping bookkeeping incl. the best weights."""
+        ck = {"flat": self.model.flat.detach().cpu(),
+              "opt": {"t": self.opt.t, "m": self.opt.m.cpu(), "v": self.opt.v.cpu()},
+              "signature": self._signature(),
+              "rng": dict(rng._state),
+              "fixed_seeds": {f"{k[0]}:{k[1]}": list(v) for k, v in self.model._fixed_seeds.items()},
+              "step_state": self.step_state.cpu() if self.use_graph else None,
+              "early_stop": {"vlss_mn": self.vlss_mn, "vacc_mx": self.vacc_mx, "curr_step": self.curr_step},
+              "best_state": self.best_state.cpu() if self.best_state is not None else None}
+        torch.save(ck, path)
 
     def load_checkpoint(self, path):
         ck = torch.load(path, weights_only=True)
+        sig = self._signature()
+        if ck.get("signature") != sig:
+            raise ValueError("checkpoint was written for a different model / trainer configuration: "
+                             f"{ck.get('signature')} vs {sig}")
         m = self.model
-        if tuple(ck["shape"]) != (m.P, m.F, m.K, m.FP, m.A, m.C, m.HC):
-            raise ValueError("checkpoint was written for a different model shape")
         m.flat.copy_(ck["flat"])
         self.opt.load_state_dict(ck["opt"])
+        rng._state.update(ck["rng"])
+        fixed = {(int(k.split(":")[0]), int(k.split(":")[1])): tuple(v) for k, v in ck["fixed_seeds"].items()}
+        if self._graph is not None and fixed != m._fixed_seeds:
+            raise RuntimeError("this trainer has already captured its epoch with other per-meta-path seed "
+                               "constants baked in; load the checkpoint before the first epoch")
+        m._fixed_seeds = fixed
         if self.use_graph:
+            self.step_state.copy_(ck["step_state"])
             self.step_state[1] = self.opt.t
+        es = ck["early_stop"]
+        self.vlss_mn, self.vacc_mx, self.curr_step = float(es["vlss_mn"]), float(es["vacc_mx"]), int(es["curr_step"])
+        self.best_state = ck["best_state"].to(m.flat.device) if ck["best_state"] is not None else None
 
     def restore_best(self):
         """saver.restore(sess, checkpt_file) (ex_acm3025.py:247)."""

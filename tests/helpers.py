@@ -26,13 +26,13 @@ def random_adj(rng, n, density, symmetric=True, special_rows=True):
 
 
 def make_problem(seed, n, f, p, c, densities, dtype=np.float64, nonzero_biases=True, hid_units=None,
-                 n_heads=(8, 1), residual=False):
+                 n_heads=(8, 1), residual=False, mp_att_size=128):
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((1, n, f)).astype(dtype)
     adjs = [random_adj(rng, n, densities[i % len(densities)])[None] for i in range(p)]
     biases = [ho.adj_to_bias(a, [n], 1) for a in adjs]
     params = ho.init_params(rng, p, f, c, nonzero_biases=nonzero_biases, hid_units=hid_units,
-                            n_heads=n_heads, residual=residual)
+                            n_heads=n_heads, residual=residual, mp_att_size=mp_att_size)
     labels = rng.integers(0, c, size=n)
     onehot = np.eye(c)[labels]
     mask = rng.random(n) < 0.4
@@ -48,9 +48,11 @@ def load_params(model, bp):
             getattr(model, k).copy_(bp[k].to(torch.float32))
 
 
-def build_model(prob, dev, mp_att_size=128):
+def build_model(prob, dev, mp_att_size=None):
     from han_amd.gat import HeteGAT_multi
     model = HeteGAT_multi()
+    if mp_att_size is None:
+        mp_att_size = int(np.asarray(prob["params"]["w_omega"]).shape[1])
     heads0 = prob["params"]["heads"][0]
     k0, fp0 = len(heads0), len(heads0[0]["a1"])          # first layer: K heads of width F'
     hid_units, n_heads = (fp0,), (k0, len(prob["params"]["cls"]))
@@ -80,3 +82,21 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def group_masks(seed, n, f, K, FP, rowptr, colidx, drop, row_offset=0):
+    """The dropout masks the kernels draw for a layer of K heads of width FP (han_amd.gat.node_level): the
+    heads run in groups of 64 // FP (64 columns per K1/K2 launch); group g uses seed + g and a head's RNG
+    key is its index INSIDE the group.  Returns the oracle's mask dict: seq (K,N,F), coef (E,K), fts (N,K*FP)."""
+    import torch
+    from tests import rng_ref
+    kg = 64 // FP
+    seq, coef, fts = [], [], []
+    for g0 in range(0, K, kg):
+        nh = min(kg, K - g0)
+        sd = (int(seed) + g0 // kg) & ((1 << 64) - 1)
+        seq.append(rng_ref.seq_mask(sd, n, f, kg, drop, row_offset)[:nh])
+        coef.append(rng_ref.coef_mask_csr(sd, rowptr, colidx, kg, drop, row_offset)[:, :nh])
+        fts.append(rng_ref.fts_mask(sd, n, 64, drop, row_offset)[:, :nh * FP])
+    return {"seq": torch.tensor(np.concatenate(seq, 0)), "coef": torch.tensor(np.concatenate(coef, 1)),
+            "fts": torch.tensor(np.concatenate(fts, 1))}

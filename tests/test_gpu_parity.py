@@ -12,7 +12,7 @@ import torch
 from oracle import han_oracle as ho
 from oracle import han_oracle_torch as ht
 from tests import rng_ref
-from tests.helpers import load_params, build_model, gpu_inputs, make_problem, rel_err
+from tests.helpers import load_params, build_model, gpu_inputs, group_masks, make_problem, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -250,9 +250,8 @@ def _gpu_loss_and_grads(model, prob, dev, attn_drop=0.0, ffd_drop=0.0):
     mask = _t(prob["mask"].astype(np.uint8), dev, torch.uint8)
     model.zero_grad_flat()
     M = model.node_level([x] * prob["p"], graphs, attn_drop, ffd_drop, True, ops.ACT_ELU)
-    Z, _ = layers.SemanticAttention.apply(M, model.w_omega, model.b_omega, model.u_omega)
-    loss, acc, logits = layers.ClassifierLoss.apply(Z, model.Wc, model.bc, labels, mask,
-                                                    1.0 / int(prob["mask"].sum()))
+    Z, _ = model.semantic(M)
+    loss, acc, logits = model.classifier_loss(Z, labels, mask, 1.0 / int(prob["mask"].sum()))
     loss.backward()
     grads = {k: getattr(model, k).grad.detach().cpu().numpy().copy() for k in ht.PARAM_ORDER}
     return float(loss), grads, logits.cpu().numpy(), float(acc)
@@ -360,36 +359,39 @@ def test_dropout_statistics(dev):
     assert not torch.equal(H[:, 0], H[:, 8])
 
 
-@pytest.mark.parametrize("K,FP", [(16, 4), (4, 16), (2, 32), (1, 64)])
+@pytest.mark.parametrize("K,FP,A", [(16, 4, 128), (4, 16, 128), (2, 32, 128), (1, 64, 128),      # K*F' = 64
+                                    (8, 16, 128), (4, 8, 128), (3, 8, 48), (12, 8, 80), (5, 16, 64),  # 128, 32, 24, 96, 80
+                                    (1, 4, 16), (2, 64, 128)])                                       # 4, 128
 @pytest.mark.parametrize("drop", [0.0, 0.6])
-def test_other_head_shapes_match_oracle(dev, K, FP, drop):
-    """hid_units=[F'], n_heads=[K,1] with K*F' = 64 but not 8x8: every kernel template
-    (K1 per-head dropout tiles, K2 lane->head maps, score-parameter reductions) against the
-    oracle -- inference, then loss + all gradients with the dropouts on the same hash masks."""
+def test_other_head_shapes_match_oracle(dev, K, FP, A, drop):
+    """hid_units=[F'], n_heads=[K,1] other than 8x8 and mp_att_size other than 128 (models/gat.py:37,42-57
+    leave them free).  K*F' = 64: every kernel template (K1 per-head dropout tiles, K2 lane->head maps,
+    score-parameter reductions).  Other widths: the heads run through K1/K2 in 64-column groups (short
+    groups completed with zero-weight heads), K3 / the classifier take the embedding zero-padded to 64 or
+    128 columns (the 128-wide kernels) and mp_att_size zero-padded to 64 / 128 -- exact.  Inference, then
+    loss + all gradients with the dropouts on the same hash masks, against the oracle."""
     from han_amd import rng as hrng
     n, f, p = 90, 14, 2
-    prob = make_problem(500 + K, n, f, p, 3, [0.06, 0.4], hid_units=[FP], n_heads=(K, 1))
+    prob = make_problem(500 + K, n, f, p, 3, [0.06, 0.4], hid_units=[FP], n_heads=(K, 1), mp_att_size=A)
     model, bp = build_model(prob, dev)
-    assert (model.K, model.FP) == (K, FP)
+    assert (model.K, model.FP, model.A) == (K, FP, A) and tuple(model.w_omega.shape) == (K * FP, A)
     lg, fe, att = ho.hetegat_multi_inference([prob["x"]] * p, 3, n, False, 0.0, 0.0, prob["biases"],
-                                             [FP], [K, 1], prob["params"])
+                                             [FP], [K, 1], prob["params"], mp_att_size=A)
     x, graphs = gpu_inputs(prob, dev)
     with torch.no_grad():
-        logits, final_embed, att_val = model.inference([x] * p, 3, n, False, 0.0, 0.0, graphs, [FP], [K, 1])
+        logits, final_embed, att_val = model.inference([x] * p, 3, n, False, 0.0, 0.0, graphs, [FP], [K, 1],
+                                                       mp_att_size=A)
+    assert tuple(final_embed.shape) == (n, K * FP)
     assert np.abs(logits[0].cpu().numpy() - lg[0]).max() < TOL
     assert np.abs(final_embed.cpu().numpy() - fe).max() < TOL
+    assert np.abs(att_val.cpu().numpy() - att).max() < TOL
     hrng.manual_seed(4242)
     seeds = [hrng.next_seed() for _ in range(p)]
     hrng.manual_seed(4242)
     masks, keep = None, 1.0
     if drop > 0:
         keep = rng_ref.keep_prob32(drop)
-        masks = []
-        for q in range(p):
-            rp, ci = ho.bias_to_csr(prob["biases"][q])
-            masks.append({"seq": torch.tensor(rng_ref.seq_mask(seeds[q], n, f, K, drop)),
-                          "coef": torch.tensor(rng_ref.coef_mask_csr(seeds[q], rp, ci, K, drop)),
-                          "fts": torch.tensor(rng_ref.fts_mask(seeds[q], n, 64, drop))})
+        masks = [group_masks(seeds[q], n, f, K, FP, *ho.bias_to_csr(prob["biases"][q]), drop) for q in range(p)]
     loss_ref, gref, lg_ref = _oracle_grads(prob, bp, masks=masks, keep=keep, dense=False)
     loss, grads, lgg, _ = _gpu_loss_and_grads(model, prob, dev, attn_drop=drop, ffd_drop=drop)
     assert np.abs(lgg - lg_ref).max() < 5 * TOL
@@ -399,18 +401,22 @@ def test_other_head_shapes_match_oracle(dev, K, FP, drop):
 
 
 # ----------------------------------------------------------------------------- K3
-@pytest.mark.parametrize("n,p,a", [(1, 1, 128), (50, 2, 128), (333, 4, 128), (40, 3, 64), (2000, 8, 128),
-                                   (77, 5, 64), (3, 16, 128), (1000, 4, 64), (5000, 1, 64), (129, 64, 128)])
-def test_semantic_attention_fwd_bwd(dev, n, p, a):
+@pytest.mark.parametrize("n,p,a,d", [(1, 1, 128, 64), (50, 2, 128, 64), (333, 4, 128, 64), (40, 3, 64, 64),
+                                     (2000, 8, 128, 64), (77, 5, 64, 64), (3, 16, 128, 64), (1000, 4, 64, 64),
+                                     (5000, 1, 64, 64), (129, 64, 128, 64),
+                                     # 128-wide embeddings (hid_units=[16] x 8 heads): the width-templated kernels
+                                     (1, 1, 128, 128), (50, 2, 128, 128), (333, 4, 64, 128), (2000, 8, 128, 128),
+                                     (77, 5, 128, 128), (129, 64, 64, 128), (5000, 3, 128, 128)])
+def test_semantic_attention_fwd_bwd(dev, n, p, a, d):
     from han_amd import ops
     rng = np.random.default_rng(n + p)
-    M = rng.standard_normal((n, p, 64))
-    w, b, u = rng.standard_normal((64, a)) * 0.2, rng.standard_normal(a) * 0.2, rng.standard_normal(a)
+    M = rng.standard_normal((n, p, d))
+    w, b, u = rng.standard_normal((d, a)) * 0.2, rng.standard_normal(a) * 0.2, rng.standard_normal(a)
     Zr, br = ho.simple_att_layer(M, w, b, u, return_alphas=True)
     Z, beta = ops.sem_attn_fwd(_t(M, dev), _t(w, dev), _t(b, dev), _t(u, dev))
     assert np.abs(Z.cpu().numpy() - Zr).max() < TOL
     assert np.abs(beta.cpu().numpy() - br).max() < TOL
-    dZ = rng.standard_normal((n, 64))
+    dZ = rng.standard_normal((n, d))
     tM, tw, tb, tu = (torch.tensor(v, requires_grad=True) for v in (M, w, b, u))
     Zt, _ = ht.semantic_attention(tM, tw, tb, tu)
     (Zt * torch.tensor(dZ)).sum().backward()
@@ -444,12 +450,13 @@ def test_empty_inputs_are_noops(dev):
 
 
 # ----------------------------------------------------------- classifier / loss / opt
-@pytest.mark.parametrize("n,c,hc", [(5, 3, 1), (257, 4, 1), (100, 7, 2), (64, 16, 1)])
-def test_classifier_loss_matches_oracle(dev, n, c, hc):
+@pytest.mark.parametrize("n,c,hc,d", [(5, 3, 1, 64), (257, 4, 1, 64), (100, 7, 2, 64), (64, 16, 1, 64),
+                                      (5, 3, 1, 128), (257, 4, 2, 128), (300, 8, 1, 128), (64, 16, 1, 128)])
+def test_classifier_loss_matches_oracle(dev, n, c, hc, d):
     from han_amd import ops
     rng = np.random.default_rng(n + c)
-    Z = rng.standard_normal((n, 64))
-    Wc, bc = rng.standard_normal((hc, 64, c)) * 0.3, rng.standard_normal((hc, c)) * 0.1
+    Z = rng.standard_normal((n, d))
+    Wc, bc = rng.standard_normal((hc, d, c)) * 0.3, rng.standard_normal((hc, c)) * 0.1
     labels = rng.integers(0, c, n)
     mask = rng.random(n) < 0.5
     mask[0] = True
@@ -820,6 +827,94 @@ def test_captured_epoch_replay_matches_eager_and_oracle(dev):
     assert torch.equal(trainers[0].model.flat, trainers[1].model.flat)
     for k in ht.PARAM_ORDER:
         assert np.abs(getattr(trainers[0].model, k).detach().cpu().numpy() - bpo[k].numpy()).max() < 2e-4, k
+
+
+def test_workspace_growth_between_graph_replays(dev):
+    """The process-global scratch buffers are grow-only and a captured epoch replays with the raw
+    pointers it saw: a LARGER request for the same buffers between two replays (another model, a
+    bigger graph) must not free memory the graph still uses.  Capture a small epoch, then run a much
+    larger model eagerly (every workspace tag grows), then replay: bitwise the eager flow."""
+    from han_amd import ops, rng as hrng, synth
+    from han_amd.gat import HeteGAT_multi
+    from han_amd.trainer import HANTrainer
+    n, f, drop = 70, 12, 0.6
+    prob = make_problem(52, n, f, 2, 3, [0.08, 0.4])
+    x, graphs = gpu_inputs(prob, dev)
+    labels = _t(prob["labels"], dev, torch.int32)
+    tm = _t(prob["mask"].astype(np.uint8), dev, torch.uint8)
+    trainers = []
+    for capture in (True, False):
+        model, _ = build_model(prob, dev)
+        tr = HANTrainer(model, [x, x], graphs, labels, tm, attn_drop=drop, ffd_drop=drop, use_graph=True)
+        tr._capture = capture
+        trainers.append(tr)
+
+    def both():
+        outs = [[float(v) for v in tr.epoch()] for tr in trainers]
+        assert outs[0] == outs[1]
+    hrng.manual_seed(3)
+    trainers[0].epoch()
+    hrng.manual_seed(3)
+    trainers[1].epoch()
+    both(); both()                     # trainers[0] has captured and replayed once
+    assert trainers[0]._graph is not None
+    before = {k: v.data_ptr() for k, v in ops._workspaces.items()}
+    wl = synth.make_workload("syn-100k", device=dev, n_override=300_000)      # 60x the rows: every slab grows
+    big = HeteGAT_multi().build(wl["p"], wl["f"], wl["c"], device=dev)
+    tb = HANTrainer(big, [wl["x"]] * wl["p"], wl["graphs"], wl["labels"], wl["train_mask"], wl["val_mask"])
+    tb.epoch()
+    torch.cuda.synchronize()
+    grown = [k for k, v in ops._workspaces.items() if k in before and before[k] != v.data_ptr()]
+    assert grown, "the large model was expected to outgrow at least one workspace"
+    del tb, big, wl
+    torch.cuda.empty_cache()
+    junk = torch.full((64 << 20,), 7.0e30, device=dev)      # anything freed would be handed out again here
+    both(); both()
+    assert torch.equal(trainers[0].model.flat, trainers[1].model.flat)
+    del junk
+
+
+def test_inference_with_arbitrary_activation_callables(dev):
+    """models/gat.py:36: `activation` may be any callable (the reference's GAT class passes
+    lambda x: x).  Anything but ELU / identity is applied by torch on the kernels' pre-activation, per
+    head; forward against the oracle and the gradients through torch's autograd of the callable."""
+    from han_amd import layers, ops
+    prob = make_problem(78, 60, 10, 2, 3, [0.1, 0.4])
+    model, bp = build_model(prob, dev)
+    x, graphs = gpu_inputs(prob, dev)
+    sm_np = lambda a: np.exp(a - a.max(-1, keepdims=True)) / np.exp(a - a.max(-1, keepdims=True)).sum(-1, keepdims=True)
+    for tact, nact in ((torch.tanh, np.tanh), (lambda t: torch.softmax(t, -1), sm_np), (lambda t: t, lambda a: a)):
+        lg, fe, att = ho.hetegat_multi_inference([prob["x"]] * 2, 3, 60, False, 0.0, 0.0, prob["biases"], [8], [8, 1],
+                                                 prob["params"], activation=nact)
+        with torch.no_grad():
+            logits, final_embed, att_val = model.inference([x[None]] * 2, 3, 60, False, 0.0, 0.0, graphs, [8], [8, 1],
+                                                           activation=tact)
+        assert np.abs(logits.cpu().numpy() - lg).max() < TOL
+        assert np.abs(final_embed.cpu().numpy() - fe).max() < TOL
+        assert np.abs(att_val.cpu().numpy() - att).max() < TOL
+    # gradients with tanh: float64 autograd of the torch restatement with the same activation swapped in
+    import torch.nn.functional as Fnn
+    bpo = {k: v.clone().requires_grad_(True) for k, v in bp.items()}
+    og = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]
+    orig = Fnn.elu
+    try:
+        ht.Fnn.elu = torch.tanh
+        lref, _, _ = ht.hetegat_forward([torch.tensor(prob["x"][0])] * 2, og, bpo)
+    finally:
+        ht.Fnn.elu = orig
+    loss_ref = ht.masked_softmax_cross_entropy(lref, torch.tensor(prob["onehot"]), torch.tensor(prob["mask"]))
+    loss_ref.backward()
+    model.zero_grad_flat()
+    code, post = layers._act_code(torch.tanh)
+    M = model.node_level([x, x], graphs, 0.0, 0.0, True, code, post=post)
+    Z, _ = layers.SemanticAttention.apply(M, model.w_omega, model.b_omega, model.u_omega)
+    loss, _, _ = layers.ClassifierLoss.apply(Z, model.Wc, model.bc, _t(prob["labels"], dev, torch.int32),
+                                             _t(prob["mask"].astype(np.uint8), dev, torch.uint8),
+                                             1.0 / int(prob["mask"].sum()))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-4
+    for k in ht.PARAM_ORDER:
+        assert rel_err(getattr(model, k).grad.cpu().numpy(), bpo[k].grad.numpy()) < GTOL, k
 
 
 def test_training_learns_planted_communities(dev):

@@ -10,7 +10,7 @@ import torch
 from oracle import han_oracle as ho
 from oracle import han_oracle_torch as ht
 from tests import rng_ref
-from tests.helpers import load_params, make_problem, rel_err
+from tests.helpers import group_masks, load_params, make_problem, rel_err
 
 
 @pytest.fixture()
@@ -298,10 +298,16 @@ def test_model_variables_and_initialisers():
     assert abs(float(m.w_omega.std()) - 0.1) < 0.01
     m2 = HeteGAT_multi().build(2, 10, 3, (8, 8), (8, 8, 1), device="cpu")      # models/gat.py:48-57
     assert tuple(m2.W_1.shape) == (2, 64, 64) and tuple(m2.a1_1.shape) == (2, 8, 8)
+    # widths other than 8 x 8 (models/gat.py:42-57 leaves hid_units / n_heads free): variables keep the
+    # reference's shapes, whatever K*F' is; mp_att_size is free up to 128
+    m3 = HeteGAT_multi().build(2, 10, 3, (16,), (8, 1), 48, device="cpu")       # K*F' = 128
+    assert tuple(m3.W.shape) == (2, 10, 128) and tuple(m3.w_omega.shape) == (128, 48) and tuple(m3.Wc.shape) == (1, 128, 3)
+    m4 = HeteGAT_multi().build(2, 10, 3, (8, 8), (12, 4, 1), device="cpu")      # 96 wide, then 32 wide
+    assert tuple(m4.W_1.shape) == (2, 96, 32) and tuple(m4.w_omega.shape) == (32, 128)
     with pytest.raises(NotImplementedError):
-        HeteGAT_multi().build(2, 10, 3, (8,), (4, 1), device="cpu")            # K*F' != 64
+        HeteGAT_multi().build(2, 10, 3, (10,), (4, 1), device="cpu")           # head width not a lane-mapped size
     with pytest.raises(NotImplementedError):
-        HeteGAT_multi().build(2, 10, 3, (8, 8), (8, 4, 1), device="cpu")       # layer 1: 4*8 != 64
+        HeteGAT_multi().build(2, 10, 3, (32,), (8, 1), device="cpu")           # final width 256 > 128
     with pytest.raises(ValueError):
         HeteGAT_multi().build(2, 10, 3, (8, 8), (8, 1), device="cpu")          # n_heads too short
 
@@ -489,3 +495,116 @@ def test_mat_loader_follows_the_reference_script(tmp_path):
     rp, ci = ho.bias_to_csr(ho.adj_to_bias(adj[0][None], [n], 1))
     assert np.array_equal(g.rowptr.numpy(), rp) and np.array_equal(g.colidx.numpy(), ci)
     assert g.nnz == int((pap > 0).sum())
+
+
+def test_checkpoint_resume_is_bit_exact_with_dropout(cpu_ops, tmp_path):
+    """A resumed run must continue the SAME dropout mask stream and early-stopping bookkeeping:
+    save after epoch 1, run epochs 2-3; a fresh trainer that loads the checkpoint and runs two
+    epochs must end on identical parameters (the checkpoint carries the seed-stream state)."""
+    from han_amd import rng as hrng
+    from han_amd.trainer import HANTrainer
+    prob = make_problem(43, 40, 6, 2, 3, [0.1, 0.3])
+    xt = torch.tensor(prob["x"][0], dtype=torch.float32)
+
+    def mk():
+        model, _ = _cpu_model(prob)
+        return model, HANTrainer(model, [xt, xt], _cpu_graphs(prob), torch.tensor(prob["labels"], dtype=torch.int32),
+                                 torch.tensor(prob["mask"].astype(np.uint8)), attn_drop=0.6, ffd_drop=0.6)
+    hrng.manual_seed(5)
+    model, tr = mk()
+    tr.epoch()
+    tr.early_stopping(1.25, 0.5)
+    path = str(tmp_path / "resume.pt")
+    tr.save_checkpoint(path)
+    tr.epoch(); tr.epoch()
+    want = model.flat.clone()
+    hrng.manual_seed(12345)                  # a different process: the stream state comes from the file
+    model2, tr2 = mk()
+    tr2.load_checkpoint(path)
+    assert (tr2.vlss_mn, tr2.vacc_mx, tr2.curr_step) == (1.25, 0.5, 0) and tr2.best_state is not None
+    tr2.epoch(); tr2.epoch()
+    assert torch.equal(model2.flat, want)
+    # a checkpoint of another configuration is refused
+    prob3 = make_problem(43, 40, 7, 2, 3, [0.1, 0.3])
+    model3, _ = _cpu_model(prob3)
+    tr3 = HANTrainer(model3, [torch.zeros(40, 7)] * 2, _cpu_graphs(prob3), torch.tensor(prob["labels"], dtype=torch.int32),
+                     torch.tensor(prob["mask"].astype(np.uint8)))
+    with pytest.raises(ValueError):
+        tr3.load_checkpoint(path)
+
+
+def test_module_apply_keeps_parameters_bound_to_flat():
+    """nn.Module.to()/.float()/... must not detach the parameter views from the flat buffer that
+    Adam updates (they are re-created on the moved buffer); a dtype change is refused."""
+    from han_amd.gat import HeteGAT_multi
+    model = HeteGAT_multi().build(2, 5, 3, device="cpu")
+    w0 = model.W.detach().clone()
+    model.to("cpu").float()
+    assert torch.equal(model.W, w0)
+    lo = model.flat.data_ptr()
+    hi = lo + model.flat.numel() * 4
+    for name, _ in model.param_shapes():
+        v = getattr(model, name)
+        assert lo <= v.data_ptr() < hi and lo <= v.grad.data_ptr() - model.flat_grad.data_ptr() + lo < hi, name
+    model.flat.add_(1.0)                     # what the optimiser does
+    assert torch.equal(model.W, w0 + 1.0)
+    with pytest.raises(TypeError):
+        model.double()
+
+
+def test_arbitrary_activation_callable_on_cpu_backend(cpu_ops):
+    """models/gat.py:36 takes any `activation`: callables other than ELU / identity are applied by torch
+    on the kernels' pre-activation, per head (the last axis is the head's F' features)."""
+    from han_amd import layers
+    prob = make_problem(77, 30, 6, 2, 3, [0.1, 0.4])
+    model, bp = _cpu_model(prob)
+    x = torch.tensor(prob["x"][0], dtype=torch.float32)
+    for tact, nact in ((torch.tanh, np.tanh),
+                       (lambda t: torch.softmax(t, -1), lambda a: np.exp(a - a.max(-1, keepdims=True))
+                        / np.exp(a - a.max(-1, keepdims=True)).sum(-1, keepdims=True))):
+        _, fe_ref, _ = ho.hetegat_multi_inference([prob["x"]] * 2, 3, 30, False, 0.0, 0.0, prob["biases"], [8], [8, 1],
+                                                  prob["params"], activation=nact)
+        code, post = layers._act_code(tact)
+        with torch.no_grad():
+            M = model.node_level([x, x], _cpu_graphs(prob), 0.0, 0.0, False, code, post=post)
+            Z, _ = layers.SemanticAttention.apply(M, model.w_omega, model.b_omega, model.u_omega)
+        assert np.abs(Z.numpy() - fe_ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("K,FP,A", [(8, 16, 128), (4, 8, 128), (3, 8, 48), (12, 8, 80)])
+@pytest.mark.parametrize("drop", [0.0, 0.6])
+def test_general_head_widths_on_cpu_backend(cpu_ops, K, FP, A, drop):
+    """Host logic of the widths other than 8 x 8 (han_amd.gat.node_level / semantic / classifier_loss): head
+    groups of 64 columns with seed + g, zero-weight completion heads, zero-padded K3 / classifier operands --
+    loss and every gradient against float64 autograd of the oracle with the same hash masks."""
+    from han_amd import ops, rng as hrng
+    from han_amd.gat import HeteGAT_multi
+    n, f, p = 40, 9, 2
+    prob = make_problem(900 + K, n, f, p, 3, [0.1, 0.4], hid_units=[FP], n_heads=(K, 1), mp_att_size=A)
+    model = HeteGAT_multi().build(p, f, 3, (FP,), (K, 1), A, device="cpu")
+    bp = ht.to_batched(prob["params"])
+    load_params(model, bp)
+    hrng.manual_seed(11)
+    seeds = [hrng.next_seed() for _ in range(p)]
+    hrng.manual_seed(11)
+    masks, keep = None, 1.0
+    if drop > 0:
+        keep = rng_ref.keep_prob32(drop)
+        masks = [group_masks(seeds[q], n, f, K, FP, *ho.bias_to_csr(prob["biases"][q]), drop) for q in range(p)]
+    bpo = {k: v.clone().requires_grad_(True) for k, v in bp.items()}
+    og = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]
+    lref, _, _ = ht.hetegat_forward([torch.tensor(prob["x"][0])] * p, og, bpo, keep_in=keep, keep_coef=keep, masks=masks)
+    loss_ref = ht.masked_softmax_cross_entropy(lref, torch.tensor(prob["onehot"]), torch.tensor(prob["mask"]))
+    loss_ref.backward()
+    x = torch.tensor(prob["x"][0], dtype=torch.float32)
+    model.zero_grad_flat()
+    M = model.node_level([x] * p, _cpu_graphs(prob), drop, drop, True, ops.ACT_ELU)
+    assert tuple(M.shape) == (n, p, K * FP)
+    Z, _ = model.semantic(M)
+    loss, _, logits = model.classifier_loss(Z, torch.tensor(prob["labels"], dtype=torch.int32),
+                                            torch.tensor(prob["mask"].astype(np.uint8)), 1.0 / int(prob["mask"].sum()))
+    loss.backward()
+    assert np.abs(logits.detach().numpy() - lref.detach().numpy()).max() < 1e-4
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-5
+    for k in ht.PARAM_ORDER:
+        assert rel_err(getattr(model, k).grad.numpy(), bpo[k].grad.numpy()) < 1e-4, k
