@@ -12,6 +12,7 @@
 // fp32-MFMA ridge: HBM-bound in eval, MFMA-bound in training where the per-head
 // input dropout (layers.py:18-19 sits inside the per-head call) forces one
 // masked MFMA per head per 16-column tile.
+#include <stdlib.h>
 #include "han_common.h"
 
 namespace {
@@ -200,6 +201,249 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a_in
                 if (a.thr_fts < HAN_KEEP_ALL) {
                     // projected-row dropout (layers.py:31-32): the keep bit rides in the lowest
                     // mantissa bit of the STORED element (fp32 bit 0 / bf16 bit 0)
+                    const int d = 16 * t + l15;
+                    const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_FTS,
+                                                    (uint32_t)(row + a.row_offset), (uint32_t)(d >> 2));
+                    keepbit = rn.field(d & 3) < a.thr_fts ? 1u : 0u;
+                    stamp = 1;
+                }
+                if (row < a.N) {
+                    if (a.h_bf16) {
+                        uint32_t b = han_f32_to_bf16_bits(v);
+                        if (stamp) b = (b & ~1u) | keepbit;
+                        reinterpret_cast<uint16_t *>(a.H)[row * HAN_D + 16 * t + l15] = (uint16_t)b;
+                    } else {
+                        if (stamp) v = __uint_as_float((__float_as_uint(v) & ~1u) | keepbit);
+                        reinterpret_cast<float *>(a.H)[row * HAN_D + 16 * t + l15] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward on the bf16 matrix pipe with fp32-class accuracy ("bf16 x 6").
+//
+// An fp32 number splits EXACTLY into three bf16 terms by truncation, x = hi + mid + lo (8 + 8 + 8
+// significand bits; every subtraction below is exact).  With both operands split, the six products
+//     hi*hi' + hi*mid' + mid*hi' + hi*lo' + lo*hi' + mid*mid'
+// (each bf16 x bf16 product is exact in the fp32 accumulator) leave out only mid*lo', lo*mid', lo*lo':
+// < 2^-23 of |x w| per term, the size of an fp32 rounding -- against 6 MFMAs of
+// v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32) where the exact-fp32 pipe needs 8
+// v_mfma_f32_16x16x4_f32 of 32 cycles: 2.7x less matrix time, and the per-head input-dropout masks
+// (layers.py:18-19; two heads per 16-column tile at F' = 8, so every tile is issued twice) become
+// packed 16-bit ANDs on the A fragments instead of fp32 selects.
+// Block: 128 rows x all 64 columns, K-step 32; X / W tiles are split while they are staged into LDS
+// (X row-major [row][k], W transposed [col][k], 96-B rows) so that a lane's 8 k-values are one
+// 16-B read.  DROP is built for F' = 8 (the reference shape); without dropout any head shape runs.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int B6_ROWS = 128;             // rows per block
+constexpr int B6_LDB = 96;               // bytes per LDS row: 32 bf16 + 32 B pad (24 dwords: the 16-lane groups of a
+                                         // ds_read_b128 then start on 16 distinct multiples of 4 dwords -- conflict-free;
+                                         // 80-B rows measured 45 % conflict cycles)
+constexpr int B6_XBYTES = B6_ROWS * B6_LDB;
+constexpr int B6_WBYTES = HAN_D * B6_LDB;
+
+// x == h + m + l exactly; each term has <= 8 significand bits (its low 16 bits are zero)
+__device__ __forceinline__ void b6_split(float x, uint32_t &h, uint32_t &m, uint32_t &l) {
+    h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));
+}
+// two truncated terms -> one packed bf16 pair (element 0 in the low half)
+__device__ __forceinline__ uint32_t b6_pack(uint32_t e0, uint32_t e1) {
+    return __builtin_amdgcn_perm(e1, e0, 0x07060302u);
+}
+__device__ __forceinline__ f32x4 b6_mfma(const i32x4 &a, const i32x4 &b, const f32x4 &c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                   0, 0, 0);
+}
+// per 16-bit field f of w: 0xFFFF if f < thr else 0 (thr < 2^16 in both halves of `thr2`):
+// saturating thr - f is non-zero exactly when f < thr; min(.,1) -> 0/1; 0 - that -> 0 / 0xFFFF
+// (three packed 16-bit instructions for two fields)
+__device__ __forceinline__ uint32_t b6_keep_masks(uint32_t w, uint32_t thr2, uint32_t one2) {
+    // inline asm: hipcc turns the vector-typed form into per-field v_cmp + v_cndmask + re-pack
+    uint32_t s, m;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(s) : "v"(thr2), "v"(w));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(s), "v"(one2));
+    asm("v_pk_sub_u16 %0, 0, %1" : "=v"(s) : "v"(m));
+    return s;
+}
+
+template <bool DROP, bool XBF>
+__global__ __launch_bounds__(256) void project_fwd_b6_kernel(const ProjFwdArgs a_in) {
+    ProjFwdArgs a = a_in;
+    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
+    constexpr int NX = XBF ? 1 : 3;       // split terms of X (a bf16 X is its own high term)
+    constexpr int HPT = DROP ? 2 : 1;     // heads per 16-column tile (F' = 8 when DROP)
+    constexpr int MT = 2;                 // 16-row tiles per wave
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NX * B6_XBYTES + 3 * B6_WBYTES];
+    unsigned char *Xs = lds;                          // [NX][128][96 B]
+    unsigned char *Ws = lds + NX * B6_XBYTES;         // [3][64][96 B]   (transposed: [col][k])
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * B6_ROWS;
+
+    f32x4 acc[MT][4][HPT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int hh = 0; hh < HPT; ++hh) acc[m][t][hh] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging registers: X 4 x float4 (row = idx >> 3, k4 = (idx & 7) * 4), W 8 floats (col = tid & 63,
+    // k = (tid >> 6) * 8 + j: 64 lanes read 64 consecutive columns per load)
+    float4_t xr[4];
+    float wr[8];
+    auto load_tile = [&](int k0) {
+        // unconditional loads from clamped addresses + selects: a predicated load becomes a branch
+        // around it with its own s_waitcnt, which serialises the tile's loads
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx >> 3, c4 = (idx & 7) * 4;
+            const int64_t row = row0 + r;
+            const bool ok = row < a.N && k0 + c4 < a.F;
+            const int64_t rc = row < a.N ? row : a.N - 1;
+            const int kc = k0 + c4 < a.F ? k0 + c4 : a.F - 4;       // F % 4 == 0 (vec path)
+            const float4_t v = load_x4(a.X, XBF, rc * a.ldx + kc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xr[i][e] = ok ? v[e] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kw = k0 + (tid >> 6) * 8 + j;
+            const float v = a.W[(int64_t)(kw < a.F ? kw : a.F - 1) * HAN_D + (tid & 63)];
+            wr[j] = kw < a.F ? v : 0.f;
+        }
+    };
+    const uint32_t thr2 = (a.thr_in & 0xFFFFu) * 0x00010001u, one2 = 0x00010001u;   // keep iff field < thr_in
+    load_tile(0);
+    for (int k0 = 0; k0 < a.F; k0 += 32) {
+        __syncthreads();   // the previous tile's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int off = (idx >> 3) * B6_LDB + (idx & 7) * 8;
+            uint32_t h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b6_split(xr[i][e], h[e], m[e], l[e]);
+            *reinterpret_cast<uint2 *>(Xs + off) = make_uint2(b6_pack(h[0], h[1]), b6_pack(h[2], h[3]));
+            if (!XBF) {
+                *reinterpret_cast<uint2 *>(Xs + B6_XBYTES + off) = make_uint2(b6_pack(m[0], m[1]), b6_pack(m[2], m[3]));
+                *reinterpret_cast<uint2 *>(Xs + 2 * B6_XBYTES + off) = make_uint2(b6_pack(l[0], l[1]), b6_pack(l[2], l[3]));
+            }
+        }
+        {
+            uint32_t h[8], m[8], l[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b6_split(wr[j], h[j], m[j], l[j]);
+            const int off = (tid & 63) * B6_LDB + (tid >> 6) * 16;
+            i32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (int)b6_pack(h[2 * i], h[2 * i + 1]);
+            *reinterpret_cast<i32x4 *>(Ws + off) = v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (int)b6_pack(m[2 * i], m[2 * i + 1]);
+            *reinterpret_cast<i32x4 *>(Ws + B6_WBYTES + off) = v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (int)b6_pack(l[2 * i], l[2 * i + 1]);
+            *reinterpret_cast<i32x4 *>(Ws + 2 * B6_WBYTES + off) = v;
+        }
+        __syncthreads();
+        if (k0 + 32 < a.F) load_tile(k0 + 32);   // in flight under the MFMAs
+        // B fragments of the four column tiles: B[k = 8*l4 + j][col = 16t + l15]
+        i32x4 bf[4][3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3)
+                bf[t][s3] = *reinterpret_cast<const i32x4 *>(Ws + s3 * B6_WBYTES + (16 * t + l15) * B6_LDB + 16 * l4);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int lr = 16 * (w * MT + m) + l15;
+            i32x4 af[NX];
+#pragma unroll
+            for (int s3 = 0; s3 < NX; ++s3)
+                af[s3] = *reinterpret_cast<const i32x4 *>(Xs + s3 * B6_XBYTES + lr * B6_LDB + 16 * l4);
+            if (!DROP) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    f32x4 c = acc[m][t][0];
+                    if (!XBF) {
+                        c = b6_mfma(af[1], bf[t][1], c);      // small terms first
+                        c = b6_mfma(af[2], bf[t][0], c);
+                        c = b6_mfma(af[1], bf[t][0], c);
+                    }
+                    c = b6_mfma(af[0], bf[t][2], c);
+                    c = b6_mfma(af[0], bf[t][1], c);
+                    c = b6_mfma(af[0], bf[t][0], c);
+                    acc[m][t][0] = c;
+                }
+            } else {
+                // keep masks of this lane's 8 elements (row nglob, k = k0 + 8*l4 + j) for the 8 heads:
+                // call c serves heads 4c..4c+3: x = fields of heads 4c, 4c+1; y = heads 4c+2, 4c+3
+                const uint32_t nglob = (uint32_t)(row0 + lr + a.row_offset);
+                uint32_t mk[8][2][2];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t kglob = (uint32_t)(k0 + 8 * l4 + j);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob, kglob * 2u + (uint32_t)c);
+                        mk[j][c][0] = b6_keep_masks(rn.x, thr2, one2);
+                        mk[j][c][1] = b6_keep_masks(rn.y, thr2, one2);
+                    }
+                }
+#pragma unroll
+                for (int head = 0; head < 8; ++head) {
+                    const int t = head >> 1, hh = head & 1;
+                    const int c = head >> 2, wd = (head >> 1) & 1;
+                    const uint32_t sel = (head & 1) ? 0x07060302u : 0x05040100u;
+                    i32x4 am[NX];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t pm = __builtin_amdgcn_perm(mk[2 * i + 1][c][wd], mk[2 * i][c][wd], sel);
+#pragma unroll
+                        for (int s3 = 0; s3 < NX; ++s3) am[s3][i] = af[s3][i] & (int)pm;
+                    }
+                    f32x4 cc = acc[m][t][hh];
+                    if (!XBF) {
+                        cc = b6_mfma(am[1], bf[t][1], cc);
+                        cc = b6_mfma(am[2], bf[t][0], cc);
+                        cc = b6_mfma(am[1], bf[t][0], cc);
+                    }
+                    cc = b6_mfma(am[0], bf[t][2], cc);
+                    cc = b6_mfma(am[0], bf[t][1], cc);
+                    cc = b6_mfma(am[0], bf[t][0], cc);
+                    acc[m][t][hh] = cc;
+                }
+            }
+        }
+    }
+    // epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg (as the fp32 kernel's)
+    const int myhh = HPT > 1 ? l15 / 8 : 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 16 * (w * MT + m) + l4 * 4 + r;
+                float v = acc[m][t][0][r];
+                if (HPT > 1) v = myhh ? acc[m][t][HPT - 1][r] : v;
+                if (DROP) v *= a.inv_keep_in;
+                uint32_t keepbit = 0, stamp = 0;
+                if (a.thr_fts < HAN_KEEP_ALL) {
                     const int d = 16 * t + l15;
                     const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_FTS,
                                                     (uint32_t)(row + a.row_offset), (uint32_t)(d >> 2));
@@ -606,6 +850,22 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
         if (!workspace || workspace_bytes < han_project_fwd_workspace(N, F, K, FP)) return HAN_E_WORKSPACE;
         a.partial = (float *)workspace;
     }
+    // bf16 x 6 matrix-pipe kernel (fp32-class accuracy, see project_fwd_b6_kernel): whole-F blocks of 128
+    // rows with 16-byte X loads; with dropout it is built for the reference head shape (8 x 8)
+    const char *b6env = getenv("HAN_K1_B6");
+    const bool b6 = vec && nsplit == 1 && N >= 64 * 256 && (in_drop == 0.f || (K == 8 && FP == 8)) &&
+                    !(b6env && b6env[0] == '0');
+    if (b6) {
+        const dim3 g6((unsigned)((N + B6_ROWS - 1) / B6_ROWS));
+        if (in_drop > 0.f) {
+            if (a.x_bf16) project_fwd_b6_kernel<true, true><<<g6, 256, 0, st>>>(a);
+            else project_fwd_b6_kernel<true, false><<<g6, 256, 0, st>>>(a);
+        } else {
+            if (a.x_bf16) project_fwd_b6_kernel<false, true><<<g6, 256, 0, st>>>(a);
+            else project_fwd_b6_kernel<false, false><<<g6, 256, 0, st>>>(a);
+        }
+        HAN_CHECK_LAUNCH();
+    }
     const dim3 grid((unsigned)((N + 64 * mt - 1) / (64 * mt)), (unsigned)nsplit);
 #define HAN_LAUNCH_FWD(MTC)                                                                  \
     HAN_DISPATCH_FP(FP, {                                                                    \
@@ -617,7 +877,7 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
             else project_fwd_kernel<FPC, false, MTC, false><<<grid, 256, 0, st>>>(a);        \
         }                                                                                    \
     })
-    if (mt == 2) { HAN_LAUNCH_FWD(2) } else { HAN_LAUNCH_FWD(1) }
+    if (b6) { /* done above */ } else if (mt == 2) { HAN_LAUNCH_FWD(2) } else { HAN_LAUNCH_FWD(1) }
 #undef HAN_LAUNCH_FWD
     HAN_CHECK_LAUNCH();
     if (nsplit > 1) {

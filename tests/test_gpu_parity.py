@@ -70,6 +70,73 @@ def test_project_dropout_matches_hash_masks(dev, n, f):
     assert rel_err(dW.cpu().numpy(), dWref) < 1e-4
 
 
+@pytest.mark.parametrize("n,f,xbf", [(16384 + 77, 64, False), (20000, 1870 - 2, False), (17000, 256, True),
+                                     (40000, 36, False)])
+def test_project_matrix_pipe_kernel_fp32_class_accuracy(dev, n, f, xbf, monkeypatch):
+    """Large inputs run K1 on the bf16 matrix pipe with an exact three-way bf16 split of both operands
+    (six products; project_fwd_b6_kernel).  It must be as accurate as the exact-fp32 MFMA kernel: both
+    against the float64 product, at the ACM feature width (1868 ~ 1870, F % 4 == 0) too; F = 36 has a
+    partial last K-step; xbf: bf16 features (their split is one term)."""
+    from han_amd import ops
+    rng = np.random.default_rng(n + f)
+    x = rng.standard_normal((n, f)) * np.exp(rng.standard_normal((n, 1)))       # rows of very different scale
+    W = rng.standard_normal((f, 64)) * 0.2
+    a = [rng.standard_normal((8, 8)) for _ in range(2)] + [rng.standard_normal(8) for _ in range(2)]
+    xt = _t(x, dev)
+    if xbf:
+        xt = xt.to(torch.bfloat16)
+        x = xt.to(torch.float32).cpu().numpy().astype(np.float64)
+    args = (xt, _t(W, dev), _t(a[0], dev), _t(a[1], dev), _t(a[2], dev), _t(a[3], dev))
+    Href = x @ W.astype(np.float32).astype(np.float64)
+    scale = np.abs(x) @ np.abs(W)                    # sum |x w|: what an fp32 dot product's error scales with
+    monkeypatch.setenv("HAN_K1_B6", "0")
+    H32, _, _ = ops.project_fwd(*args)
+    monkeypatch.setenv("HAN_K1_B6", "1")
+    H6, f1, f2 = ops.project_fwd(*args)
+    e32 = np.abs(H32.cpu().numpy() - Href) / scale
+    e6 = np.abs(H6.cpu().numpy() - Href) / scale
+    assert e6.max() < 4e-7, (e6.max(), e32.max())      # a few fp32 ulps of sum |x w|, like the fp32 pipe
+    assert e6.max() < 4 * max(e32.max(), 5e-8)
+    f1ref = (Href.reshape(n, 8, 8) * a[0][None]).sum(-1) + a[2]
+    assert np.abs(f1.cpu().numpy() - f1ref).max() < 1e-3 * max(1.0, np.abs(f1ref).max())
+
+
+@pytest.mark.parametrize("f,xbf", [(44, False), (256, False), (64, True)])
+def test_project_matrix_pipe_kernel_dropout_masks(dev, f, xbf, monkeypatch):
+    """The matrix-pipe kernel with the per-head input dropout (layers.py:18-19: packed 16-bit keep masks on
+    the A fragments) and the projected-row keep bits, against the NumPy-regenerated hash masks -- and
+    bit-for-bit the same keep decisions as the fp32 kernel."""
+    from han_amd import ops
+    monkeypatch.setenv("HAN_K1_B6", "1")
+    n = 16384 + 130
+    rng = np.random.default_rng(f)
+    seed, drop, off = 0x0BADC0DE1234, 0.6, 977
+    x = rng.standard_normal((n, f))
+    W = rng.standard_normal((f, 64)) * 0.2
+    a = [rng.standard_normal((8, 8)) for _ in range(2)] + [rng.standard_normal(8) for _ in range(2)]
+    xt = _t(x, dev)
+    if xbf:
+        xt = xt.to(torch.bfloat16)
+        x = xt.to(torch.float32).cpu().numpy().astype(np.float64)
+    H, _, _ = ops.project_fwd(xt, _t(W, dev), _t(a[0], dev), _t(a[1], dev), _t(a[2], dev), _t(a[3], dev),
+                              in_drop=drop, fts_drop=drop, seed=seed, row_offset=off)
+    keep = rng_ref.keep_prob32(drop)
+    sm = rng_ref.seq_mask(seed, n, f, 8, drop, row_offset=off)
+    Wd = W.astype(np.float32).astype(np.float64)
+    Href = np.concatenate([(x / keep * sm[k]) @ Wd[:, 8 * k:8 * k + 8] for k in range(8)], 1)
+    assert np.abs(H.cpu().numpy() - Href).max() < 1e-5 * max(1.0, np.abs(Href).max())
+    fm = rng_ref.fts_mask(seed, n, 64, drop, row_offset=off)
+    assert np.array_equal((H.cpu().numpy().view(np.uint32) & 1).astype(np.float64), fm)
+    # other drop rates exercise the threshold arithmetic of the packed compare (odd / even thresholds)
+    for dr in (0.25, 0.9):
+        H2, _, _ = ops.project_fwd(xt, _t(W, dev), _t(a[0], dev), _t(a[1], dev), _t(a[2], dev), _t(a[3], dev),
+                                   in_drop=dr, seed=seed, row_offset=off)
+        kp = rng_ref.keep_prob32(dr)
+        sm2 = rng_ref.seq_mask(seed, n, f, 8, dr, row_offset=off)
+        Href2 = np.concatenate([(x / kp * sm2[k]) @ Wd[:, 8 * k:8 * k + 8] for k in range(8)], 1)
+        assert np.abs(H2.cpu().numpy() - Href2).max() < 1e-5 * max(1.0, np.abs(Href2).max()), dr
+
+
 @pytest.mark.parametrize("n,f", [(33, 70), (3025, 130)])
 def test_project_bwd_no_dropout(dev, n, f):
     from han_amd import ops
