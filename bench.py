@@ -291,6 +291,9 @@ def main():
     ap.add_argument("--hbm-regime-nodes", type=int, default=10_000_000,
                     help="rows of the extra single-meta-path table on which the K2 kernels are re-timed in the "
                          "HBM-served regime after the timed region (0 = skip; single GPU only)")
+    ap.add_argument("--reorder", choices=("none", "bfs"), default="none",
+                    help="locality pass (han_amd.reorder): breadth-first relabelling of the nodes before training "
+                         "(single GPU; the pass itself is timed separately and reported)")
     ap.add_argument("--table-dtype", choices=("f32", "bf16"), default="f32",
                     help="storage of X and of the H/g gather tables (bf16 = the 10M-node config's "
                          "'bf16 feats'); accumulation is fp32 either way")
@@ -333,6 +336,20 @@ def main():
     wl = synth.make_workload(args.workload, device=dev, n_override=args.nodes or None,
                              rows=(part.row_start, part.row_end) if part is not None else None)
     n, p = wl["n"], wl["p"]
+    reorder_info = None
+    if args.reorder != "none":
+        if part is not None:
+            raise SystemExit("--reorder is a single-process pass over the whole graph")
+        from han_amd import reorder
+        torch.cuda.synchronize()
+        t_r = time.perf_counter()
+        halo_before = reorder.halo_fraction(wl["graphs"], 8)
+        rel = reorder.relabel(wl, args.reorder)
+        wl = rel.wl
+        torch.cuda.synchronize()
+        reorder_info = {"method": args.reorder, "seconds": round(time.perf_counter() - t_r, 2),
+                        "halo_fraction_8_ranks_before": [round(h, 4) for h in halo_before],
+                        "halo_fraction_8_ranks_after": [round(h, 4) for h in reorder.halo_fraction(wl["graphs"], 8)]}
     gen = torch.Generator().manual_seed(0)
     tdt = torch.bfloat16 if args.table_dtype == "bf16" else torch.float32
     model = HeteGAT_multi().build(p, wl["f"], wl["c"], (8,), (8, 1), 128, device=dev, generator=gen,
@@ -418,6 +435,7 @@ def main():
                        "parallelism": f"node-partition x{world}" if world > 1 else
                        ("single GPU, epoch replayed from a hipGraph" if use_graph else "single GPU"),
                        **({"exchange": exchange} if exchange is not None else {}),
+                       **({"reorder": reorder_info} if reorder_info is not None else {}),
                        "dropout": "0.6/0.6 (train step)", "optimizer": "TF-form Adam lr 0.005, L2 0.001"},
             "final": {"train_loss": round(tl, 5), "train_acc": round(ta, 5),
                       "val_loss": round(vl, 5), "val_acc": round(va, 5)},

@@ -48,6 +48,18 @@ __device__ __forceinline__ float dot4(const float4_t &x, const float4_t &y) {
     return x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
 }
 
+// XCD-aware work order.  Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each XCD
+// has its own 4 MB L2), and a grid-stride sweep keeps ~gridDim.x * 4 consecutive rows in flight.  With the
+// identity order every XCD touches rows spread over that whole stripe, so on a graph with locality all eight
+// L2s cache the SAME source window (each source row is fetched up to 8 times per sweep).  Here the blocks of
+// one XCD take one contiguous eighth of every stripe instead: the eight L2s hold eight different windows.
+// Pure speed: any bijection of the work units is correct; it is the identity when gridDim.x % 8 != 0.
+__device__ __forceinline__ int64_t xcd_first_unit(int wave_in_block) {
+    const unsigned b = blockIdx.x, g = gridDim.x;
+    const unsigned vb = (g % 8u == 0u) ? (b % 8u) * (g / 8u) + b / 8u : b;
+    return (int64_t)vb * 4 + wave_in_block;
+}
+
 struct FwdArgs {
     const int64_t *rowptr;
     const int32_t *colidx;
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) 
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
     const int head = (4 * q) / FP;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wave0 = xcd_first_unit(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const float4_t c4 = *reinterpret_cast<const float4_t *>(a.c + 4 * q);
     const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
@@ -658,7 +670,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
     const int head = (4 * q) / FP;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wave0 = xcd_first_unit(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const bool drop_c = a.thr_coef < HAN_KEEP_ALL;
     const float4_t a14 = *reinterpret_cast<const float4_t *>(a.a1 + 4 * q);

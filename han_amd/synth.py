@@ -159,6 +159,12 @@ CONFIGS = {
     "syn-1m-skew": dict(n=1_000_000, f=256, c=4, graphs=[("powerlaw", 50_000_000, 2.1)] * 4),
     # locality: neighbours within +-20000 of the row id -> halo exchange under a node partition
     "syn-1m-local": dict(n=1_000_000, f=256, c=4, graphs=[("banded", 50, 20_000)] * 4),
+    # the same locality hidden behind arbitrary node ids (what a real data set looks like): the banded graphs
+    # under ONE random relabelling of the nodes -- the input of the locality pass (han_amd.reorder)
+    "syn-1m-local-shuffled": dict(n=1_000_000, f=256, c=4, graphs=[("banded_shuffled", 50, 20_000)] * 4),
+    # tighter communities (neighbours within +-2000 of the row id), ids shuffled: after the locality pass the
+    # source window of the rows one XCD has in flight fits its 4 MB L2
+    "syn-1m-comm-shuffled": dict(n=1_000_000, f=256, c=4, graphs=[("banded_shuffled", 50, 2_000)] * 4),
     "syn-100k": dict(n=100_000, f=256, c=4, graphs=[("regular", 50)] * 4),
     # BASELINE.json configs[4] (meant for 8 GPUs; fits one 288 GB MI355X with bf16 tables)
     "syn-10m": dict(n=10_000_000, f=256, c=4, graphs=[("regular", 50)] * 8),
@@ -174,6 +180,14 @@ def make_graph(spec, n, seed, device, rows=None):
         return powerlaw_graph(n, spec[1], spec[2], seed, device, rows=rows)
     if kind == "banded":
         return banded_graph(n, spec[1], min(spec[2], max(n // 4, 1)), seed, device, rows=rows)
+    if kind == "banded_shuffled":
+        if rows is not None:
+            raise NotImplementedError("the shuffled-ids workload is generated whole (single process)")
+        from .reorder import permute_graph
+        g = banded_graph(n, spec[1], min(spec[2], max(n // 4, 1)), seed, device)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(424242 + n)                  # one relabelling for all meta-paths of a workload
+        return permute_graph(g, torch.randperm(n, generator=gen, device=device))
     if kind == "bernoulli":
         g = bernoulli_graph(n, spec[1], seed, device)
         if rows is None:

@@ -1397,3 +1397,34 @@ def test_multi_layer_stack_matches_oracle(dev, drop, residual):
     assert abs(float(loss.detach()) - float(loss_ref.detach())) < 5e-4 * max(1.0, float(loss_ref.detach()))
     for k in ht.param_order(bp):
         assert rel_err(getattr(model, k).grad.cpu().numpy(), bpo[k].grad.numpy()) < GTOL, k
+
+
+def test_locality_pass_is_a_pure_relabelling(dev):
+    """han_amd.reorder on the real kernels: a breadth-first relabelling of a graph whose locality hides
+    behind shuffled ids changes nothing but the order of the nodes -- loss, accuracy, gradients equal, the
+    per-node outputs equal after unpermute() -- while the 8-way halo shrinks from all-gather to a few %."""
+    from han_amd import ops, reorder, synth
+    from han_amd.gat import HeteGAT_multi
+    n, f, p = 20000, 16, 2
+    gen = torch.Generator(device=dev).manual_seed(3)
+    shuf = torch.randperm(n, generator=gen, device=dev)
+    graphs = [reorder.permute_graph(synth.banded_graph(n, 12, 150, 5 + q, dev), shuf) for q in range(p)]
+    x = torch.randn((n, f), device=dev, generator=gen)
+    labels = torch.randint(0, 3, (n,), device=dev, generator=gen, dtype=torch.int32)
+    mask = (torch.rand((n,), device=dev, generator=gen) < 0.3).to(torch.uint8)
+    wl = dict(x=x, labels=labels, train_mask=mask, val_mask=mask, graphs=graphs)
+    rel = reorder.relabel(wl)
+    assert max(reorder.halo_fraction(rel.wl["graphs"], 8)) < 0.15 < 0.6 < min(reorder.halo_fraction(graphs, 8))
+    res = []
+    for w, back in ((wl, lambda t: t), (rel.wl, rel.unpermute)):
+        model = HeteGAT_multi().build(p, f, 3, device=dev, generator=torch.Generator().manual_seed(0))
+        model.zero_grad_flat()
+        M = model.node_level([w["x"]] * p, w["graphs"], 0.0, 0.0, True, ops.ACT_ELU)
+        Z, att = model.semantic(M)
+        loss, acc, logits = model.classifier_loss(Z, w["labels"], w["train_mask"], 1.0 / int(mask.sum()))
+        loss.backward()
+        res.append((float(loss.detach()), float(acc), back(logits.detach()), back(Z.detach()), model.flat_grad.clone()))
+    (l0, a0, lg0, z0, g0), (l1, a1, lg1, z1, g1) = res
+    assert abs(l0 - l1) < 1e-5 and abs(a0 - a1) < 1e-6
+    assert float((lg0 - lg1).abs().max()) < TOL and float((z0 - z1).abs().max()) < TOL
+    assert float((g0 - g1).abs().max()) < 1e-4 * max(1.0, float(g0.abs().max()))

@@ -608,3 +608,66 @@ def test_general_head_widths_on_cpu_backend(cpu_ops, K, FP, A, drop):
     assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-5
     for k in ht.PARAM_ORDER:
         assert rel_err(getattr(model, k).grad.numpy(), bpo[k].grad.numpy()) < 1e-4, k
+
+
+def test_locality_pass_relabelling_roundtrip():
+    """han_amd.reorder: permute_graph keeps the edge multiset (values travel with the edges), bfs_order is a
+    permutation that recovers hidden locality (mean |i - j| and the 8-way halo shrink on a banded graph
+    whose ids were shuffled), Relabelled permutes per-node tensors in and unpermute() brings outputs back."""
+    from han_amd import reorder, synth
+    from han_amd.graph import CSRGraph
+    n = 1500
+    g = synth.banded_graph(n, 8, 20, 3)
+    vals = torch.arange(g.nnz, dtype=torch.float32)
+    g = CSRGraph(g.rowptr, g.colidx, n, values=vals)
+    shuf = torch.randperm(n, generator=torch.Generator().manual_seed(1))
+    gs = reorder.permute_graph(g, shuf)
+    inv = torch.empty_like(shuf)
+    inv[shuf] = torch.arange(n)
+    rows = torch.repeat_interleave(torch.arange(n), g.degrees())
+    old = sorted(zip(inv[rows].tolist(), inv[g.colidx.long()].tolist(), g.values.tolist()))
+    rows2 = torch.repeat_interleave(torch.arange(n), gs.degrees())
+    new = sorted(zip(rows2.tolist(), gs.colidx.tolist(), gs.values.tolist()))
+    assert old == new
+
+    def spread(gr):
+        r = torch.repeat_interleave(torch.arange(n), gr.degrees())
+        d = (gr.colidx.long() - r).abs()
+        return float(torch.minimum(d, n - d).float().mean())
+    perm = reorder.bfs_order([gs])
+    assert sorted(perm.tolist()) == list(range(n))
+    gr = reorder.permute_graph(gs, perm)
+    assert spread(gs) > 10 * spread(gr) and reorder.halo_fraction([gr], 8)[0] < 0.2 < reorder.halo_fraction([gs], 8)[0]
+    wl = dict(x=torch.arange(n, dtype=torch.float32)[:, None].repeat(1, 3), labels=torch.arange(n, dtype=torch.int32),
+              train_mask=torch.ones(n, dtype=torch.uint8), val_mask=torch.zeros(n, dtype=torch.uint8), graphs=[gs])
+    rel = reorder.relabel(wl)
+    assert torch.equal(rel.wl["labels"].long(), rel.perm) and torch.equal(rel.unpermute(rel.wl["x"]), wl["x"])
+    # two components + an isolated node
+    rp = torch.tensor([0, 2, 4, 5, 7, 9], dtype=torch.int64)
+    ci = torch.tensor([0, 1, 0, 1, 2, 3, 4, 3, 4], dtype=torch.int32)
+    assert sorted(reorder.bfs_order([CSRGraph(rp, ci, 5)]).tolist()) == [0, 1, 2, 3, 4]
+
+
+def test_locality_pass_is_a_pure_relabelling_on_cpu_backend(cpu_ops):
+    """Loss, accuracy and every parameter gradient are those of the original problem; per-node outputs
+    come back in the original order (drop = 0: dropout masks are keyed by node id)."""
+    from han_amd import ops, reorder
+    prob = make_problem(17, 60, 7, 2, 3, [0.05, 0.2])
+    x = torch.tensor(prob["x"][0], dtype=torch.float32)
+    labels = torch.tensor(prob["labels"], dtype=torch.int32)
+    mask = torch.tensor(prob["mask"].astype(np.uint8))
+    graphs = _cpu_graphs(prob)
+    res = []
+    rel = reorder.relabel(dict(x=x, labels=labels, train_mask=mask, val_mask=mask, graphs=graphs))
+    for wl, back in ((dict(x=x, labels=labels, train_mask=mask, graphs=graphs), lambda t: t), (rel.wl, rel.unpermute)):
+        model, _ = _cpu_model(prob)
+        model.zero_grad_flat()
+        M = model.node_level([wl["x"]] * 2, wl["graphs"], 0.0, 0.0, True, ops.ACT_ELU)
+        Z, att = model.semantic(M)
+        loss, acc, logits = model.classifier_loss(Z, wl["labels"], wl["train_mask"], 1.0 / int(mask.sum()))
+        loss.backward()
+        res.append((float(loss.detach()), float(acc), back(logits.detach()), back(att.detach()), model.flat_grad.clone()))
+    (l0, a0, lg0, at0, g0), (l1, a1, lg1, at1, g1) = res
+    assert abs(l0 - l1) < 1e-6 and abs(a0 - a1) < 1e-7
+    assert float((lg0 - lg1).abs().max()) < 1e-5 and float((at0 - at1).abs().max()) < 1e-6
+    assert float((g0 - g1).abs().max()) < 1e-6 * max(1.0, float(g0.abs().max()))
