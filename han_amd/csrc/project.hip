@@ -853,8 +853,11 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
     // bf16 x 6 matrix-pipe kernel (fp32-class accuracy, see project_fwd_b6_kernel): whole-F blocks of 128
     // rows with 16-byte X loads; with dropout it is built for the reference head shape (8 x 8)
     const char *b6env = getenv("HAN_K1_B6");
-    const bool b6 = vec && nsplit == 1 && N >= 64 * 256 && (in_drop == 0.f || (K == 8 && FP == 8)) &&
-                    !(b6env && b6env[0] == '0');
+    // Used for the training forward (measured at SYN-1M in one process: 0.77 ms against 0.96 ms for the
+    // exact-fp32 kernel); without dropout both take the same time (0.48 / 0.50 ms: staging-latency bound), so
+    // the eval forward stays on the exact-fp32 pipe unless HAN_K1_B6=1 asks for this kernel.
+    const bool b6_want = in_drop > 0.f ? !(b6env && b6env[0] == '0') : (b6env && b6env[0] == '1');
+    const bool b6 = vec && nsplit == 1 && N >= 64 * 256 && (in_drop == 0.f || (K == 8 && FP == 8)) && b6_want;
     if (b6) {
         const dim3 g6((unsigned)((N + B6_ROWS - 1) / B6_ROWS));
         if (in_drop > 0.f) {
@@ -926,6 +929,9 @@ extern "C" int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const fl
     a.row_offset = row_offset;
     dim3 grid(ftiles, (unsigned)nch);
     const bool vec = !a.x_bf16 && (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
+    // (dW on the bf16 x 6 matrix pipe was built and measured in round 2 -- coalesced loads + on-chip transpose:
+    // 0.55 ms without / 0.83 ms with dropout against 0.41 / 0.84 ms for this exact-fp32 kernel at SYN-1M --
+    // and not kept: the transposition of both operands through LDS costs what the shorter matrix time saves.)
     HAN_DISPATCH_FP(FP, {
         if (in_drop > 0.f) {
             if (vec) project_bwd_kernel<FPC, true, kBwdMT, true><<<grid, 256, 0, st>>>(a);

@@ -127,6 +127,11 @@ def test_project_matrix_pipe_kernel_dropout_masks(dev, f, xbf, monkeypatch):
     assert np.abs(H.cpu().numpy() - Href).max() < 1e-5 * max(1.0, np.abs(Href).max())
     fm = rng_ref.fts_mask(seed, n, 64, drop, row_offset=off)
     assert np.array_equal((H.cpu().numpy().view(np.uint32) & 1).astype(np.float64), fm)
+    # the backward (exact-fp32 dW kernel) regenerates the very same draws
+    dH = rng.standard_normal((n, 64))
+    dW = ops.project_bwd(xt, _t(dH, dev), 8, 8, in_drop=drop, seed=seed, row_offset=off)
+    dWref = np.concatenate([(x / keep * sm[k]).T @ dH[:, 8 * k:8 * k + 8] for k in range(8)], 1)
+    assert rel_err(dW.cpu().numpy(), dWref) < 2e-6
     # other drop rates exercise the threshold arithmetic of the packed compare (odd / even thresholds)
     for dr in (0.25, 0.9):
         H2, _, _ = ops.project_fwd(xt, _t(W, dev), _t(a[0], dev), _t(a[1], dev), _t(a[2], dev), _t(a[3], dev),
@@ -825,11 +830,15 @@ def test_three_training_steps_match_oracle(dev):
 
 
 def test_training_with_dropout_reduces_loss(dev):
-    from han_amd.trainer import HANTrainer
-    from han_amd import synth
-    wl = synth.make_workload("tiny", device="cpu")
+    """60 reference epochs (dropout 0.6/0.6, Adam, L2) on a small learnable task: the training loss must
+    fall by a large factor and the held-out accuracy rise above chance.  Seeded end to end (variable
+    initialisers, dropout seed stream) so that the trajectory does not depend on which tests ran before."""
+    from han_amd import rng as hrng, synth
     from han_amd.gat import HeteGAT_multi
-    model = HeteGAT_multi().build(wl["p"], wl["f"], wl["c"], device=dev)
+    from han_amd.trainer import HANTrainer
+    hrng.manual_seed(2)
+    wl = synth.make_workload("tiny", device="cpu")
+    model = HeteGAT_multi().build(wl["p"], wl["f"], wl["c"], device=dev, generator=torch.Generator().manual_seed(2))
     x = wl["x"].to(dev)
     # make labels learnable: class = argmax of three fixed feature columns
     labels = x[:, :3].argmax(1).to(torch.int32)
@@ -839,9 +848,9 @@ def test_training_with_dropout_reduces_loss(dev):
     for ep in range(60):
         tl, ta, vl, va = tr.epoch()
         if first is None:
-            first = float(vl)
-    assert float(vl) < 0.97 * first
-    assert np.isfinite(float(tl))
+            first = (float(tl), float(vl))
+    assert float(tl) < 0.6 * first[0] and np.isfinite(float(vl))
+    assert float(vl) < first[1] and float(va) > 0.4          # 3 classes: chance = 1/3
 
 
 def test_captured_epoch_replay_matches_eager_and_oracle(dev):
