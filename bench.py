@@ -97,6 +97,11 @@ def k2_rooflines(timing, esz, regime):
                     "avg_launch_ms": round(avg, 4), "launches_timed": len(v),
                     "total_ms_in_timed_region": round(total[tag], 3), "rows": nr, "edges": nnz,
                     "regime": regime}
+        if ach > HBM_PEAK_GBS:
+            # e.g. power-law graphs: a few hub rows take most of the gathers and stay in the L2s
+            out[tag]["bound"] = "l2 / infinity cache"
+            out[tag]["note"] = ("requested bytes per second exceed the HBM peak: the gather is served from the "
+                                "caches (hot rows), this is not an HBM rate")
     dom = max(total, key=total.get) if total else None
     return out, dom
 
