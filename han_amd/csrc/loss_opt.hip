@@ -175,6 +175,112 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Many classes (16 < C <= 64): one wave per row, lane c = class c.  The averaged classifier column of
+// the lane's class and its gradient accumulator live in registers (2*D VGPRs); the row z is broadcast
+// element by element with v_readlane (lane d holds z[d], z[d + 64]); softmax statistics are wave
+// reductions; dZ is formed by lane d from the LDS copy of the matrix (row stride C_LD = 65: lanes that
+// step d hit different banks).  ~ (2D + C) * 3 vector instructions per row -- several times the cost
+// per row of the small-C kernel, which keeps 16 rows per block iteration; only used when C > 16.
+// ---------------------------------------------------------------------------------------------
+constexpr int WC_LD = 65;
+
+template <bool BWD, int NV>
+__global__ __launch_bounds__(256) void classifier_wide_kernel(const ClsArgs a) {
+    constexpr int D = 64 * NV;
+    __shared__ float Wl[D * WC_LD];       // averaged matrix [d][c]; reused as the reduction scratch at the end
+    __shared__ float sc2[64 + 2];         // db | loss | acc
+    const int C = a.C;
+    const float invh = 1.f / (float)a.HC;
+    for (int i = threadIdx.x; i < D * C; i += 256) {
+        float s = 0.f;
+        for (int h = 0; h < a.HC; ++h) s += a.Wc[(int64_t)h * D * C + i];
+        Wl[(i / C) * WC_LD + (i % C)] = s * invh;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool cls = lane < C;
+    float bq = 0.f;
+    if (cls)
+        for (int h = 0; h < a.HC; ++h) bq += a.bc[h * C + lane];
+    bq *= invh;
+    float wcol[D], dwcol[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        wcol[d] = cls ? Wl[d * WC_LD + lane] : 0.f;
+        dwcol[d] = 0.f;
+    }
+    float dbacc = 0.f, loss_acc = 0.f, acc_acc = 0.f;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave0; row < a.N; row += nwaves) {
+        float z[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) z[v] = a.Z[row * D + 64 * v + lane];
+        float lg = bq;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            lg += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z[d >> 6]), d & 63)) * wcol[d];
+        if (cls) a.logits[row * C + lane] = lg;
+        const float lgm = cls ? lg : HAN_NEG_BIG;
+        float mx = lgm;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const unsigned long long hit = __ballot(cls && lgm == mx);
+        const int am = __ffsll((long long)hit) - 1;              // first maximum, as argmax
+        const float ex = cls ? __expf(lg - mx) : 0.f;
+        const float se = han_wave_sum(ex);
+        const int lab = a.labels[row];
+        const float wgt = a.mask[row] ? a.row_weight : 0.f;
+        const float llab = __shfl(lg, lab, 64);
+        if (lane == 0) {
+            loss_acc += wgt * (mx + __logf(se) - llab);
+            acc_acc += wgt * (am == lab ? 1.f : 0.f);
+        }
+        if (BWD) {
+            const float dl = cls ? wgt * (ex / se - (lane == lab ? 1.f : 0.f)) : 0.f;
+            dbacc += dl;
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                dwcol[d] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z[d >> 6]), d & 63)) * dl;
+            float dz[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) dz[v] = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float dlc = __shfl(dl, c, 64);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) dz[v] += dlc * Wl[(64 * v + lane) * WC_LD + c];
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) a.dZ[row * D + 64 * v + lane] = dz[v];
+        }
+    }
+    // block reduction: the 4 waves add their dW columns one after the other into the LDS matrix
+    __syncthreads();
+    for (int ww = 0; ww < 4; ++ww) {
+        if (w == ww) {
+            if (BWD && cls) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) Wl[d * WC_LD + lane] = (ww == 0 ? 0.f : Wl[d * WC_LD + lane]) + dwcol[d];
+                sc2[lane] = (ww == 0 ? 0.f : sc2[lane]) + dbacc;
+            }
+            if (lane == 0) {
+                sc2[64] = (ww == 0 ? 0.f : sc2[64]) + loss_acc;
+                sc2[65] = (ww == 0 ? 0.f : sc2[65]) + acc_acc;
+            }
+        }
+        __syncthreads();
+    }
+    const int width = D * C + C + 2;
+    float *out = a.slab + (int64_t)blockIdx.x * width;
+    for (int i = threadIdx.x; i < width; i += 256) {
+        float v;
+        if (i < D * C) v = BWD ? Wl[(i / C) * WC_LD + (i % C)] : 0.f;
+        else if (i < D * C + C) v = BWD ? sc2[i - D * C] : 0.f;
+        else v = sc2[64 + (i - D * C - C)];
+        out[i] = v;
+    }
+}
+
 template <int NV>
 static void launch_classifier(const ClsArgs &a, bool bwd, int grid, hipStream_t st) {
     if (a.C <= 4) {
@@ -268,7 +374,7 @@ extern "C" int han_classifier_loss(const float *Z, const float *Wc, const float 
                                    int64_t N, int D, int C, int HC, void *stream) {
     if (!Z || !Wc || !bc || !labels || !mask || !logits || !loss_acc || !workspace || N < 0 || HC <= 0)
         return HAN_E_BADARG;
-    if ((D != 64 && D != 128) || C < 1 || C > MAXC) return HAN_E_UNSUPPORTED;
+    if ((D != 64 && D != 128) || C < 1 || C > 64) return HAN_E_UNSUPPORTED;
     const bool bwd = dZ != nullptr;
     if (bwd && (!dWc || !dbc)) return HAN_E_BADARG;
     if (workspace_bytes < han_classifier_workspace(N, D, C, HC)) return HAN_E_WORKSPACE;
@@ -276,8 +382,17 @@ extern "C" int han_classifier_loss(const float *Z, const float *Wc, const float 
     ClsArgs a;
     a.Z = Z; a.Wc = Wc; a.bc = bc; a.labels = labels; a.mask = mask; a.row_weight = row_weight;
     a.logits = logits; a.dZ = dZ; a.slab = (float *)workspace; a.N = N; a.C = C; a.HC = HC;
-    const int grid = han_grid_for(N > 0 ? N : 1, 16, kClsBlocks);
-    if (D == 128) launch_classifier<2>(a, bwd, grid, st);
+    int grid = han_grid_for(N > 0 ? N : 1, 16, kClsBlocks);
+    if (C > MAXC) {        // class-per-lane kernel, one wave per row
+        grid = han_grid_for(N > 0 ? N : 1, 4, kClsBlocks);
+        if (D == 128) {
+            if (bwd) classifier_wide_kernel<true, 2><<<grid, 256, 0, st>>>(a);
+            else classifier_wide_kernel<false, 2><<<grid, 256, 0, st>>>(a);
+        } else {
+            if (bwd) classifier_wide_kernel<true, 1><<<grid, 256, 0, st>>>(a);
+            else classifier_wide_kernel<false, 1><<<grid, 256, 0, st>>>(a);
+        }
+    } else if (D == 128) launch_classifier<2>(a, bwd, grid, st);
     else launch_classifier<1>(a, bwd, grid, st);
     HAN_CHECK_LAUNCH();
     const int width = D * C + C + 2;

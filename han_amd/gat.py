@@ -129,8 +129,8 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
                                       f"{MAX_WIDTH} columns")
         if not (1 <= mp_att_size <= 128):
             raise NotImplementedError("mp_att_size must be in [1, 128] in this build")
-        if not (1 <= nb_classes <= 16):
-            raise NotImplementedError("nb_classes must be in [1,16] in this build")
+        if not (1 <= nb_classes <= 64):
+            raise NotImplementedError("nb_classes must be in [1,64] in this build")
         dev = torch.device(device) if device is not None else (self._device or torch.device("cuda:0"))
         self.P, self.F, self.K, self.FP = int(n_metapaths), int(ft_size), K, FP
         self.A, self.C, self.HC = int(mp_att_size), int(nb_classes), HC

@@ -523,7 +523,10 @@ def test_empty_inputs_are_noops(dev):
 
 # ----------------------------------------------------------- classifier / loss / opt
 @pytest.mark.parametrize("n,c,hc,d", [(5, 3, 1, 64), (257, 4, 1, 64), (100, 7, 2, 64), (64, 16, 1, 64),
-                                      (5, 3, 1, 128), (257, 4, 2, 128), (300, 8, 1, 128), (64, 16, 1, 128)])
+                                      (5, 3, 1, 128), (257, 4, 2, 128), (300, 8, 1, 128), (64, 16, 1, 128),
+                                      # more than 16 classes: the class-per-lane kernel
+                                      (5, 17, 1, 64), (300, 40, 1, 64), (1000, 64, 2, 64), (257, 64, 2, 128),
+                                      (130, 33, 1, 128)])
 def test_classifier_loss_matches_oracle(dev, n, c, hc, d):
     from han_amd import ops
     rng = np.random.default_rng(n + c)
@@ -1437,3 +1440,23 @@ def test_locality_pass_is_a_pure_relabelling(dev):
     assert abs(l0 - l1) < 1e-5 and abs(a0 - a1) < 1e-6
     assert float((lg0 - lg1).abs().max()) < TOL and float((z0 - z1).abs().max()) < TOL
     assert float((g0 - g1).abs().max()) < 1e-4 * max(1.0, float(g0.abs().max()))
+
+
+def test_many_classes_through_the_model(dev):
+    """nb_classes = 30 (models/gat.py:68 leaves it free): inference and loss + gradients against the oracle."""
+    n, f, p, c = 80, 12, 2, 30
+    prob = make_problem(321, n, f, p, c, [0.06, 0.4])
+    model, bp = build_model(prob, dev)
+    lg, fe, att = ho.hetegat_multi_inference([prob["x"]] * p, c, n, False, 0.0, 0.0, prob["biases"], [8], [8, 1],
+                                             prob["params"])
+    x, graphs = gpu_inputs(prob, dev)
+    with torch.no_grad():
+        logits, final_embed, _ = model.inference([x] * p, c, n, False, 0.0, 0.0, graphs, [8], [8, 1])
+    assert np.abs(logits[0].cpu().numpy() - lg[0]).max() < TOL
+    loss_ref, gref, lg_ref = _oracle_grads(prob, bp, dense=False)
+    loss, grads, lgg, acc = _gpu_loss_and_grads(model, prob, dev)
+    assert abs(loss - loss_ref) < 5e-4 and np.abs(lgg - lg_ref).max() < 5 * TOL
+    acc_ref = float(ht.masked_accuracy(torch.tensor(lg_ref), torch.tensor(prob["onehot"]), torch.tensor(prob["mask"])))
+    assert abs(acc - acc_ref) < 1e-5
+    for k in ht.PARAM_ORDER:
+        assert rel_err(grads[k], gref[k]) < GTOL, k

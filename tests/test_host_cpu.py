@@ -308,6 +308,9 @@ def test_model_variables_and_initialisers():
         HeteGAT_multi().build(2, 10, 3, (10,), (4, 1), device="cpu")           # head width not a lane-mapped size
     with pytest.raises(NotImplementedError):
         HeteGAT_multi().build(2, 10, 3, (32,), (8, 1), device="cpu")           # final width 256 > 128
+    assert tuple(HeteGAT_multi().build(2, 10, 40, device="cpu").Wc.shape) == (1, 64, 40)   # up to 64 classes
+    with pytest.raises(NotImplementedError):
+        HeteGAT_multi().build(2, 10, 65, device="cpu")
     with pytest.raises(ValueError):
         HeteGAT_multi().build(2, 10, 3, (8, 8), (8, 1), device="cpu")          # n_heads too short
 
