@@ -28,6 +28,7 @@
 //
 // Roofline: MFMA fp32 (155 TF): forward 2*R*64*A flop = 65.5 GF at N = 1M, P = 4
 // (0.42 ms at peak), backward 3x that; the M / Z / dM streams are 1-2 GB (HBM, ~0.3 ms).
+#include <stdlib.h>
 #include "han_common.h"
 
 namespace {
@@ -266,6 +267,195 @@ __global__ __launch_bounds__(256) void sem_attn_fwd_wave_kernel(const float *__r
             if (row < R) {
                 if (l4 % (P / 4) == 0) *reinterpret_cast<float4_t *>(Z + (row / P) * 64 + 4 * l15) = z;
                 if (l15 < 4) beta[row + l15] = mine;      // beta is (N,P) flat == row index
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The wave-local forward on the bf16 matrix pipe with fp32-class accuracy (the "bf16 x 6" scheme of
+// project.hip): M rows and Womega are split EXACTLY into three bf16 terms (truncation), six products
+// per K = 32 step replace sixteen v_mfma_f32_16x16x4_f32 per 64-deep row -- 12 MFMAs of 16 cycles
+// instead of 16 of 32 per column tile.  Womega is split once per block into LDS, transposed
+// ([term][a][k], 144-B rows) so that a lane's 8 k-values are one 16-B read; a lane loads ITS 16 k-values
+// of its row as four 16-byte loads (one tile ahead) and splits them in registers.  Everything after
+// the contraction (tanh, score dot, per-node softmax, weighted sum) is the fp32 kernel's.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 sa_bf16x8 __attribute__((ext_vector_type(8)));
+typedef int sa_i32x4 __attribute__((ext_vector_type(4)));
+constexpr int SA_WLDB = 144;     // bytes per LDS row of the transposed, split Womega: 64 bf16 + 16 B
+
+__device__ __forceinline__ void sa_split(float x, uint32_t &h, uint32_t &m, uint32_t &l) {
+    h = __float_as_uint(x) & 0xFFFF0000u;             // x == h + m + l exactly (8 + 8 + 8 significand bits)
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));
+}
+__device__ __forceinline__ uint32_t sa_pack(uint32_t e0, uint32_t e1) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
+__device__ __forceinline__ f32x4 sa_mfma(const sa_i32x4 &a, const sa_i32x4 &b, const f32x4 &c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sa_bf16x8, a), __builtin_bit_cast(sa_bf16x8, b),
+                                                   c, 0, 0, 0);
+}
+// 8 consecutive floats -> the three packed bf16x8 fragments
+__device__ __forceinline__ void sa_split8(const float (&v)[8], sa_i32x4 &fh, sa_i32x4 &fm, sa_i32x4 &fl) {
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sa_split(v[j], h[j], m[j], l[j]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        fh[q] = (int)sa_pack(h[2 * q], h[2 * q + 1]);
+        fm[q] = (int)sa_pack(m[2 * q], m[2 * q + 1]);
+        fl[q] = (int)sa_pack(l[2 * q], l[2 * q + 1]);
+    }
+}
+
+template <int CA, int P>
+__global__ __launch_bounds__(256) void sem_attn_fwd_wave_b6_kernel(const float *__restrict__ M, const float *Wg,
+                                                                   const float *bw, const float *uw, float *Z,
+                                                                   float *beta, int64_t N) {
+    constexpr int A = 64 * CA;
+    constexpr int TA = A / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char *Wt = reinterpret_cast<unsigned char *>(smem);      // [3][A][144 B]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // Womega (64 x A, row-major [k][a]) -> split, transposed: item (a, g) = 8 k-values 8g..8g+7 of column a
+    for (int it = threadIdx.x; it < A * 8; it += 256) {
+        const int acol = it % A, g = it / A;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Wg[(8 * g + j) * A + acol];
+        sa_i32x4 fh, fm, fl;
+        sa_split8(v, fh, fm, fl);
+        unsigned char *dst = Wt + acol * SA_WLDB + g * 16;
+        *reinterpret_cast<sa_i32x4 *>(dst) = fh;
+        *reinterpret_cast<sa_i32x4 *>(dst + A * SA_WLDB) = fm;
+        *reinterpret_cast<sa_i32x4 *>(dst + 2 * A * SA_WLDB) = fl;
+    }
+    __syncthreads();
+    float bcol[TA], ucol[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        bcol[t] = bw[16 * t + l15];
+        ucol[t] = uw[16 * t + l15];
+    }
+    const int64_t R = N * P;
+    const int64_t ntiles = (R + 15) / 16;
+    const int64_t tstride = (int64_t)gridDim.x * 4;
+    // this lane's 16 k-values of its row: k = 32 s + 8 l4 + j  (s = 0, 1; j < 8): four 16-byte loads
+    float4_t araw[4];
+    {
+        const int64_t t0 = (int64_t)blockIdx.x * 4 + w;
+        const int64_t ra = t0 * 16 + l15 < R ? t0 * 16 + l15 : R - 1;
+        const float *mr = M + ra * 64 + 8 * l4;
+        araw[0] = *reinterpret_cast<const float4_t *>(mr);
+        araw[1] = *reinterpret_cast<const float4_t *>(mr + 4);
+        araw[2] = *reinterpret_cast<const float4_t *>(mr + 32);
+        araw[3] = *reinterpret_cast<const float4_t *>(mr + 36);
+    }
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += tstride) {
+        const int64_t r0 = tile * 16;
+        f32x4 acc[TA];
+#pragma unroll
+        for (int t = 0; t < TA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        sa_i32x4 af[2][3];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const float v[8] = {araw[2 * s2][0], araw[2 * s2][1], araw[2 * s2][2], araw[2 * s2][3],
+                                araw[2 * s2 + 1][0], araw[2 * s2 + 1][1], araw[2 * s2 + 1][2], araw[2 * s2 + 1][3]};
+            sa_split8(v, af[s2][0], af[s2][1], af[s2][2]);
+        }
+        {
+            const int64_t rn = (tile + tstride) * 16 + l15;
+            const float *mr = M + (rn < R ? rn : R - 1) * 64 + 8 * l4;      // next tile, in flight under the MFMAs
+            araw[0] = *reinterpret_cast<const float4_t *>(mr);
+            araw[1] = *reinterpret_cast<const float4_t *>(mr + 4);
+            araw[2] = *reinterpret_cast<const float4_t *>(mr + 32);
+            araw[3] = *reinterpret_cast<const float4_t *>(mr + 36);
+        }
+        float4_t mz[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t row = r0 + 4 * l4 + rr;
+            mz[rr] = *reinterpret_cast<const float4_t *>(M + (row < R ? row : R - 1) * 64 + 4 * l15);
+        }
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            f32x4 c = acc[t];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const unsigned char *wb = Wt + (16 * t + l15) * SA_WLDB + (32 * s2 + 8 * l4) * 2;
+                const sa_i32x4 bh = *reinterpret_cast<const sa_i32x4 *>(wb);
+                const sa_i32x4 bm = *reinterpret_cast<const sa_i32x4 *>(wb + A * SA_WLDB);
+                const sa_i32x4 bl = *reinterpret_cast<const sa_i32x4 *>(wb + 2 * A * SA_WLDB);
+                c = sa_mfma(af[s2][1], bm, c);      // small terms first
+                c = sa_mfma(af[s2][2], bh, c);
+                c = sa_mfma(af[s2][0], bl, c);
+                c = sa_mfma(af[s2][1], bh, c);
+                c = sa_mfma(af[s2][0], bm, c);
+                c = sa_mfma(af[s2][0], bh, c);
+            }
+            acc[t] = c;
+            __builtin_amdgcn_sched_barrier(0);      // keep one column tile's 6 fragment reads in flight, not all 48
+        }
+        float sc[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < TA; ++t) s += fast_tanh(acc[t][reg] + bcol[t]) * ucol[t];
+            s = han_row16_sum(s);
+            sc[reg] = s;
+        }
+        if constexpr (P <= 4) {
+#pragma unroll
+            for (int k = 0; k < 4 / P; ++k) {
+                const int64_t row = r0 + 4 * l4 + k * P;
+                if (row < R) {
+                    float mx = sc[k * P];
+#pragma unroll
+                    for (int p = 1; p < P; ++p) mx = fmaxf(mx, sc[k * P + p]);
+                    float e[P], den = 0.f;
+#pragma unroll
+                    for (int p = 0; p < P; ++p) { e[p] = __expf(sc[k * P + p] - mx); den += e[p]; }
+                    const float inv = 1.f / den;
+                    float4_t z = {0.f, 0.f, 0.f, 0.f};
+                    float mine = 0.f;
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const float bp = e[p] * inv;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) z[c] += bp * mz[k * P + p][c];
+                        mine = (l15 == p) ? bp : mine;
+                    }
+                    const int64_t node = row / P;
+                    *reinterpret_cast<float4_t *>(Z + node * 64 + 4 * l15) = z;
+                    if (l15 < P) beta[node * P + l15] = mine;
+                }
+            }
+        } else {
+            float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+            mx = node_xmax<P>(mx);
+            float e[4], den = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) { e[reg] = __expf(sc[reg] - mx); den += e[reg]; }
+            den = node_xsum<P>(den);
+            const float inv = 1.f / den;
+            float4_t z = {0.f, 0.f, 0.f, 0.f};
+            float mine = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float bp = e[reg] * inv;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) z[c] += bp * mz[reg][c];
+                mine = (l15 == reg) ? bp : mine;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) z[c] = node_xsum<P>(z[c]);
+            const int64_t row = r0 + 4 * l4;
+            if (row < R) {
+                if (l4 % (P / 4) == 0) *reinterpret_cast<float4_t *>(Z + (row / P) * 64 + 4 * l15) = z;
+                if (l15 < 4) beta[row + l15] = mine;
             }
         }
     }
@@ -662,6 +852,279 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_kernel(const float *__r
     for (int i = threadIdx.x; i < 64 * A + 2 * A; i += 256) out[i] = red[i];
 }
 
+// The wave-local backward with G1 (recompute of pre) and G2 (dM = dpre . Womega^T) on the bf16 matrix pipe
+// (exact 3-way split, fp32-class accuracy: see sem_attn_fwd_wave_b6_kernel); G3 (dWomega += M^T dpre, whose
+// reduction runs over the 16 rows of a tile -- half a K = 32 step) stays on the fp32 pipe.  Womega is split
+// twice into LDS at block start: transposed [a][k] for G1, as stored [f][a] for G2.
+template <int CA, int P>
+__global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *__restrict__ M, const float *Wg,
+                                                                const float *bw, const float *uw,
+                                                                const float *beta, const float *dZ, float *dM,
+                                                                float *slab, int64_t N) {
+    constexpr int A = 64 * CA;
+    constexpr int TA = A / 16;
+    constexpr int WLD2 = A + 4;                 // dpre tile rows: 16-B aligned for the 8-float fragment reads
+    constexpr int W2LDB = A * 2 + 16;           // bytes per row of the split Womega [f][a] (G2's B operand)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char *Wt = reinterpret_cast<unsigned char *>(smem);        // G1 B operand: [3][A][144 B]   (transposed [a][k])
+    unsigned char *W2s = Wt + 3 * A * SA_WLDB;                          // G2 B operand: [3][64 f][W2LDB] (as stored [f][a])
+    float *dp = reinterpret_cast<float *>(W2s + 3 * 64 * W2LDB);        // [4 waves][16][WLD2] fp32
+    for (int it = threadIdx.x; it < A * 8; it += 256) {                 // (a, g): k-values 8g..8g+7 of column a
+        const int acol = it % A, g = it / A;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Wg[(8 * g + j) * A + acol];
+        sa_i32x4 fh, fm, fl;
+        sa_split8(v, fh, fm, fl);
+        unsigned char *dst = Wt + acol * SA_WLDB + g * 16;
+        *reinterpret_cast<sa_i32x4 *>(dst) = fh;
+        *reinterpret_cast<sa_i32x4 *>(dst + A * SA_WLDB) = fm;
+        *reinterpret_cast<sa_i32x4 *>(dst + 2 * A * SA_WLDB) = fl;
+    }
+    for (int it = threadIdx.x; it < 64 * (A / 8); it += 256) {          // (f, g): a-values 8g..8g+7 of row f
+        const int f = it / (A / 8), g = it % (A / 8);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Wg[f * A + 8 * g + j];
+        sa_i32x4 fh, fm, fl;
+        sa_split8(v, fh, fm, fl);
+        unsigned char *dst = W2s + f * W2LDB + g * 16;
+        *reinterpret_cast<sa_i32x4 *>(dst) = fh;
+        *reinterpret_cast<sa_i32x4 *>(dst + 64 * W2LDB) = fm;
+        *reinterpret_cast<sa_i32x4 *>(dst + 2 * 64 * W2LDB) = fl;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    float bcol[TA], ucol[TA], du[TA], db[TA];
+    f32x4 dW[4][TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        bcol[t] = bw[16 * t + l15];
+        ucol[t] = uw[16 * t + l15];
+        du[t] = 0.f;
+        db[t] = 0.f;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) dW[ft][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float *mydp = dp + w * 16 * WLD2;
+    __syncthreads();
+    const int64_t R = N * P;
+    const int64_t ntiles = (R + 15) / 16;
+    // The rows of a tile come from HBM and with one wave per SIMD nothing else hides that
+    // latency, so the row-local inputs (M rows, dZ rows, beta) are fetched ONE TILE AHEAD into
+    // registers -- which also pulls the tile into L2 for the strided fragment loads of G1 / G3
+    // (3.47 -> 3.20 ms at SYN-1M).
+    const int64_t tstride = (int64_t)gridDim.x * 4;
+    float4_t mv_n[4], dz_n[4];
+    float bt_n[4];
+    auto fetch_rows = [&](int64_t tile) {
+        const int64_t g0n = tile * 16 + 4 * l4;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t row = g0n + rr;
+            const bool ok = row < R;
+            const int64_t rc = ok ? row : R - 1;
+            mv_n[rr] = *reinterpret_cast<const float4_t *>(M + rc * 64 + 4 * l15);
+            dz_n[rr] = *reinterpret_cast<const float4_t *>(dZ + (rc / P) * 64 + 4 * l15);
+            bt_n[rr] = ok ? beta[rc] : 0.f;        // beta is (N,P) flat == row index
+        }
+    };
+    fetch_rows((int64_t)blockIdx.x * 4 + w);
+    float4_t araw[4];      // G1: this lane's 16 k-values of its row (k = 32 s + 8 l4 + j), one tile ahead
+    {
+        const int64_t t0 = (int64_t)blockIdx.x * 4 + w;
+        const int64_t ra = t0 * 16 + l15 < R ? t0 * 16 + l15 : R - 1;
+        const float *mr = M + ra * 64 + 8 * l4;
+        araw[0] = *reinterpret_cast<const float4_t *>(mr);
+        araw[1] = *reinterpret_cast<const float4_t *>(mr + 4);
+        araw[2] = *reinterpret_cast<const float4_t *>(mr + 32);
+        araw[3] = *reinterpret_cast<const float4_t *>(mr + 36);
+    }
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += tstride) {
+        const int64_t r0 = tile * 16;
+        const int64_t g0 = r0 + 4 * l4;           // first row of this lane group
+        // ---- d beta, d s inside the lane group (lane = features 4*l15 .. 4*l15+3)
+        float ds[4], bt[4];
+        {
+            float dbt[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float4_t mv = mv_n[rr], dz = dz_n[rr];
+                float d = mv[0] * dz[0] + mv[1] * dz[1] + mv[2] * dz[2] + mv[3] * dz[3];
+                d = han_row16_sum(d);
+                dbt[rr] = d;
+                bt[rr] = bt_n[rr];
+            }
+            fetch_rows(tile + tstride);      // next tile: in flight under this tile's MFMAs
+            if constexpr (P <= 4) {
+#pragma unroll
+                for (int k = 0; k < 4 / P; ++k) {
+                    float S = 0.f;
+#pragma unroll
+                    for (int p2 = 0; p2 < P; ++p2) S += bt[k * P + p2] * dbt[k * P + p2];
+#pragma unroll
+                    for (int p2 = 0; p2 < P; ++p2) ds[k * P + p2] = bt[k * P + p2] * (dbt[k * P + p2] - S);
+                }
+            } else {     // P = 8 / 16: the node's rows span P/4 lane groups
+                float S = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) S += bt[rr] * dbt[rr];
+                S = node_xsum<P>(S);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) ds[rr] = bt[rr] * (dbt[rr] - S);
+            }
+        }
+        // ---- G1: pre = M_tile . Womega
+        f32x4 acc[TA];
+#pragma unroll
+        for (int t = 0; t < TA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float dzt[4][4];      // dZ of this tile's rows in the accumulator layout (L2 hits, used by G2)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t rg = g0 + reg < R ? g0 + reg : R - 1;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) dzt[reg][ft] = dZ[(rg / P) * 64 + 16 * ft + l15];
+        }
+        {
+            sa_i32x4 af[2][3];     // G1's A fragments: exact 3-way bf16 split of this tile's rows
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float v[8] = {araw[2 * s2][0], araw[2 * s2][1], araw[2 * s2][2], araw[2 * s2][3],
+                                    araw[2 * s2 + 1][0], araw[2 * s2 + 1][1], araw[2 * s2 + 1][2], araw[2 * s2 + 1][3]};
+                sa_split8(v, af[s2][0], af[s2][1], af[s2][2]);
+            }
+            {
+                const int64_t rn = (tile + tstride) * 16 + l15;      // next tile's rows, in flight under the MFMAs
+                const float *mr = M + (rn < R ? rn : R - 1) * 64 + 8 * l4;
+                araw[0] = *reinterpret_cast<const float4_t *>(mr);
+                araw[1] = *reinterpret_cast<const float4_t *>(mr + 4);
+                araw[2] = *reinterpret_cast<const float4_t *>(mr + 32);
+                araw[3] = *reinterpret_cast<const float4_t *>(mr + 36);
+            }
+            // G3's A operand: this tile's rows, feature-major per lane (L2 hits)
+            float g3a[4][4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t rg = g0 + reg < R ? g0 + reg : R - 1;     // dpre of a padding row is 0
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) g3a[reg][ft] = M[rg * 64 + l15 + 16 * ft];
+            }
+            // Column tile by column tile: G1(t) -> dpre(t) -> G3(t).  The VALU work of dpre(t)
+            // (tanh, products, LDS store) has no dependence on the MFMAs of G1(t+1), so the
+            // scheduler can run it in their shadow instead of after all of G1.
+#pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                {
+                    f32x4 c = acc[t];
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const unsigned char *wb = Wt + (16 * t + l15) * SA_WLDB + (32 * s2 + 8 * l4) * 2;
+                        const sa_i32x4 bh = *reinterpret_cast<const sa_i32x4 *>(wb);
+                        const sa_i32x4 bm = *reinterpret_cast<const sa_i32x4 *>(wb + A * SA_WLDB);
+                        const sa_i32x4 bl = *reinterpret_cast<const sa_i32x4 *>(wb + 2 * A * SA_WLDB);
+                        c = sa_mfma(af[s2][1], bm, c);
+                        c = sa_mfma(af[s2][2], bh, c);
+                        c = sa_mfma(af[s2][0], bl, c);
+                        c = sa_mfma(af[s2][1], bh, c);
+                        c = sa_mfma(af[s2][0], bm, c);
+                        c = sa_mfma(af[s2][0], bh, c);
+                    }
+                    acc[t] = c;
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float v = fast_tanh(acc[t][reg] + bcol[t]);
+                    const float d = ds[reg] * ucol[t] * (1.f - v * v);
+                    du[t] += ds[reg] * v;
+                    db[t] += d;
+                    acc[t][reg] = d;
+                    mydp[(4 * l4 + reg) * WLD2 + 16 * t + l15] = d;
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                    for (int ft = 0; ft < 4; ++ft)
+                        dW[ft][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(g3a[reg][ft], acc[t][reg], dW[ft][t], 0, 0, 0);
+            }
+        }
+        // ---- G2: dMx = dpre . Womega^T   (A operand from the wave's LDS tile)
+        // the accumulators start at beta * dZ (the direct term of dM); its loads were issued
+        // before G1, so the epilogue is stores only
+        f32x4 acc2[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) acc2[ft][reg] = bt[reg] * dzt[reg][ft];
+#pragma unroll
+        for (int s2 = 0; s2 < A / 32; ++s2) {       // K = 32 columns of the attention space per step
+            const float4_t d0 = *reinterpret_cast<const float4_t *>(mydp + l15 * WLD2 + 32 * s2 + 8 * l4);
+            const float4_t d1 = *reinterpret_cast<const float4_t *>(mydp + l15 * WLD2 + 32 * s2 + 8 * l4 + 4);
+            const float v[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+            sa_i32x4 ah, am, al;
+            sa_split8(v, ah, am, al);
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const unsigned char *wb = W2s + (16 * ft + l15) * W2LDB + (32 * s2 + 8 * l4) * 2;
+                const sa_i32x4 bh = *reinterpret_cast<const sa_i32x4 *>(wb);
+                const sa_i32x4 bm = *reinterpret_cast<const sa_i32x4 *>(wb + 64 * W2LDB);
+                const sa_i32x4 bl = *reinterpret_cast<const sa_i32x4 *>(wb + 2 * 64 * W2LDB);
+                f32x4 c = acc2[ft];
+                c = sa_mfma(am, bm, c);
+                c = sa_mfma(al, bh, c);
+                c = sa_mfma(ah, bl, c);
+                c = sa_mfma(am, bh, c);
+                c = sa_mfma(ah, bm, c);
+                c = sa_mfma(ah, bh, c);
+                acc2[ft] = c;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t row = g0 + reg;
+            if (row < R) {
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) dM[row * 64 + 16 * ft + l15] = acc2[ft][reg];
+            }
+        }
+    }
+    // ---- parameter gradients: lane groups -> waves (LDS) -> slab row
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            du[t] += __shfl_xor(du[t], o, 64);
+            db[t] += __shfl_xor(db[t], o, 64);
+        }
+    }
+    __syncthreads();
+    float *red = smem;   // [64*A] dW | [A] db | [A] du  (fits inside the split-Womega region)
+    for (int ww = 0; ww < 4; ++ww) {
+        if (w == ww) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int idx = (16 * ft + 4 * l4 + reg) * A + 16 * t + l15;
+                        red[idx] = (ww == 0 ? 0.f : red[idx]) + dW[ft][t][reg];
+                    }
+            if (l4 == 0) {
+#pragma unroll
+                for (int t = 0; t < TA; ++t) {
+                    const int idx = 64 * A + 16 * t + l15;
+                    red[idx] = (ww == 0 ? 0.f : red[idx]) + db[t];
+                    red[idx + A] = (ww == 0 ? 0.f : red[idx + A]) + du[t];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *out = slab + (int64_t)blockIdx.x * (64 * A + 2 * A);
+    for (int i = threadIdx.x; i < 64 * A + 2 * A; i += 256) out[i] = red[i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wider embeddings: D = 128 (e.g. hid_units = [16] with 8 heads, models/gat.py:42-57 leaves both
 // free).  The block-level kernels above with the feature width as a template parameter
@@ -946,6 +1409,28 @@ int launch_fwd(const float *M, const float *w, const float *b, const float *u, f
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+    const char *b6env = getenv("HAN_K3_B6");
+    if ((P == 1 || P == 2 || P == 4 || P == 8 || P == 16) && N * P >= 64 * 1024 && !(b6env && b6env[0] == '0')) {
+        // large inputs: the contraction on the bf16 matrix pipe (exact 3-way split, fp32-class accuracy)
+        const size_t blds = (size_t)3 * 64 * CA * SA_WLDB;
+        const int grid = han_grid_for(N * P, 64, 256 * 2);
+        hipError_t e2 = hipSuccess;
+#define HAN_LAUNCH_FWD_B6(PV)                                                                            \
+    e2 = hipFuncSetAttribute((const void *)sem_attn_fwd_wave_b6_kernel<CA, PV>,                          \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);                     \
+    if (e2 == hipSuccess) sem_attn_fwd_wave_b6_kernel<CA, PV><<<grid, 256, blds, st>>>(M, w, b, u, Z, beta, N);
+        switch (P) {
+            case 1: HAN_LAUNCH_FWD_B6(1) break;
+            case 2: HAN_LAUNCH_FWD_B6(2) break;
+            case 4: HAN_LAUNCH_FWD_B6(4) break;
+            case 8: HAN_LAUNCH_FWD_B6(8) break;
+            default: HAN_LAUNCH_FWD_B6(16) break;
+        }
+#undef HAN_LAUNCH_FWD_B6
+        if (e2 != hipSuccess) return (int)e2;
+        HAN_CHECK_LAUNCH();
+        return 0;
+    }
     if (P == 1 || P == 2 || P == 4 || P == 8 || P == 16) {
         constexpr bool WREG = false;
         const size_t wlds = WREG ? 0 : (size_t)64 * (64 * CA + 16) * sizeof(float);
@@ -972,6 +1457,30 @@ int launch_bwd(const float *M, const float *w, const float *b, const float *u, c
     hipError_t e = hipFuncSetAttribute((const void *)sem_attn_bwd_kernel<CA>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
+    const char *b6env = getenv("HAN_K3_B6");
+    if ((P == 1 || P == 2 || P == 4 || P == 8 || P == 16) && N * P >= 64 * 1024 && !(b6env && b6env[0] == '0')) {
+        const int grid = han_grid_for(N * P, 64, kSemBwdBlocks);
+        *grid_out = grid;
+        constexpr int A6 = 64 * CA;
+        const size_t blds = (size_t)3 * A6 * SA_WLDB + (size_t)3 * 64 * (A6 * 2 + 16) + (size_t)4 * 16 * (A6 + 4) * sizeof(float);
+        hipError_t e3 = hipSuccess;
+#define HAN_LAUNCH_BWD_B6(PV)                                                                            \
+    e3 = hipFuncSetAttribute((const void *)sem_attn_bwd_wave_b6_kernel<CA, PV>,                          \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);                     \
+    if (e3 == hipSuccess)                                                                                \
+        sem_attn_bwd_wave_b6_kernel<CA, PV><<<grid, 256, blds, st>>>(M, w, b, u, beta, dZ, dM, slab, N);
+        switch (P) {
+            case 1: HAN_LAUNCH_BWD_B6(1) break;
+            case 2: HAN_LAUNCH_BWD_B6(2) break;
+            case 4: HAN_LAUNCH_BWD_B6(4) break;
+            case 8: HAN_LAUNCH_BWD_B6(8) break;
+            default: HAN_LAUNCH_BWD_B6(16) break;
+        }
+#undef HAN_LAUNCH_BWD_B6
+        if (e3 != hipSuccess) return (int)e3;
+        HAN_CHECK_LAUNCH();
+        return 0;
+    }
     if (P == 1 || P == 2 || P == 4 || P == 8 || P == 16) {
         const int grid = han_grid_for(N > 0 ? N * P : 1, 64, kSemBwdBlocks);
         *grid_out = grid;

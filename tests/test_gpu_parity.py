@@ -478,7 +478,10 @@ def test_other_head_shapes_match_oracle(dev, K, FP, A, drop):
                                      (5000, 1, 64, 64), (129, 64, 128, 64),
                                      # 128-wide embeddings (hid_units=[16] x 8 heads): the width-templated kernels
                                      (1, 1, 128, 128), (50, 2, 128, 128), (333, 4, 64, 128), (2000, 8, 128, 128),
-                                     (77, 5, 128, 128), (129, 64, 64, 128), (5000, 3, 128, 128)])
+                                     (77, 5, 128, 128), (129, 64, 64, 128), (5000, 3, 128, 128),
+                                     # >= 65536 rows: the forward contraction runs on the bf16 matrix pipe (exact split)
+                                     (20000, 4, 128, 64), (70000, 1, 64, 64), (9000, 8, 128, 64), (5000, 16, 64, 64),
+                                     (40000, 2, 128, 64)])
 def test_semantic_attention_fwd_bwd(dev, n, p, a, d):
     from han_amd import ops
     rng = np.random.default_rng(n + p)
