@@ -70,9 +70,10 @@ def test_project_dropout_matches_hash_masks(dev, n, f):
     assert rel_err(dW.cpu().numpy(), dWref) < 1e-4
 
 
+@pytest.mark.parametrize("variant", ["1"])
 @pytest.mark.parametrize("n,f,xbf", [(16384 + 77, 64, False), (20000, 1870 - 2, False), (17000, 256, True),
-                                     (40000, 36, False)])
-def test_project_matrix_pipe_kernel_fp32_class_accuracy(dev, n, f, xbf, monkeypatch):
+                                     (40000, 36, False), (16500, 200, True)])
+def test_project_matrix_pipe_kernel_fp32_class_accuracy(dev, n, f, xbf, variant, monkeypatch):
     """Large inputs run K1 on the bf16 matrix pipe with an exact three-way bf16 split of both operands
     (six products; project_fwd_b6_kernel).  It must be as accurate as the exact-fp32 MFMA kernel: both
     against the float64 product, at the ACM feature width (1868 ~ 1870, F % 4 == 0) too; F = 36 has a
@@ -91,7 +92,7 @@ def test_project_matrix_pipe_kernel_fp32_class_accuracy(dev, n, f, xbf, monkeypa
     scale = np.abs(x) @ np.abs(W)                    # sum |x w|: what an fp32 dot product's error scales with
     monkeypatch.setenv("HAN_K1_B6", "0")
     H32, _, _ = ops.project_fwd(*args)
-    monkeypatch.setenv("HAN_K1_B6", "1")
+    monkeypatch.setenv("HAN_K1_B6", variant)
     H6, f1, f2 = ops.project_fwd(*args)
     e32 = np.abs(H32.cpu().numpy() - Href) / scale
     e6 = np.abs(H6.cpu().numpy() - Href) / scale
@@ -101,13 +102,14 @@ def test_project_matrix_pipe_kernel_fp32_class_accuracy(dev, n, f, xbf, monkeypa
     assert np.abs(f1.cpu().numpy() - f1ref).max() < 1e-3 * max(1.0, np.abs(f1ref).max())
 
 
-@pytest.mark.parametrize("f,xbf", [(44, False), (256, False), (64, True)])
-def test_project_matrix_pipe_kernel_dropout_masks(dev, f, xbf, monkeypatch):
+@pytest.mark.parametrize("variant", ["1"])
+@pytest.mark.parametrize("f,xbf", [(44, False), (256, False), (64, True), (328, False)])
+def test_project_matrix_pipe_kernel_dropout_masks(dev, f, xbf, variant, monkeypatch):
     """The matrix-pipe kernel with the per-head input dropout (layers.py:18-19: packed 16-bit keep masks on
     the A fragments) and the projected-row keep bits, against the NumPy-regenerated hash masks -- and
     bit-for-bit the same keep decisions as the fp32 kernel."""
     from han_amd import ops
-    monkeypatch.setenv("HAN_K1_B6", "1")
+    monkeypatch.setenv("HAN_K1_B6", variant)
     n = 16384 + 130
     rng = np.random.default_rng(f)
     seed, drop, off = 0x0BADC0DE1234, 0.6, 977
