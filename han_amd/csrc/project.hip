@@ -41,7 +41,41 @@ struct ProjFwdArgs {
     // ([nsplit][N][64] fp32); project_finish_kernel sums them in a fixed order.
     int f_chunk;        // multiple of BK; >= F when not split
     float *partial;     // null when not split
+    // attention scores in the epilogue (layers.py:23-24), from the values exactly as stored; null f1 = not fused
+    // (split-F: project_scores_kernel runs after the finish kernel)
+    const float *a1, *a2, *b1, *b2;
+    float *f1, *f2;
 };
+
+// f1 = H_k . a1_k + b1_k, f2 likewise, for the row whose stored elements (row, 16t + l15), t < 4, this lane
+// holds in vst[]: the F' columns of a head sit in min(F',16) consecutive lanes of a 16-lane group and in
+// max(1, F'/16) column tiles.  Epilogue code (once per output element), not a hot loop.
+template <int FP>
+__device__ __forceinline__ void tile_scores(const ProjFwdArgs &a, int64_t row, bool row_ok, const float (&vst)[4],
+                                            const float (&a1c)[4], const float (&a2c)[4], int l15) {
+    constexpr int K = HAN_D / FP;
+    constexpr int NT = FP >= 16 ? FP / 16 : 1;       // column tiles per head
+    constexpr int NL = FP >= 16 ? 16 : FP;           // lanes per head inside a tile
+#pragma unroll
+    for (int u = 0; u < 4 / NT; ++u) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = u * NT; t < (u + 1) * NT; ++t) {
+            s1 += vst[t] * a1c[t];
+            s2 += vst[t] * a2c[t];
+        }
+#pragma unroll
+        for (int o = 1; o < NL; o <<= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+        }
+        const int head = FP >= 16 ? u : (16 * u + l15) / FP;
+        if (row_ok && (l15 % NL) == 0) {
+            a.f1[row * K + head] = s1 + a.b1[head];
+            a.f2[row * K + head] = s2 + a.b2[head];
+        }
+    }
+}
 
 __device__ __forceinline__ float load_x1(const void *X, int bf, int64_t idx) {
     if (bf) return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(X)[idx] << 16);
@@ -182,17 +216,27 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a_in
     }
     // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
     const int myhh = HPT > 1 ? l15 / FP : 0;   // which head accumulator holds this lane's column
+    float a1c[4], a2c[4];
+    if (a.f1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a1c[t] = a.a1[16 * t + l15];
+            a2c[t] = a.a2[16 * t + l15];
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 16 * (w * MT + m) + l4 * 4 + r;
+            float vst[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = row0 + 16 * (w * MT + m) + l4 * 4 + r;
+            for (int t = 0; t < 4; ++t) {
                 float v = acc[m][t][0][r];
 #pragma unroll
                 for (int hh = 1; hh < HPT; ++hh) v = (myhh == hh) ? acc[m][t][hh][r] : v;
                 if (DROP) v *= a.inv_keep_in;
+                vst[t] = v;
                 if (a.partial) {   // split-F: raw partial sums, finished by project_finish_kernel
                     if (row < a.N) a.partial[((int64_t)blockIdx.y * a.N + row) * HAN_D + 16 * t + l15] = v;
                     continue;
@@ -207,17 +251,18 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a_in
                     keepbit = rn.field(d & 3) < a.thr_fts ? 1u : 0u;
                     stamp = 1;
                 }
-                if (row < a.N) {
-                    if (a.h_bf16) {
-                        uint32_t b = han_f32_to_bf16_bits(v);
-                        if (stamp) b = (b & ~1u) | keepbit;
-                        reinterpret_cast<uint16_t *>(a.H)[row * HAN_D + 16 * t + l15] = (uint16_t)b;
-                    } else {
-                        if (stamp) v = __uint_as_float((__float_as_uint(v) & ~1u) | keepbit);
-                        reinterpret_cast<float *>(a.H)[row * HAN_D + 16 * t + l15] = v;
-                    }
+                if (a.h_bf16) {
+                    uint32_t b = han_f32_to_bf16_bits(v);
+                    if (stamp) b = (b & ~1u) | keepbit;
+                    if (row < a.N) reinterpret_cast<uint16_t *>(a.H)[row * HAN_D + 16 * t + l15] = (uint16_t)b;
+                    vst[t] = __uint_as_float(b << 16);
+                } else {
+                    if (stamp) v = __uint_as_float((__float_as_uint(v) & ~1u) | keepbit);
+                    if (row < a.N) reinterpret_cast<float *>(a.H)[row * HAN_D + 16 * t + l15] = v;
+                    vst[t] = v;
                 }
             }
+            if (a.f1) tile_scores<FP>(a, row, row < a.N, vst, a1c, a2c, l15);
         }
     }
 }
@@ -432,13 +477,22 @@ __global__ __launch_bounds__(256) void project_fwd_b6_kernel(const ProjFwdArgs a
     }
     // epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg (as the fp32 kernel's)
     const int myhh = HPT > 1 ? l15 / 8 : 0;
+    float a1c[4], a2c[4];
+    if (DROP && a.f1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a1c[t] = a.a1[16 * t + l15];
+            a2c[t] = a.a2[16 * t + l15];
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 16 * (w * MT + m) + l4 * 4 + r;
+            float vst[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = row0 + 16 * (w * MT + m) + l4 * 4 + r;
+            for (int t = 0; t < 4; ++t) {
                 float v = acc[m][t][0][r];
                 if (HPT > 1) v = myhh ? acc[m][t][HPT - 1][r] : v;
                 if (DROP) v *= a.inv_keep_in;
@@ -450,17 +504,18 @@ __global__ __launch_bounds__(256) void project_fwd_b6_kernel(const ProjFwdArgs a
                     keepbit = rn.field(d & 3) < a.thr_fts ? 1u : 0u;
                     stamp = 1;
                 }
-                if (row < a.N) {
-                    if (a.h_bf16) {
-                        uint32_t b = han_f32_to_bf16_bits(v);
-                        if (stamp) b = (b & ~1u) | keepbit;
-                        reinterpret_cast<uint16_t *>(a.H)[row * HAN_D + 16 * t + l15] = (uint16_t)b;
-                    } else {
-                        if (stamp) v = __uint_as_float((__float_as_uint(v) & ~1u) | keepbit);
-                        reinterpret_cast<float *>(a.H)[row * HAN_D + 16 * t + l15] = v;
-                    }
+                if (a.h_bf16) {
+                    uint32_t b = han_f32_to_bf16_bits(v);
+                    if (stamp) b = (b & ~1u) | keepbit;
+                    if (row < a.N) reinterpret_cast<uint16_t *>(a.H)[row * HAN_D + 16 * t + l15] = (uint16_t)b;
+                    vst[t] = __uint_as_float(b << 16);
+                } else {
+                    if (stamp) v = __uint_as_float((__float_as_uint(v) & ~1u) | keepbit);
+                    if (row < a.N) reinterpret_cast<float *>(a.H)[row * HAN_D + 16 * t + l15] = v;
+                    vst[t] = v;
                 }
             }
+            if (DROP && a.f1) tile_scores<8>(a, row, row < a.N, vst, a1c, a2c, l15);
         }
     }
 }
@@ -846,7 +901,9 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
     int mt, nsplit;
     fwd_geometry(N, F, &mt, &nsplit, &a.f_chunk);
     a.partial = nullptr;
+    a.a1 = a1; a.a2 = a2; a.b1 = b1; a.b2 = b2; a.f1 = f1; a.f2 = f2;      // scores fused into the epilogue ...
     if (nsplit > 1) {
+        a.f1 = nullptr; a.f2 = nullptr;                                     // ... except on the split-F path
         if (!workspace || workspace_bytes < han_project_fwd_workspace(N, F, K, FP)) return HAN_E_WORKSPACE;
         a.partial = (float *)workspace;
     }
@@ -891,6 +948,7 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
         else project_finish_kernel<false><<<fgrid, 256, 0, st>>>(a, nsplit);
         HAN_CHECK_LAUNCH();
     }
+    if (a.f1 && !(b6 && in_drop == 0.f)) return 0;      // f1 / f2 were written by the epilogue
     ScoreArgs s;
     s.H = H; s.a1 = a1; s.a2 = a2; s.b1 = b1; s.b2 = b2; s.f1 = f1; s.f2 = f2;
     s.N = N;
