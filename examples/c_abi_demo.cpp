@@ -97,7 +97,7 @@ int main(int argc, char **argv) {
                            N, F, K, FP, 0.f, 0.f, 0, nullptr, 0, st));
     HAN_OK(han_node_attn_fwd(drp, dci, nullptr, dH, HAN_DTYPE_F32, nullptr, df1, da2, db2, dc, nullptr, dM, D,
                              nullptr, nullptr, nullptr, nullptr, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0,
-                             HAN_ACT_ELU, nullptr, st));
+                             HAN_ACT_ELU, /*flags*/ 0, nullptr, st));
     HAN_OK(han_sem_attn_fwd(dM, dwo, dbo, duo, dZ, dbeta, N, 1, D, A, st));
     HIP_OK(hipStreamSynchronize(st));
 

@@ -41,7 +41,7 @@ SIGNATURES = {
     "han_project_bwd_input": (c_int, [P, P, P, I64, I64, c_int, c_int, c_int, c_float, c_uint64, P, I64, P]),
     "han_row_split_workspace": (c_size_t, [I64]),
     "han_node_attn_fwd": (c_int, [P, P, P, P, c_int, P, P, P, P, P, P, P, I64, P, P, P, P, I64, I64, c_int,
-                                  c_int, c_float, c_float, c_float, c_uint64, P, I64, c_int, P, P]),
+                                  c_int, c_float, c_float, c_float, c_uint64, P, I64, c_int, c_int, P, P]),
     "han_node_attn_coefs": (c_int, [P, P, P, P, P, P, P, c_int, I64, I64, c_int, c_int, c_float, c_float,
                                     c_uint64, P, I64, P]),
     "han_node_attn_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
@@ -49,7 +49,7 @@ SIGNATURES = {
     "han_node_attn_bwd_rows": (c_int, [P, I64, P, P, P, P, P, P, P, P, c_int, P, P, P, c_size_t, I64,
                                        c_int, c_int, c_int, P]),
     "han_node_attn_bwd_cols": (c_int, [P, P, P, P, P, P, c_int, P, P, P, P, P, P, I64, I64, c_int, c_int,
-                                       c_float, c_float, c_float, c_uint64, P, I64, I64, P, P]),
+                                       c_float, c_float, c_float, c_uint64, P, I64, I64, c_int, P, P]),
     "han_score_param_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
     "han_score_param_bwd": (c_int, [P, c_int, P, P, P, P, P, P, P, c_size_t, I64, c_int, c_int, P]),
     "han_sem_attn_fwd": (c_int, [P, P, P, P, P, P, I64, c_int, c_int, c_int, P]),
@@ -65,7 +65,7 @@ SIGNATURES = {
     "han_bias_fill_csr": (c_int, [P, I64, I64, P, P, P]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

@@ -53,10 +53,11 @@ __device__ __forceinline__ float dot4(const float4_t &x, const float4_t &y) {
 // identity order every XCD touches rows spread over that whole stripe, so on a graph with locality all eight
 // L2s cache the SAME source window (each source row is fetched up to 8 times per sweep).  Here the blocks of
 // one XCD take one contiguous eighth of every stripe instead: the eight L2s hold eight different windows.
-// Pure speed: any bijection of the work units is correct; it is the identity when gridDim.x % 8 != 0.
-__device__ __forceinline__ int64_t xcd_first_unit(int wave_in_block) {
+// Pure speed: any bijection of the work units is correct; it is the identity when gridDim.x % 8 != 0 and when
+// the caller does not set HAN_FLAG_XCD_ORDER (graphs without locality: 9 % slower in the HBM regime).
+__device__ __forceinline__ int64_t xcd_first_unit(int wave_in_block, int xcd_order) {
     const unsigned b = blockIdx.x, g = gridDim.x;
-    const unsigned vb = (g % 8u == 0u) ? (b % 8u) * (g / 8u) + b / 8u : b;
+    const unsigned vb = (xcd_order && g % 8u == 0u) ? (b % 8u) * (g / 8u) + b / 8u : b;
     return (int64_t)vb * 4 + wave_in_block;
 }
 
@@ -82,6 +83,7 @@ struct FwdArgs {
     float inv_keep_coef, inv_keep_fts;
     int64_t row_offset;
     int activation;
+    int xcd_order;      // HAN_FLAG_XCD_ORDER
     // row splitting for skewed graphs (see HanRowSplit): rows longer than split_deg are
     // skipped by the main launch and handled by the partial + finish launches
     int64_t split_deg;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) 
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
     const int head = (4 * q) / FP;
-    const int64_t wave0 = xcd_first_unit(threadIdx.x >> 6);
+    const int64_t wave0 = xcd_first_unit(threadIdx.x >> 6, a.xcd_order);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const float4_t c4 = *reinterpret_cast<const float4_t *>(a.c + 4 * q);
     const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
@@ -580,6 +582,7 @@ struct BwdColsArgs {
     const uint64_t *seed_dev;
     float inv_keep_coef, inv_keep_fts;
     int64_t src_offset, dst_offset;
+    int xcd_order;
     int64_t split_deg;
     int64_t n_long, n_chunks;
     const int64_t *long_rows, *long_ptr, *chunk_start, *chunk_end;
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
     const int head = (4 * q) / FP;
-    const int64_t wave0 = xcd_first_unit(threadIdx.x >> 6);
+    const int64_t wave0 = xcd_first_unit(threadIdx.x >> 6, a.xcd_order);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const bool drop_c = a.thr_coef < HAN_KEEP_ALL;
     const float4_t a14 = *reinterpret_cast<const float4_t *>(a.a1 + 4 * q);
@@ -1069,7 +1072,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
                                  float *lse,
                                  float *aggp, float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
                                  float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev,
-                                 int64_t row_offset, int activation, const han_row_split_t *split,
+                                 int64_t row_offset, int activation, int flags, const han_row_split_t *split,
                                  void *stream) {
     if (N == 0) return 0;   // nothing to do; row pointers of empty tensors may be null
     if (!rowptr || (!colidx && E > 0) || !H || !f1 || !a2 || !b2 || !c || !out || N < 0 || E < 0 || out_stride < HAN_D)
@@ -1089,7 +1092,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
     a.inv_keep_fts = 1.f / (1.f - fts_drop);
-    a.row_offset = row_offset; a.activation = activation;
+    a.row_offset = row_offset; a.activation = activation; a.xcd_order = (flags & HAN_FLAG_XCD_ORDER) ? 1 : 0;
     const bool has_split = split && split->n_long > 0;
     a.split_deg = has_split ? split->split_deg : INT64_MAX;
     a.n_long = has_split ? split->n_long : 0;
@@ -1160,8 +1163,8 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
                                       const float *df1, const float *a1, const float *a2,
                                       float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                                       float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev,
-                                      int64_t src_offset, int64_t dst_offset, const han_row_split_t *split,
-                                      void *stream) {
+                                      int64_t src_offset, int64_t dst_offset, int flags,
+                                      const han_row_split_t *split, void *stream) {
     if (!colptr || (!rowidx && E > 0) || !gs || !H || !f2 || !df1 || !a1 || !a2 || !dH || !df2 || NS < 0 || E < 0)
         return HAN_E_BADARG;
     if (!split_ok(split)) return HAN_E_BADARG;
@@ -1175,7 +1178,7 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
     a.inv_keep_fts = 1.f / (1.f - fts_drop);
-    a.src_offset = src_offset; a.dst_offset = dst_offset;
+    a.src_offset = src_offset; a.dst_offset = dst_offset; a.xcd_order = (flags & HAN_FLAG_XCD_ORDER) ? 1 : 0;
     const bool has_split = split && split->n_long > 0;
     a.split_deg = has_split ? split->split_deg : INT64_MAX;
     a.n_long = has_split ? split->n_long : 0;

@@ -50,6 +50,7 @@ class CSRGraph:
         self.values = values
         self._t = None
         self._split = {}
+        self._locality = None
         if validate:
             self.validate()
 
@@ -71,6 +72,21 @@ class CSRGraph:
 
     def degrees(self) -> torch.Tensor:
         return self.rowptr[1:] - self.rowptr[:-1]
+
+    def has_locality(self) -> bool:
+        """True when neighbour ids sit close to the row id (mean |col - row| below 5 % of the table): the K2
+        launches then use the XCD-aware work order (HAN_FLAG_XCD_ORDER).  One pass over a sample of the
+        edges, cached; graphs indexing a [local | halo] table (remapped columns) count as local."""
+        if self._locality is None:
+            if self.nnz == 0 or self.n_rows == 0:
+                self._locality = False
+            else:
+                step = max(1, self.nnz // 2_000_000)
+                pos = torch.arange(0, self.nnz, step, device=self.device)
+                rows = torch.searchsorted(self.rowptr, pos, right=True) - 1
+                dist = (self.colidx[pos].long() - rows).abs().double().mean()
+                self._locality = bool(float(dist) < 0.05 * max(self.n_cols, 1))
+        return self._locality
 
     def has_empty_rows(self) -> bool:
         return self.n_rows > 0 and bool((self.degrees() == 0).any())

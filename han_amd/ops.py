@@ -15,6 +15,7 @@ from .graph import CSRGraph
 
 ACT_IDENTITY = 0
 ACT_ELU = 1
+FLAG_XCD_ORDER = 1         # HAN_FLAG_XCD_ORDER: XCD-aware work order for graphs with locality
 LEAKY_SLOPE = 0.2          # tf.nn.leaky_relu default (utils/layers.py:27)
 D = 64                     # K * F' of this build
 STATS_ROW_BYTES = 128      # per destination row: the (f1, lse, s, 0) records of the K = 8 heads inside the fused gs row (bench.py byte model)
@@ -271,7 +272,7 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         a2.data_ptr(), b2.data_ptr(), c.data_ptr(), res.data_ptr() if res is not None else None,
         out.data_ptr(), out.stride(0) if N > 1 else D,
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
-        int(seed), _dev_word(seed_dev), int(row_offset), int(activation),
+        int(seed), _dev_word(seed_dev), int(row_offset), int(activation), FLAG_XCD_ORDER if graph.has_locality() else 0,
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_fwd")
     if timing is not None:
         ev1.record()
@@ -390,7 +391,7 @@ def node_attn_bwd_cols(graph_t: CSRGraph, gs_tab, H, f2, df1, a1, a2, coef_drop=
         table_gid.data_ptr() if table_gid is not None else None, H.data_ptr(),
         tcode, f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
         NS, graph_t.nnz, K, FP, LEAKY_SLOPE, _check_drop(coef_drop, "coef_drop"), fts_drop,
-        int(seed), _dev_word(seed_dev), int(src_offset), int(dst_offset),
+        int(seed), _dev_word(seed_dev), int(src_offset), int(dst_offset), FLAG_XCD_ORDER if graph_t.has_locality() else 0,
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_bwd_cols")
     if timing is not None:
         ev1.record()

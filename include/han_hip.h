@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HAN_ABI_VERSION 2
+#define HAN_ABI_VERSION 3
 
 #define HAN_E_BADARG   (-1)   /* null pointer, negative size, inconsistent shape.  The forward
                               * entry points return 0 at once for N == 0 (empty tensors may
@@ -37,6 +37,11 @@ extern "C" {
 
 #define HAN_ACT_IDENTITY 0
 #define HAN_ACT_ELU      1
+/* `flags` of han_node_attn_fwd / han_node_attn_bwd_cols */
+#define HAN_FLAG_XCD_ORDER 1   /* graph has locality (neighbour ids close to the row id): give the blocks of one
+                                  XCD a contiguous share of the rows in flight, so that the eight L2s cache eight
+                                  different source windows.  Speed only; off for graphs without structure, where it
+                                  measured 9 % slower in the HBM regime (eight separate index / output streams). */
 
 /* storage type of X and of the gather tables H / g ("bf16 feats" of the 10M-node
  * config): everything is accumulated in fp32; bf16 tables need K == FP == 8      */
@@ -135,7 +140,7 @@ int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float 
                       float *out, int64_t out_stride, float *pre, float *lse, float *aggp,
                       float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
                       float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset,
-                      int activation, const han_row_split_t *split, void *stream);
+                      int activation, int flags, const han_row_split_t *split, void *stream);
 
 /* The attention coefficients themselves (attn_head(..., return_coef=True),
  * utils/layers.py:27-30,43-44; models/gat.py:143-172 averages them over the heads):
@@ -187,7 +192,7 @@ int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const f
                            const float *df1, const float *a1, const float *a2,
                            float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                            float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev,
-                           int64_t src_offset, int64_t dst_offset,
+                           int64_t src_offset, int64_t dst_offset, int flags,
                            const han_row_split_t *split, void *stream);
 
 /* Backward, step 3: gradients of the score parameters
