@@ -56,6 +56,7 @@ __device__ __forceinline__ void tile_scores(const ProjFwdArgs &a, int64_t row, b
     constexpr int K = HAN_D / FP;
     constexpr int NT = FP >= 16 ? FP / 16 : 1;       // column tiles per head
     constexpr int NL = FP >= 16 ? 16 : FP;           // lanes per head inside a tile
+    float r1[4 / NT], r2[4 / NT];
 #pragma unroll
     for (int u = 0; u < 4 / NT; ++u) {
         float s1 = 0.f, s2 = 0.f;
@@ -69,10 +70,35 @@ __device__ __forceinline__ void tile_scores(const ProjFwdArgs &a, int64_t row, b
             s1 += __shfl_xor(s1, o, 64);
             s2 += __shfl_xor(s2, o, 64);
         }
+        r1[u] = s1;
+        r2[u] = s2;
+    }
+    if (FP == 8) {
+        // lanes 0 / 8 of the group hold heads 2u / 2u+1: bring the odd heads over and let lane 0 write the
+        // row's 8 scores as two 16-byte stores (16 scattered 4-byte stores per row cost as much as the
+        // separate scores kernel they replaced)
+        float4_t o1[2], o2[2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float e1 = __shfl_xor(r1[u], 8, 64), e2 = __shfl_xor(r2[u], 8, 64);
+            o1[u >> 1][2 * (u & 1)] = r1[u] + a.b1[2 * u];
+            o1[u >> 1][2 * (u & 1) + 1] = e1 + a.b1[2 * u + 1];
+            o2[u >> 1][2 * (u & 1)] = r2[u] + a.b2[2 * u];
+            o2[u >> 1][2 * (u & 1) + 1] = e2 + a.b2[2 * u + 1];
+        }
+        if (row_ok && l15 == 0) {
+            float4_t *p1 = reinterpret_cast<float4_t *>(a.f1 + row * K), *p2 = reinterpret_cast<float4_t *>(a.f2 + row * K);
+            p1[0] = o1[0]; p1[1] = o1[1];
+            p2[0] = o2[0]; p2[1] = o2[1];
+        }
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < 4 / NT; ++u) {
         const int head = FP >= 16 ? u : (16 * u + l15) / FP;
         if (row_ok && (l15 % NL) == 0) {
-            a.f1[row * K + head] = s1 + a.b1[head];
-            a.f2[row * K + head] = s2 + a.b2[head];
+            a.f1[row * K + head] = r1[u] + a.b1[head];
+            a.f2[row * K + head] = r2[u] + a.b2[head];
         }
     }
 }
