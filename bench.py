@@ -413,10 +413,11 @@ def main():
         r["traffic"] = (traffic_per or {}).get(tkey[tag]) if traffic_per else None
         r["traffic_source"] = traffic_src
     hbm = None
-    if rank == 0 and world == 1 and args.hbm_regime_nodes > 0 and not use_graph and table_mb < 600:
+    if rank == 0 and world == 1 and args.hbm_regime_nodes > 0 and not use_graph and table_mb < 600 \
+            and args.workload.startswith("syn-1m"):      # the headline family; other workloads are not priced against HBM
         del trainer, model
         torch.cuda.empty_cache()
-        hbm = hbm_regime_probe(dev, args.hbm_regime_nodes, args.table_dtype, max(args.steps, 5))
+        hbm = hbm_regime_probe(dev, args.hbm_regime_nodes, args.table_dtype, min(max(args.steps, 5), 20))
 
     if rank == 0:
         out = {
