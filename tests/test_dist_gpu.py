@@ -34,16 +34,24 @@ def test_two_ranks_match_single_process(dev, tmp_path, drop):
     assert np.abs(a["hist"] - b["hist"]).max() < 2e-5
 
 
-def test_rccl_collectives_on_a_one_rank_group(dev, tmp_path):
-    """The RCCL code path (backend nccl: all_gather_into_tensor async + wait,
-    all_reduce of the flat gradients, barrier) on a 1-rank communicator -- the
-    only way to execute those calls on a single-GPU box."""
+@pytest.mark.parametrize("mode", ["halo", "allgather-local-rows", "allgather-local-rows-bf16"])
+def test_rccl_collectives_on_a_one_rank_group(dev, tmp_path, mode):
+    """The RCCL code path on a 1-rank communicator -- the only way to execute those calls on a single-GPU
+    box: all_to_all_single with (empty) uneven splits for the halo plans and their per-step exchange,
+    all_gather_into_tensor async + wait into the persistent tables (fp32 H, fused uint8 [g | stats] rows,
+    bf16 storage), the edge all-to-all-v of shard_local_graph, the all_reduce of the flat gradients, barrier."""
     one, forced = str(tmp_path / "one.npz"), str(tmp_path / "forced.npz")
-    _launch(1, 2, 0.6, one, 29621)
-    _launch(1, 2, 0.6, forced, 29623, {"HAN_FORCE_COLLECTIVES": "1", "HAN_TEST_BACKEND": "nccl"})
+    extra = {}
+    if mode != "halo":
+        extra = {"HAN_TEST_ALLGATHER": "1", "HAN_TEST_LOCAL": "1",
+                 "HAN_TEST_BF16": "1" if mode.endswith("bf16") else "0"}
+    _launch(1, 2, 0.6, one, 29621, extra)
+    _launch(1, 2, 0.6, forced, 29623, {"HAN_FORCE_COLLECTIVES": "1", "HAN_TEST_BACKEND": "nccl", **extra})
     a, b = np.load(one), np.load(forced)
-    assert np.abs(a["flat"] - b["flat"]).max() < 5e-6      # different kernel instantiations (FAST / generic)
-    assert np.abs(a["hist"] - b["hist"]).max() < 1e-6
+    tol = 5e-6 if not mode.endswith("bf16") else 5e-4      # different kernel instantiations (FAST / generic)
+    assert np.abs(a["flat"] - b["flat"]).max() < tol
+    assert np.abs(a["hist"] - b["hist"]).max() < max(tol, 1e-6)
+    assert int(b["halo_plans"]) == (4 if mode == "halo" else 0)
 
 
 def test_halo_exchange_two_ranks_real_kernels(dev, tmp_path):
