@@ -941,7 +941,9 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
     // the eval forward stays on the exact-fp32 pipe unless HAN_K1_B6=1 asks for this kernel.  (A wave-local
     // variant -- no LDS staging of X, no barrier per K-step, W chunks of 128 k in LDS -- measured the same:
     // 0.49 / 0.80 ms against 0.46 / 0.78 ms for this one, eval / training, kernel_bench.py k1.)
-    const bool b6_want = in_drop > 0.f ? !(b6env && b6env[0] == '0') : (b6env && b6env[0] == '1');
+    // bf16 features are their own high term (no split, three products instead of six): there the matrix-pipe
+    // kernel is also the faster eval forward
+    const bool b6_want = (in_drop > 0.f || a.x_bf16) ? !(b6env && b6env[0] == '0') : (b6env && b6env[0] == '1');
     const bool b6 = vec && nsplit == 1 && N >= 64 * 256 && (in_drop == 0.f || (K == 8 && FP == 8)) && b6_want;
     if (b6) {
         const dim3 g6((unsigned)((N + B6_ROWS - 1) / B6_ROWS));
@@ -1014,7 +1016,8 @@ extern "C" int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const fl
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
     dim3 grid(ftiles, (unsigned)nch);
-    const bool vec = !a.x_bf16 && (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
+    // 16-byte fp32 / 8-byte bf16 X loads (the scalar path costs 1.7x at SYN-10M: 14.3 vs 8.4 ms per launch)
+    const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & (a.x_bf16 ? 7 : 15)) == 0);
     // (dW on the bf16 x 6 matrix pipe was built and measured in round 2 -- coalesced loads + on-chip transpose:
     // 0.55 ms without / 0.83 ms with dropout against 0.41 / 0.84 ms for this exact-fp32 kernel at SYN-1M --
     // and not kept: the transposition of both operands through LDS costs what the shorter matrix time saves.)

@@ -76,6 +76,8 @@ def main():
         del g, gt, X, H
     if "k1" in which:
         X = rnd(n, f)
+        if kv.get("xbf") == "1":          # bf16 features (configs[4])
+            X = X.to(torch.bfloat16)
         W = rnd(f, 64) * 0.1
         a1, a2, b1, b2 = rnd(8, 8), rnd(8, 8), rnd(8), rnd(8)
         dH = rnd(n, 64)
