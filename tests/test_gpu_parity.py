@@ -1468,3 +1468,52 @@ def test_many_classes_through_the_model(dev):
     assert abs(acc - acc_ref) < 1e-5
     for k in ht.PARAM_ORDER:
         assert rel_err(grads[k], gref[k]) < GTOL, k
+
+
+def test_structural_properties_of_the_node_attention(dev):
+    """Properties SURVEY.md section 4 lists, on the real kernels (no oracle needed):
+    (1) the order of the stored neighbours inside a row does not matter;
+    (2) K single-head calls of the reference-named attn_head, concatenated, equal the K-head model layer
+        (models/gat.py:42-46 builds the layer exactly that way);
+    (3) a repeated neighbour is a repeated softmax term (the multigraph reading the synthetic graphs rely on):
+        doubling every edge of a row changes nothing, doubling ONE edge shifts weight to it;
+    (4) rows are independent: changing the neighbour list of row r changes only output row r."""
+    import torch.nn.functional as Fnn
+    from han_amd import layers, ops
+    from han_amd.graph import CSRGraph
+    prob = make_problem(77, 120, 10, 1, 3, [0.08])
+    model, bp = build_model(prob, dev)
+    x, graphs = gpu_inputs(prob, dev)
+    g = graphs[0]
+    with torch.no_grad():
+        M = model.node_level([x], [g], 0.0, 0.0, False, ops.ACT_ELU)[:, 0, :]
+        # (1) shuffle the columns inside every row
+        gen = torch.Generator(device=dev).manual_seed(1)
+        rows = torch.repeat_interleave(torch.arange(g.n_rows, device=dev), g.degrees())
+        key = rows.double() + torch.rand(g.nnz, device=dev, generator=gen, dtype=torch.float64) * 0.5
+        perm = torch.sort(key).indices
+        gs = CSRGraph(g.rowptr, g.colidx[perm].contiguous(), g.n_cols)
+        assert not torch.equal(gs.colidx, g.colidx)
+        Ms = model.node_level([x], [gs], 0.0, 0.0, False, ops.ACT_ELU)[:, 0, :]
+        assert float((M - Ms).abs().max()) < 2e-6
+        # (2) eight single-head calls
+        heads = []
+        for k in range(8):
+            params = {"W": model.W[0][:, 8 * k:8 * k + 8].contiguous(), "a1": model.a1[0, k], "b1": model.b1[0, k],
+                      "a2": model.a2[0, k], "b2": model.b2[0, k], "c": model.c[0][8 * k:8 * k + 8].contiguous()}
+            heads.append(layers.attn_head(x[None], 8, g, Fnn.elu, params=params)[0])
+        assert float((torch.cat(heads, 1) - M).abs().max()) < 2e-6
+        # (3) every edge doubled: identical; one extra copy of a single edge: only that row moves
+        dbl = CSRGraph(g.rowptr * 2, torch.repeat_interleave(g.colidx, 2).contiguous(), g.n_cols)
+        Md = model.node_level([x], [dbl], 0.0, 0.0, False, ops.ACT_ELU)[:, 0, :]
+        assert float((M - Md).abs().max()) < 2e-6
+        r = 17
+        s, e = int(g.rowptr[r]), int(g.rowptr[r + 1])
+        cols = torch.cat([g.colidx[:e], g.colidx[s:s + 1], g.colidx[e:]])
+        rp = g.rowptr.clone()
+        rp[r + 1:] += 1
+        one = CSRGraph(rp, cols.contiguous(), g.n_cols)
+        Mo = model.node_level([x], [one], 0.0, 0.0, False, ops.ACT_ELU)[:, 0, :]
+        # (4) only row r changed
+        changed = ((M - Mo).abs().max(1).values > 1e-7).nonzero().flatten().tolist()
+        assert changed == [r] or (changed == [] and e - s == 1)

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from han_amd import ops, synth  # noqa: E402
 
 
-def train_variants(dev, sizes=(1_000_000, 4_000_000)):
+def train_variants(dev, sizes=(1_000_000, 4_000_000, 10_000_000)):
     if os.environ.get("N_ONLY"):
         sizes = (int(os.environ["N_ONLY"]),)
     """Training kernels (forward with both dropouts, transposed-graph backward) in the
@@ -47,8 +47,18 @@ def train_variants(dev, sizes=(1_000_000, 4_000_000)):
             gs, df1, dc = ops.node_attn_bwd_rows(dOut, sv[0], sv[2], sv[3], f1, sv[1], c, table_dtype=tdt)
             tb = timeit(lambda: ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, coef_drop=0.6,
                                                        fts_drop=0.6, seed=3))
+            # 128-B lines requested per edge: the gathered row (2 fp32 / 1 bf16) + in the backward the line with
+            # the (f1, lse, s) records; DESIGN.md section 3 (K2): time ~ lines per edge, not bytes
+            lf, lb = (2, 3) if tdt == torch.float32 else (1, 2)
+            e = g.nnz
             print(json.dumps({"N": n, "tables": tag, "fwd_eval_ms": round(te, 3), "fwd_train_ms": round(tt, 3),
-                              "bwd_cols_ms": round(tb, 3)}), flush=True)
+                              "bwd_cols_ms": round(tb, 3), "lines_per_edge": {"fwd": lf, "bwd": lb},
+                              "ns_per_1000_lines": {"fwd_eval": round(te * 1e6 / (e * lf) * 1e3, 2),
+                                                    "fwd_train": round(tt * 1e6 / (e * lf) * 1e3, 2),
+                                                    "bwd_cols": round(tb * 1e6 / (e * lb) * 1e3, 2)},
+                              "line_TBs": {"fwd_eval": round(e * lf * 128 / te / 1e9, 2),
+                                           "fwd_train": round(e * lf * 128 / tt / 1e9, 2),
+                                           "bwd_cols": round(e * lb * 128 / tb / 1e9, 2)}}), flush=True)
             del H, gs, sv
         del g, gt
         torch.cuda.empty_cache()
