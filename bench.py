@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+HBM_COPY_GBS = 6290.0      # same guide: what a float4 streaming copy reaches; random whole-row gathers: 5.5-5.8 TB/s
 
 
 # --------------------------------------------------------------------------- K2 byte models
@@ -88,6 +89,7 @@ def k2_rooflines(timing, esz, regime):
         ach = b["moved"] / (avg * 1e-3) / 1e9
         out[tag] = {"bound": "hbm", "kernel": K2_KERNEL_NAME[tag], "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "frac_of_measured_copy_rate": round(ach / HBM_COPY_GBS, 4),
                     "bytes_model": "moved = bytes the kernel requests (f2_j recomputed from the gathered row, "
                                    "no f2 gather); SURVEY.md 8d's 292 B/edge figure is algorithmic_survey_8d",
                     "moved_bytes_per_launch": b["moved"],
