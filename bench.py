@@ -388,12 +388,19 @@ def main():
         trainer.epoch()
     barrier()
     ops.K2_TIMING = None if trainer.use_graph else []      # a replayed graph records no events
+    ms0 = torch.cuda.memory_stats(dev) if os.environ.get("HAN_BENCH_DIAG") else None
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
         last = trainer.epoch()
     barrier()
     dt = time.perf_counter() - t0
+    if ms0 is not None:      # allocator activity inside the timed region (a hipMalloc / hipFree there is a stall)
+        ms1 = torch.cuda.memory_stats(dev)
+        keys = ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_ooms")
+        print("[diag] allocator in the timed region:", {k: ms1.get(k, 0) - ms0.get(k, 0) for k in keys},
+              "reserved GB %.1f allocated peak GB %.1f" % (ms1["reserved_bytes.all.current"] / 1e9,
+                                                            ms1["allocated_bytes.all.peak"] / 1e9), file=sys.stderr)
     timing, ops.K2_TIMING = ops.K2_TIMING or [], None
     use_graph = trainer.use_graph
     if use_dist:
