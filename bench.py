@@ -459,6 +459,10 @@ def main():
             # the K2 kernel with the largest total time in the timed region
             out["roofline"] = dict(roofs[dom], dominant_by="total time among the K2 kernels in the timed region")
             out["roofline_k2_all"] = roofs
+        else:
+            out["roofline"] = None
+            out["roofline_note"] = ("no per-kernel HIP events in this run (an epoch replayed from a hipGraph "
+                                    "records none); run without --graph for the K2 rooflines")
         if hbm is not None:
             # the >= 50 % HBM target of BASELINE.json is read off THIS object: same kernels, same run,
             # a table 10x larger than the Infinity Cache

@@ -1,0 +1,90 @@
+"""bench.py's JSON line: the helpers that price the K2 kernels, and the committed lines under
+profiles/ against the driver's contract (keys, units, no HBM fraction above 1, a bounded
+CPU baseline with both thread counts).  No GPU needed."""
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CONTRACT_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _lines():
+    out = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_*.json"))):
+        txt = [l for l in open(f).read().splitlines() if l.startswith("{")]
+        assert len(txt) == 1, f"{f}: expected exactly one JSON line"
+        out.append((os.path.basename(f), json.loads(txt[0])))
+    return out
+
+
+def test_k2_byte_model():
+    # eval forward = E*(4 + 256 + 32) + rows; what the kernels request drops the f2 gather
+    n, e = 1_000_000, 50_000_000
+    b = bench.k2_bytes("eval", n, e, s=4)
+    assert b["algorithmic"] - b["moved"] == e * 32
+    assert b["moved"] >= e * (4 + 256)
+    assert b["compulsory"] < b["moved"]
+    bw = bench.k2_bytes("bwd_cols", n, e, s=4)
+    assert bw["moved"] >= e * (4 + 384)            # index + the fused [g | stats] row
+    b16 = bench.k2_bytes("eval", n, e, s=2)
+    assert b16["moved"] < b["moved"]
+
+
+def test_static_traffic_is_tied_to_the_kernel_sources(monkeypatch):
+    per, src = bench.static_traffic("syn-1m", 2, "f32")      # measured on one GPU only
+    assert per is None
+    per, src = bench.static_traffic("syn-1m", 1, "bf16")
+    assert per is None
+    monkeypatch.setattr(bench, "_src_sha", lambda: "0" * 16)
+    per, why = bench.static_traffic("syn-1m", 1, "f32")
+    assert per is None and "different kernel sources" in why
+
+
+def test_committed_bench_lines_follow_the_contract():
+    lines = _lines()
+    assert any(name == "r02_bench_syn1m_f32_1gpu.json" for name, _ in lines)
+    for name, d in lines:
+        d.setdefault("roofline", None)    # hipGraph-mode lines committed before the key became unconditional
+        assert CONTRACT_KEYS <= set(d), (name, CONTRACT_KEYS - set(d))
+        assert d["unit"] == "epochs/s" and d["higher_is_better"] is True and d["data"] == "synthetic"
+        assert d["vs_baseline"] is None                       # BASELINE.md holds no published number
+        assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-3
+        assert "workload" in d["config"] and "model" not in d["config"]
+        r = d["roofline"]
+        if r is None:                                         # a replayed hipGraph records no per-kernel events
+            assert "hipGraph" in d["config"]["parallelism"]
+            continue
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r), name
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        if r["bound"] == "hbm":
+            assert r["frac"] <= 1.0, (name, r["frac"])
+        for v in (d.get("roofline_hbm_regime") or {}).values():
+            if isinstance(v, dict):
+                assert v["frac"] <= 1.0
+
+
+def test_headline_line_carries_traffic_and_both_cpu_baselines():
+    d = dict(_lines())["r02_bench_syn1m_f32_1gpu.json"]
+    assert d["n_gpus"] == 1 and d["dtype"].startswith("f32")
+    r = d["roofline"]
+    assert r["traffic"] and r["traffic_source"]
+    # measured fabric bytes within 2 % of the bytes the kernel requests
+    assert abs(r["traffic"] / r["moved_bytes_per_launch"] - 1.0) < 0.02
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "epochs/s"
+    assert c["all_cores"]["threads"] == c["cores"] and c["one_thread"]["threads"] == 1
+    assert c["all_cores"]["sample_n"] >= 50_000
+    hb = d["roofline_hbm_regime"]
+    assert all(hb[k]["frac"] >= 0.5 for k in ("eval", "train", "bwd_cols"))     # BASELINE: >= 50 % of HBM peak
+
+
+def test_host_cores_reports_usable_cores():
+    cores, affinity, quota = bench.host_cores()
+    assert 1 <= cores <= affinity <= (os.cpu_count() or 1)
+    assert quota is None or cores <= quota
