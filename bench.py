@@ -286,6 +286,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--replicate", default="auto", choices=["auto", "all", "eval", "none"],
+                    help="multi-GPU: which forward passes project the whole H table on every rank instead of "
+                         "exchanging it (auto: both up to 4 ranks, the eval forward beyond)")
     ap.add_argument("--workload", default="syn-1m")
     ap.add_argument("--nodes", type=int, default=0, help="override N (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -368,13 +371,29 @@ def main():
         e_local = e_local.to(dev) if dist.get_backend() == "nccl" else e_local
         dist.all_reduce(e_local)
     e_global = int(e_local.item())
+    # Replicated projection (han_amd/dist.py:replication_policy): the forward passes it names project the
+    # whole H table on every rank from the features of ALL rows (1 KB per row, generated by every rank
+    # from the same block seeds) instead of receiving (G-1)/G of it over the xGMI links; the graph, the
+    # labels and every other per-row tensor stay rank-local.
+    x_full = None
+    if part is not None:
+        from han_amd.dist import replication_policy
+        if replication_policy(world, args.replicate):
+            x_full = synth.features(args.workload, device=dev, n_override=args.nodes or None)
+            if tdt == torch.bfloat16:
+                x_full = x_full.to(torch.bfloat16)
     trainer = HANTrainer(model, [wl["x"]] * p, wl["graphs"], wl["labels"], wl["train_mask"],
                          wl["val_mask"], lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
-                         part=part, use_graph=args.graph and part is None, graphs_local=part is not None)
+                         part=part, use_graph=args.graph and part is None, graphs_local=part is not None,
+                         xs_full=[x_full] * p if x_full is not None else None, replicate=args.replicate)
     exchange = None
     if part is not None:
         plans = model.halo_plans[0]
-        exchange = ["halo %.1f%% of the remote rows" % (100.0 * pl.halo_fraction) if pl is not None else "all-gather"
+        rep = sorted(trainer.replicate)
+        ag = {(): "all-gather",
+              ("eval",): "all-gather (training forward + backward); H projected on every rank in the eval forward",
+              ("eval", "train"): "all-gather (backward only); H projected on every rank in both forwards"}[tuple(rep)]
+        exchange = ["halo %.1f%% of the remote rows" % (100.0 * pl.halo_fraction) if pl is not None else ag
                     for pl in plans]
     wl["graphs"] = None
     torch.cuda.synchronize()

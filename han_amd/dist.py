@@ -306,6 +306,30 @@ class GatheredTable:
         return self.table
 
 
+# Replicated projection ("recompute instead of communicate").  xGMI is point-to-point: each pair of
+# GPUs shares ONE link (about 60 GB/s per direction in practice), so receiving the (G-1)/G remote
+# rows of a 256-B-per-row table costs rows * 256 B / (G * 60 GB/s) even when all G-1 links run in
+# parallel, whereas K1 recomputes a row from its features at ~1.4 TB/s of feature bytes (0.74 ms per
+# 1 GB of features with dropout, 0.40 ms without).  Per forward table at the
+# SYN-1M shape (1M rows, F = 256): exchange 2.1 / 1.1 / 0.5 ms at G = 2 / 4 / 8 against 0.37 / 0.55 /
+# 0.65 ms (training) and 0.20 / 0.30 / 0.35 ms (eval) of extra projection.  Hence: up to 4 ranks both
+# forwards project the whole table; beyond that, where exchange and compute are about balanced, only
+# the cheaper eval projection is replicated (it takes four of the twelve tables of an epoch off the
+# links).  The backward table [g | stats] depends on the loss of its rows and is always exchanged.
+def replication_policy(world: int, mode: str = "auto") -> frozenset:
+    """Which forward passes project the whole table on every rank: subset of {"train", "eval"}."""
+    mode = os.environ.get("HAN_REPLICATE", mode)
+    if mode == "none" or world <= 1:
+        return frozenset()
+    if mode == "all":
+        return frozenset(("train", "eval"))
+    if mode == "eval":
+        return frozenset(("eval",))
+    if mode != "auto":
+        raise ValueError(f"replicate = {mode!r}: expected auto / all / eval / none")
+    return frozenset(("train", "eval")) if world <= 4 else frozenset(("eval",))
+
+
 def _row_block(g: CSRGraph, r0: int, r1: int, n_cols: int) -> CSRGraph:
     rp = g.rowptr[r0:r1 + 1]
     s, e = int(rp[0]), int(rp[-1])

@@ -243,14 +243,16 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         return out
 
     def node_level(self, xs, graphs, attn_drop, ffd_drop, train, act_code, graphs_t=None, coef_sink=None,
-                   post=None):
+                   post=None, xs_full=None):
         """models/gat.py:39-60: every node-attention layer of every meta-path -> M (N,P,K*F').
         coef_sink: a list that receives, per meta-path, the head-mean coefficients of the
         FIRST layer (models/gat.py:143-172), or None.
         post: an arbitrary `activation` callable (models/gat.py:36 takes any): the kernels then emit
         the pre-activation (act_code = identity) and torch applies `post` -- per head, on
         (N,P,K,F') so that an activation acting on the last axis sees what the reference's
-        per-head (1,N,F') tensor gives it -- with its own autograd."""
+        per-head (1,N,F') tensor gives it -- with its own autograd.
+        xs_full: under a node partition, the features of ALL rows (P tensors (N,F)): the first layer
+        then projects the whole table on every rank instead of exchanging it (replicated projection)."""
         P = len(graphs)
 
         def act(M, K, FP):
@@ -273,7 +275,7 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
                     "seeds": sd, "seed_dev": self.step_seed_dev if train else None,
                     "act": act_code, "part": self.partition, "graphs_t": graphs_t, "layer": layer,
                     "table_dtype": self.table_dtype, "plans_f": self.halo_plans[0],
-                    "plans_b": self.halo_plans[1], **kw}
+                    "plans_b": self.halo_plans[1], "xs_full": xs_full if layer == 0 else None, **kw}
 
         def layer_fwd(layer, Xin, xs_, K, FP, sink):
             """One node-attention layer: its K heads run through the 64-column K1/K2 kernels in groups of

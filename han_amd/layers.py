@@ -47,6 +47,16 @@ def _direct(p) -> bool:
     return bool(getattr(p, "_han_direct_grad", False)) and p.grad is not None
 
 
+class _Ready:
+    """A table that needs no exchange (same interface as the async exchange handles)."""
+
+    def __init__(self, table):
+        self.table = table
+
+    def wait(self):
+        return self.table
+
+
 class NodeLevelAttention(torch.autograd.Function):
     """K1 + K2 for every meta-path: (X_p, graph_p) -> M (N, P, D).
 
@@ -93,14 +103,29 @@ class NodeLevelAttention(torch.autograd.Function):
         # all projections first, each table's all-gather started as soon as it exists:
         # the exchange of meta-path p+1.. overlaps the node attention of meta-path p
         proj = []
+        xs_full = cfg.get("xs_full") if (multi and Xin is None) else None
         for p in range(P):
             seed = int(cfg["seeds"][p])
-            H, f1, f2 = ops.project_fwd(xs[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
-                                        fts_drop=in_drop, seed=seed, row_offset=row_offset,
-                                        table_dtype=cfg.get("table_dtype", torch.float32), seed_dev=seed_dev)
             plan = plans_f[p] if plans_f is not None else None
             handle = None
-            if multi:      # halo rows only (HaloPlan) or the whole shard (all-gather)
+            if xs_full is not None and plan is None:
+                # replicated projection: every rank holds the features of ALL rows and projects the whole
+                # table itself instead of receiving (G-1)/G of it -- a point-to-point xGMI link moves a
+                # 256-B row slower than K1 recomputes it (dist.replication_policy).  Masks are keyed by
+                # global row ids, so the rows are bit-identical to what their owners compute.
+                Hf, f1f, f2f = ops.project_fwd(xs_full[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
+                                               fts_drop=in_drop, seed=seed, row_offset=0,
+                                               table_dtype=cfg.get("table_dtype", torch.float32),
+                                               seed_dev=seed_dev)
+                r0, r1 = part.row_start, part.row_end
+                H, f1, f2 = Hf[r0:r1], f1f[r0:r1], f2f[r0:r1]
+                handle = _Ready(Hf)
+            else:
+                H, f1, f2 = ops.project_fwd(xs[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
+                                            fts_drop=in_drop, seed=seed, row_offset=row_offset,
+                                            table_dtype=cfg.get("table_dtype", torch.float32),
+                                            seed_dev=seed_dev)
+            if multi and handle is None:      # halo rows only (HaloPlan) or the whole shard (all-gather)
                 tag = ("f", cfg.get("layer", 0), cfg.get("group", 0), p)   # persistent exchange table of this (layer, head group, meta-path)
                 handle = plan.exchange_async(H, tag) if plan is not None else part.all_gather_rows_async(H, tag)
             if cfg.get("coef_sink") is not None:

@@ -197,6 +197,20 @@ def make_graph(spec, n, seed, device, rows=None):
     raise ValueError(kind)
 
 
+def features(name: str, device="cpu", n_override: int | None = None, rows=None) -> torch.Tensor:
+    """The feature rows of make_workload alone (same block generators): what a rank of a node partition
+    generates when it wants the features of ALL rows for the replicated projection."""
+    cfg = CONFIGS[name]
+    n = int(n_override) if n_override else cfg["n"]
+    r0, r1 = _row_range(n, rows)
+    xs = []
+    for b, lo, hi in _blocks(r0, r1):
+        nb_rows = min(ROW_BLOCK, n - b * ROW_BLOCK)
+        g = _block_generator(7, 0, b, device)
+        xs.append(torch.randn((nb_rows, cfg["f"]), generator=g, device=device, dtype=torch.float32)[lo:hi])
+    return torch.cat(xs) if xs else torch.empty((0, cfg["f"]), device=device)
+
+
 def make_workload(name: str, device="cpu", seed: int = 1234, n_override: int | None = None, rows=None):
     """Returns dict(x (N,F) fp32, graphs [P CSRGraph], labels int32 (N,),
     train_mask / val_mask uint8 (N,), n, f, c, p).

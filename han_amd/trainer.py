@@ -24,7 +24,7 @@ class HANTrainer:
     def __init__(self, model: HeteGAT_multi, xs, graphs, labels, train_mask, val_mask=None,
                  lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
                  part: NodePartition | None = None, patience=100, max_halo_fraction=0.6,
-                 use_graph=False, graphs_local=False):
+                 use_graph=False, graphs_local=False, xs_full=None, replicate="auto"):
         """xs: list of P (N_local,F) feature tensors (this rank's rows);
         graphs: list of P CSRGraph (or dense masks / CSR tuples).  Under a partition (`part`) either
         the GLOBAL graphs (graphs_local=False: each rank keeps its row block; small data sets) or --
@@ -36,7 +36,11 @@ class HANTrainer:
         hipGraph on its second call and replay it afterwards -- for the launch-bound small
         graphs (ACM / DBLP sizes).  The per-step dropout seed and Adam's step count then live
         in a 2-word device state that the graph itself advances (han_hip.h "Seeds").
-        Single-process only."""
+        Single-process only.
+        xs_full: under a partition, optionally the features of ALL rows (P tensors (N,F), the same on
+        every rank): the forward passes named by `replicate` ("auto" = dist.replication_policy,
+        "all", "eval", "none") then project the whole table on every rank instead of exchanging it;
+        `xs` may then be None (the local rows are views of xs_full)."""
         if not model._built:
             raise RuntimeError("build the model first (model.build(...))")
         self.model = model
@@ -44,6 +48,24 @@ class HANTrainer:
         self.part = part if (part is not None and part.active) else None
         model.partition = self.part
         dev = model.flat.device
+        self.xs_full, self.replicate = None, frozenset()
+        if xs_full is not None and self.part is not None:
+            from .dist import replication_policy
+            pt = self.part
+            if any(x.shape[0] != pt.n_global for x in xs_full):
+                raise ValueError("xs_full must hold the features of all %d rows" % pt.n_global)
+            if xs is None:
+                xs = [x[pt.row_start:pt.row_end] for x in xs_full]
+            # the exchanged tables have world * shard rows (the last shard may be short): pad once
+            pad = {}
+            for x in xs_full:      # the P meta-paths usually share one feature tensor
+                if id(x) not in pad:
+                    xc = x.contiguous()
+                    if pt.n_table != pt.n_global:
+                        xc = torch.cat([xc, xc.new_zeros((pt.n_table - pt.n_global, xc.shape[1]))])
+                    pad[id(x)] = xc
+            self.xs_full = tuple(pad[id(x)] for x in xs_full)
+            self.replicate = replication_policy(pt.world, replicate)
         self.xs = [x.contiguous() for x in xs]
         graphs = [as_graph(g, dev) for g in graphs]     # dense masks / (rowptr, colidx) accepted
         if self.part is not None:
@@ -97,7 +119,8 @@ class HANTrainer:
         with torch.set_grad_enabled(train):
             M = m.node_level(self.xs, self.graphs, self.attn_drop if train else 0.0,
                              self.ffd_drop if train else 0.0, train, ops.ACT_ELU,
-                             graphs_t=self.graphs_t)
+                             graphs_t=self.graphs_t,
+                             xs_full=self.xs_full if ("train" if train else "eval") in self.replicate else None)
             Z, _ = m.semantic(M)
             loss, acc, _ = m.classifier_loss(Z, self.labels, mask, weight)
         return loss, acc

@@ -75,8 +75,12 @@ def run(rank, world, device, epochs, drop, out_path, port, use_cpu_backend):
         from han_amd.dist import _row_block
         graphs = [_row_block(g, part.row_start, part.row_end, n) for g in graphs]
     # HAN_TEST_ALLGATHER=1: a negative halo threshold sends every meta-path down the all-gather path
+    # HAN_TEST_REPLICATE=all|eval|auto: every rank holds the features of all rows and projects the whole
+    # table itself in the named forward passes instead of exchanging it
+    rep = os.environ.get("HAN_TEST_REPLICATE")
     tr = HANTrainer(model, [loc(x)] * p, graphs, loc(labels), loc(tm), loc(vm), attn_drop=drop,
                     ffd_drop=drop, part=part, graphs_local=local,
+                    xs_full=[x] * p if (rep and part is not None) else None, replicate=rep or "auto",
                     max_halo_fraction=-1.0 if os.environ.get("HAN_TEST_ALLGATHER") == "1" else 0.6)
     hist = []
     for _ in range(epochs):
@@ -84,7 +88,8 @@ def run(rank, world, device, epochs, drop, out_path, port, use_cpu_backend):
     if rank == 0:
         pf, pb = model.halo_plans
         halo = 0 if pf is None else sum(x is not None for x in pf) + sum(x is not None for x in pb)
-        np.savez(out_path, flat=model.flat.detach().cpu().numpy(), hist=np.array(hist), halo_plans=halo)
+        np.savez(out_path, flat=model.flat.detach().cpu().numpy(), hist=np.array(hist), halo_plans=halo,
+                 replicate=",".join(sorted(tr.replicate)))
     if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()

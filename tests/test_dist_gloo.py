@@ -105,3 +105,35 @@ def test_two_gloo_ranks_local_rows_halo_weighted(tmp_path):
     assert int(b["halo_plans"]) == 4
     assert np.abs(a["flat"] - b["flat"]).max() < 1e-5
     assert np.abs(a["hist"] - b["hist"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("world,mode,bf16,port", [(2, "all", "0", 29821), (4, "auto", "0", 29831),
+                                                    (8, "auto", "1", 29841), (8, "eval", "0", 29851)])
+def test_replicated_projection_matches_single_process(tmp_path, world, mode, bf16, port):
+    """Recompute instead of communicate: every rank holds the features of all N = 257 rows (uneven
+    shards -> the full table is padded to world * shard rows) and projects the whole H table itself in
+    the forward passes the policy names (both up to 4 ranks, the eval forward only at 8), so only the
+    backward [g | stats] table and the gradients travel.  Rank-local graph rows, all-gather path.
+    Dropout masks are keyed by global row ids, hence the same epochs as a single process."""
+    one, many = str(tmp_path / "one.npz"), str(tmp_path / "many.npz")
+    env = {"OMP_NUM_THREADS": "1", "HAN_TEST_ALLGATHER": "1", "HAN_TEST_LOCAL": "1", "HAN_TEST_BF16": bf16}
+    _launch(1, 2, 0.6, one, port, env)
+    _launch(world, 2, 0.6, many, port + 2, dict(env, HAN_TEST_REPLICATE=mode))
+    a, b = np.load(one), np.load(many)
+    assert str(b["replicate"]) == ("eval,train" if (mode == "all" or (mode == "auto" and world <= 4)) else "eval")
+    tol = 1e-5 if bf16 == "0" else 2e-4
+    assert np.abs(a["flat"] - b["flat"]).max() < tol
+    assert np.abs(a["hist"] - b["hist"]).max() < tol
+
+
+def test_replicated_projection_keeps_halo_plans(tmp_path):
+    """A meta-path with locality keeps its halo exchange (a few boundary rows are cheaper to receive than
+    a whole table is to project); the others are projected in full."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    env = {"OMP_NUM_THREADS": "1"}
+    _launch(1, 2, 0.6, one, 29861, env)
+    _launch(8, 2, 0.6, two, 29863, dict(env, HAN_TEST_REPLICATE="all"))
+    a, b = np.load(one), np.load(two)
+    assert 0 < int(b["halo_plans"]) < 4
+    assert np.abs(a["flat"] - b["flat"]).max() < 1e-5
+    assert np.abs(a["hist"] - b["hist"]).max() < 1e-5

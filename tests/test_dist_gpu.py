@@ -81,3 +81,20 @@ def test_local_rows_all_gather_two_ranks_real_kernels(dev, tmp_path, bf16):
     tol = 2e-5 if bf16 == "0" else 5e-4
     assert np.abs(a["flat"] - b["flat"]).max() < tol
     assert np.abs(a["hist"] - b["hist"]).max() < tol
+
+
+@pytest.mark.parametrize("mode,bf16", [("all", "0"), ("eval", "0"), ("all", "1")])
+def test_replicated_projection_two_ranks_real_kernels(dev, tmp_path, mode, bf16):
+    """Recompute instead of communicate, on the real kernels: both ranks hold the features of all
+    257 rows (uneven shards: the table is padded to world * shard rows) and project the whole H table
+    themselves in the forward passes named by `mode`; K2 reads that table, the backward works on the
+    local row slice of it; only [g | stats] and the gradients travel.  Equals the single-process run."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    env = {"HAN_TEST_ALLGATHER": "1", "HAN_TEST_LOCAL": "1", "HAN_TEST_BF16": bf16}
+    _launch(1, 3, 0.6, one, 29651, env)
+    _launch(2, 3, 0.6, two, 29653, dict(env, HAN_TEST_REPLICATE=mode))
+    a, b = np.load(one), np.load(two)
+    assert str(b["replicate"]) == ("eval,train" if mode == "all" else "eval")
+    tol = 2e-5 if bf16 == "0" else 5e-4
+    assert np.abs(a["flat"] - b["flat"]).max() < tol
+    assert np.abs(a["hist"] - b["hist"]).max() < tol
