@@ -317,6 +317,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # a tree without the built library (a fresh checkout: the .so is git-ignored): compile it once,
+    # before anything touches the GPU -- local rank 0 builds, the others wait for the file
+    from han_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        if local_rank == 0:
+            _lib.build()
+        t_wait = time.time()
+        while not os.path.exists(_lib.LIB_PATH):
+            if time.time() - t_wait > 600:
+                raise SystemExit(f"{_lib.LIB_PATH} was not built")
+            time.sleep(1.0)
     # HAN_SHARE_GPU=1 + HAN_DIST_BACKEND=gloo: rehearse the N-rank partition with all ranks on
     # GPU 0 of a one-GPU box (collectives staged through the host; timings are meaningless)
     if os.environ.get("HAN_SHARE_GPU") == "1":
