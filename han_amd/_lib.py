@@ -99,7 +99,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs):
-        run(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs)
+        tmp = f"{LIB_PATH}.{os.getpid()}.tmp"      # link aside, then rename: a waiting process never sees a partial file
+        run(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + objs)
+        os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
