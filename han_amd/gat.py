@@ -49,9 +49,18 @@ def _pad_width(d: int) -> int:
     return GROUP * ((d + GROUP - 1) // GROUP)
 
 
+def _kernel_head_width(FP: int) -> int:
+    """The lane-mapped head width the K1/K2 kernels run a head of width FP at: the next of 4, 8, 16, 32, 64
+    (the extra columns carry zero weights: their scores terms and outputs are exactly 0 and are cut off)."""
+    for w in FP_SIZES:
+        if FP <= w:
+            return w
+    raise NotImplementedError(f"hid_units entries above {FP_SIZES[-1]} (got {FP})")
+
+
 def _head_groups(K: int, FP: int):
-    """Heads [k0, k1) per kernel launch group: 64 // FP heads (64 columns) each; the last group may be short."""
-    kg = GROUP // FP
+    """Heads [k0, k1) per kernel launch group: 64 // (kernel head width) heads each; the last group may be short."""
+    kg = GROUP // _kernel_head_width(FP)
     return [(k0, min(k0 + kg, K)) for k0 in range(0, K, kg)]
 
 
@@ -121,8 +130,8 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
             # any number of heads; head widths are the lane-mapped sizes of the K2 kernels; a layer's
             # concatenated width K*F' is served in 64-column head groups (K1/K2) and, for the last
             # layer, zero-padded to 64 or 128 columns for K3 / the classifier
-            if FPi not in FP_SIZES or Ki < 1:
-                raise NotImplementedError(f"hid_units entries must be one of {FP_SIZES} (got {FPi}) with n_heads >= 1")
+            if not (1 <= FPi <= FP_SIZES[-1]) or Ki < 1:
+                raise NotImplementedError(f"hid_units entries must be in [1, {FP_SIZES[-1]}] (got {FPi}) with n_heads >= 1")
         k_last, fp_last = ([(K, FP)] + self.extra)[-1]
         if k_last * fp_last > MAX_WIDTH:
             raise NotImplementedError(f"the last layer's n_heads * hid_units = {k_last * fp_last} exceeds "
@@ -290,18 +299,19 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
             if len(groups) == 1 and K * FP == GROUP:      # the reference shapes: no slicing, direct gradients
                 return layers.NodeLevelAttention.apply(Xin, W, a1, b1, a2, b2, c, Wr, br, xs_, tuple(graphs),
                                                        cfg(layer, sd, coef_sink=sink, coef_mean=True))
-            kg = GROUP // FP
+            FPk = _kernel_head_width(FP)          # head width the kernels run at (zero-weight columns beyond FP)
+            kg = GROUP // FPk
             outs, coef_acc = [], None
             for gi, (k0, k1) in enumerate(groups):
                 nh, cols = k1 - k0, slice(k0 * FP, k1 * FP)
-                padc = GROUP - nh * FP
 
-                def pc(t):            # pad the column (last) axis to 64
-                    return F_torch.pad(t[..., cols], (0, padc)).contiguous()
+                def pc(t):            # (..., K*FP) columns of this group -> (..., kg heads x FPk) = 64 columns
+                    t = t[..., cols].reshape(t.shape[:-1] + (nh, FP))
+                    return F_torch.pad(t, (0, FPk - FP, 0, kg - nh)).reshape(t.shape[:-2] + (GROUP,)).contiguous()
 
-                def ph(t, per_head):  # pad the head axis (dim 1) to kg heads
+                def ph(t, per_head):  # (P,K,FP) / (P,K) -> (P,kg,FPk) / (P,kg)
                     t = t[:, k0:k1]
-                    pad = (0, 0, 0, kg - nh) if per_head else (0, kg - nh)
+                    pad = (0, FPk - FP, 0, kg - nh) if per_head else (0, kg - nh)
                     return F_torch.pad(t, pad).contiguous()
                 gsink = [] if sink is not None else None
                 Mg = layers.NodeLevelAttention.apply(
@@ -309,7 +319,8 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
                     pc(Wr) if Wr is not None else None, pc(br) if br is not None else None, xs_, tuple(graphs),
                     cfg(layer, tuple((s_ + gi) & ((1 << 64) - 1) for s_ in sd), coef_sink=gsink, coef_mean=False,
                         group=gi))
-                outs.append(Mg[:, :, :nh * FP])
+                outs.append(Mg.reshape(Mg.shape[0], Mg.shape[1], kg, FPk)[:, :, :nh, :FP]
+                            .reshape(Mg.shape[0], Mg.shape[1], nh * FP))
                 if sink is not None:      # (E, kg) per meta-path -> sum over the real heads
                     part = [v[:, :nh].sum(1) for v in gsink]
                     coef_acc = part if coef_acc is None else [x + y for x, y in zip(coef_acc, part)]

@@ -343,12 +343,14 @@ def _squeeze_batch(seq: torch.Tensor, name="seq") -> torch.Tensor:
 
 def _single_head(seq, out_sz, graph, activation, in_drop, coef_drop, residual, params, training,
                  seed, return_coef=False):
-    """One head of width out_sz through the D=64 kernels: the head occupies
-    slot 0 of K = 64/out_sz head slots, the other slots have zero weights."""
+    """One head of width out_sz through the D=64 kernels: the head occupies slot 0 of K = 64/F'k head
+    slots of the lane-mapped width F'k = next of 4, 8, 16, 32, 64 >= out_sz; the columns beyond out_sz
+    and the other slots have zero weights."""
     x = _squeeze_batch(seq)
-    if out_sz not in (4, 8, 16, 32, 64):
-        raise NotImplementedError("out_sz must be one of 4, 8, 16, 32, 64 in this build")
-    K = D // out_sz
+    if not (1 <= out_sz <= D):
+        raise NotImplementedError(f"out_sz must be in [1, {D}] in this build")
+    fpk = next(w for w in (4, 8, 16, 32, 64) if out_sz <= w)
+    K = D // fpk
     dev = x.device
     Fin = x.shape[1]
 
@@ -358,8 +360,8 @@ def _single_head(seq, out_sz, graph, activation, in_drop, coef_drop, residual, p
         return out
 
     W = pad_last(params["W"], D)[None]                                   # (1,F,D)
-    a1 = torch.cat([params["a1"][None], x.new_zeros(K - 1, out_sz)])[None]   # (1,K,F')
-    a2 = torch.cat([params["a2"][None], x.new_zeros(K - 1, out_sz)])[None]
+    a1 = torch.cat([pad_last(params["a1"], fpk)[None], x.new_zeros(K - 1, fpk)])[None]   # (1,K,F'k)
+    a2 = torch.cat([pad_last(params["a2"], fpk)[None], x.new_zeros(K - 1, fpk)])[None]
     b1 = pad_last(params["b1"].reshape(1), K)[None]
     b2 = pad_last(params["b2"].reshape(1), K)[None]
     c = pad_last(params["c"], D)[None]

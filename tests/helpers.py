@@ -85,18 +85,22 @@ def rel_err(a, b):
 
 
 def group_masks(seed, n, f, K, FP, rowptr, colidx, drop, row_offset=0):
-    """The dropout masks the kernels draw for a layer of K heads of width FP (han_amd.gat.node_level): the
-    heads run in groups of 64 // FP (64 columns per K1/K2 launch); group g uses seed + g and a head's RNG
-    key is its index INSIDE the group.  Returns the oracle's mask dict: seq (K,N,F), coef (E,K), fts (N,K*FP)."""
+    """The dropout masks the kernels draw for a layer of K heads of width FP (han_amd.gat.node_level): a
+    head runs at the kernel width FPk = next of 4/8/16/32/64 (zero-weight columns beyond FP), the heads in
+    groups of 64 // FPk (64 columns per K1/K2 launch); group g uses seed + g, a head's RNG key is its index
+    INSIDE the group and a column's key its position in the 64-column group layout.
+    Returns the oracle's mask dict: seq (K,N,F), coef (E,K), fts (N,K*FP)."""
     import torch
     from tests import rng_ref
-    kg = 64 // FP
+    FPk = next(w for w in (4, 8, 16, 32, 64) if FP <= w)
+    kg = 64 // FPk
     seq, coef, fts = [], [], []
     for g0 in range(0, K, kg):
         nh = min(kg, K - g0)
         sd = (int(seed) + g0 // kg) & ((1 << 64) - 1)
         seq.append(rng_ref.seq_mask(sd, n, f, kg, drop, row_offset)[:nh])
         coef.append(rng_ref.coef_mask_csr(sd, rowptr, colidx, kg, drop, row_offset)[:, :nh])
-        fts.append(rng_ref.fts_mask(sd, n, 64, drop, row_offset)[:, :nh * FP])
+        m = rng_ref.fts_mask(sd, n, 64, drop, row_offset).reshape(n, kg, FPk)[:, :nh, :FP]
+        fts.append(m.reshape(n, nh * FP))
     return {"seq": torch.tensor(np.concatenate(seq, 0)), "coef": torch.tensor(np.concatenate(coef, 1)),
             "fts": torch.tensor(np.concatenate(fts, 1))}

@@ -435,7 +435,10 @@ def test_dropout_statistics(dev):
 
 @pytest.mark.parametrize("K,FP,A", [(16, 4, 128), (4, 16, 128), (2, 32, 128), (1, 64, 128),      # K*F' = 64
                                     (8, 16, 128), (4, 8, 128), (3, 8, 48), (12, 8, 80), (5, 16, 64),  # 128, 32, 24, 96, 80
-                                    (1, 4, 16), (2, 64, 128)])                                       # 4, 128
+                                    (1, 4, 16), (2, 64, 128),                                        # 4, 128
+                                    # head widths that are not a lane-mapped size run at the next one (12 -> 16,
+                                    # 20 -> 32, 3 -> 4, 50 -> 64, 10 -> 16) with zero-weight columns
+                                    (5, 12, 128), (3, 20, 64), (2, 3, 32), (1, 50, 100), (10, 10, 128)])
 @pytest.mark.parametrize("drop", [0.0, 0.6])
 def test_other_head_shapes_match_oracle(dev, K, FP, A, drop):
     """hid_units=[F'], n_heads=[K,1] other than 8x8 and mp_att_size other than 128 (models/gat.py:37,42-57
@@ -632,6 +635,14 @@ def test_attn_head_and_sp_attn_head_api(dev):
     with torch.no_grad():
         out_c = layers.attn_head_const_1(x, 8, _t(prob["biases"][0], dev), Fnn.elu, params=params)
     assert np.abs(out_c.cpu().numpy() - ho.attn_head_const_1(prob["x"], head, prob["biases"][0])).max() < TOL
+    # any out_sz up to 64 (layers.py:7 leaves it free): 11 runs at the lane-mapped width 16
+    prob11 = make_problem(6, 50, 9, 1, 3, [0.2], hid_units=[11], n_heads=(2, 1))
+    head11 = prob11["params"]["heads"][0][1]
+    with torch.no_grad():
+        out11 = layers.attn_head(_t(prob11["x"], dev), 11, _t(prob11["biases"][0], dev), Fnn.elu,
+                                 params={k: _t(v, dev) for k, v in head11.items()})
+    assert out11.shape == (1, 50, 11)
+    assert np.abs(out11.cpu().numpy() - ho.attn_head(prob11["x"], head11, prob11["biases"][0])).max() < TOL
 
 
 @pytest.mark.parametrize("drop", [0.0, 0.6])

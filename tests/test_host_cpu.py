@@ -304,8 +304,10 @@ def test_model_variables_and_initialisers():
     assert tuple(m3.W.shape) == (2, 10, 128) and tuple(m3.w_omega.shape) == (128, 48) and tuple(m3.Wc.shape) == (1, 128, 3)
     m4 = HeteGAT_multi().build(2, 10, 3, (8, 8), (12, 4, 1), device="cpu")      # 96 wide, then 32 wide
     assert tuple(m4.W_1.shape) == (2, 96, 32) and tuple(m4.w_omega.shape) == (32, 128)
+    m5 = HeteGAT_multi().build(2, 10, 3, (10,), (4, 1), device="cpu")          # any head width up to 64
+    assert tuple(m5.W.shape) == (2, 10, 40) and tuple(m5.a1.shape) == (2, 4, 10)
     with pytest.raises(NotImplementedError):
-        HeteGAT_multi().build(2, 10, 3, (10,), (4, 1), device="cpu")           # head width not a lane-mapped size
+        HeteGAT_multi().build(2, 10, 3, (65,), (1, 1), device="cpu")           # head wider than the 64-column group
     with pytest.raises(NotImplementedError):
         HeteGAT_multi().build(2, 10, 3, (32,), (8, 1), device="cpu")           # final width 256 > 128
     assert tuple(HeteGAT_multi().build(2, 10, 40, device="cpu").Wc.shape) == (1, 64, 40)   # up to 64 classes
@@ -574,11 +576,13 @@ def test_arbitrary_activation_callable_on_cpu_backend(cpu_ops):
         assert np.abs(Z.numpy() - fe_ref).max() < 1e-5
 
 
-@pytest.mark.parametrize("K,FP,A", [(8, 16, 128), (4, 8, 128), (3, 8, 48), (12, 8, 80)])
+@pytest.mark.parametrize("K,FP,A", [(8, 16, 128), (4, 8, 128), (3, 8, 48), (12, 8, 80),
+                                    (5, 12, 128), (3, 20, 64), (2, 3, 32), (1, 50, 100)])
 @pytest.mark.parametrize("drop", [0.0, 0.6])
 def test_general_head_widths_on_cpu_backend(cpu_ops, K, FP, A, drop):
     """Host logic of the widths other than 8 x 8 (han_amd.gat.node_level / semantic / classifier_loss): head
-    groups of 64 columns with seed + g, zero-weight completion heads, zero-padded K3 / classifier operands --
+    groups of 64 columns with seed + g, zero-weight completion heads, head widths that are not a lane-mapped
+    size (12, 20, 3, 50: run at 16, 32, 4, 64 with zero-weight columns), zero-padded K3 / classifier operands --
     loss and every gradient against float64 autograd of the oracle with the same hash masks."""
     from han_amd import ops, rng as hrng
     from han_amd.gat import HeteGAT_multi
