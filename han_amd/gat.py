@@ -40,13 +40,7 @@ class _ClassOrInstance:
 
 
 GROUP = ops.D        # the K1 / K2 kernels process heads in groups whose concatenated width is 64 columns
-MAX_WIDTH = 128      # widest concatenated layer output (K * F') the K3 / classifier kernels take
 FP_SIZES = (4, 8, 16, 32, 64)
-
-
-def _pad_width(d: int) -> int:
-    """Embedding width as the K3 / classifier kernels see it: zero-padded to 64 or 128 columns."""
-    return GROUP * ((d + GROUP - 1) // GROUP)
 
 
 def _kernel_head_width(FP: int) -> int:
@@ -132,10 +126,6 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
             # layer, zero-padded to 64 or 128 columns for K3 / the classifier
             if not (1 <= FPi <= FP_SIZES[-1]) or Ki < 1:
                 raise NotImplementedError(f"hid_units entries must be in [1, {FP_SIZES[-1]}] (got {FPi}) with n_heads >= 1")
-        k_last, fp_last = ([(K, FP)] + self.extra)[-1]
-        if k_last * fp_last > MAX_WIDTH:
-            raise NotImplementedError(f"the last layer's n_heads * hid_units = {k_last * fp_last} exceeds "
-                                      f"{MAX_WIDTH} columns")
         if not (1 <= mp_att_size <= 128):
             raise NotImplementedError("mp_att_size must be in [1, 128] in this build")
         if not (1 <= nb_classes <= 64):
@@ -335,35 +325,17 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
 
     def semantic(self, M):
         """models/gat.py:61-63: SimpleAttLayer over the stacked meta-path embeddings M (N,P,D_out) ->
-        (final_embed (N,D_out), att_val (N,P)).  K3 takes 64- or 128-wide rows and a 64- or 128-wide
-        attention space: other sizes are zero-padded (padded columns of w_omega / u_omega contribute
-        tanh(.) * 0 = 0 to the scores and the padded embedding columns are 0), which is exact."""
-        d, a = M.shape[2], self.A
-        dm, am = _pad_width(d), (64 if a <= 64 else 128)
-        if dm == d and am == a:
-            return layers.SemanticAttention.apply(M, self.w_omega, self.b_omega, self.u_omega)
-        Z, att = layers.SemanticAttention.apply(
-            F_torch.pad(M, (0, dm - d)), F_torch.pad(self.w_omega, (0, am - a, 0, dm - d)),
-            F_torch.pad(self.b_omega, (0, am - a)), F_torch.pad(self.u_omega, (0, am - a)))
-        return Z[:, :d], att
-
-    def _padded_classifier(self, Z):
-        d = Z.shape[1]
-        dm = _pad_width(d)
-        if dm == d:
-            return Z, self.Wc
-        return F_torch.pad(Z, (0, dm - d)), F_torch.pad(self.Wc, (0, 0, 0, dm - d))
+        (final_embed (N,D_out), att_val (N,P)); any width (layers.semantic_attention)."""
+        return layers.semantic_attention(M, self.w_omega, self.b_omega, self.u_omega)
 
     def classify(self, Z):
         """models/gat.py:65-72: logits (N,C) = mean over the output heads of Z Wc[h] + bc[h]."""
-        Zp, Wp = self._padded_classifier(Z)
-        return layers.classifier(Zp, Wp, self.bc)
+        return layers.classifier_any(Z, self.Wc, self.bc)
 
     def classifier_loss(self, Z, labels, mask, weight):
         """Fused classifier + masked softmax cross-entropy + accuracy (the trainer's step):
         returns (loss, accuracy, logits)."""
-        Zp, Wp = self._padded_classifier(Z)
-        return layers.ClassifierLoss.apply(Zp, Wp, self.bc, labels, mask, weight)
+        return layers.classifier_loss_any(Z, self.Wc, self.bc, labels, mask, weight)
 
     @_ClassOrInstance
     def inference(self, inputs_list, nb_classes, nb_nodes, training, attn_drop, ffd_drop,

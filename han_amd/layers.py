@@ -327,6 +327,70 @@ def classifier(Z, Wc, bc):
     return _ClassifierForward.apply(Z, Wc, bc)
 
 
+K3_WIDTHS = (64, 128)      # embedding widths (and attention sizes) the K3 / classifier kernels are built for
+
+
+def _pad_to(n: int) -> int:
+    return 64 * ((n + 63) // 64)
+
+
+def semantic_attention(M, w_omega, b_omega, u_omega):
+    """utils/layers.py:152-159 for any embedding width D and attention size A <= 128.
+    D, A in {64, 128}: the K3 kernels as they are.  Narrower: zero-padded -- padded columns of
+    w_omega / u_omega contribute tanh(.) * 0 = 0 to the scores and padded embedding columns are 0 --
+    which is exact.  D > 128 (a last layer wider than the kernels, e.g. 8 heads x 32): the same
+    arithmetic through torch on the GPU (library GEMM + elementwise, autograd); off the tuned path."""
+    d, a = M.shape[2], w_omega.shape[1]
+    if a > K3_WIDTHS[-1]:
+        raise NotImplementedError(f"attention size {a} > {K3_WIDTHS[-1]}")
+    if d > K3_WIDTHS[-1]:
+        ops.require_gpu(M, "inputs")
+        v = torch.tanh(torch.matmul(M, w_omega) + b_omega)
+        att = torch.softmax(torch.matmul(v, u_omega), dim=1)
+        return (M * att.unsqueeze(-1)).sum(1), att
+    dm, am = _pad_to(d), _pad_to(a)
+    if dm == d and am == a:
+        return SemanticAttention.apply(M.contiguous(), w_omega, b_omega, u_omega)
+    Z, att = SemanticAttention.apply(
+        torch.nn.functional.pad(M, (0, dm - d)), torch.nn.functional.pad(w_omega, (0, am - a, 0, dm - d)),
+        torch.nn.functional.pad(b_omega, (0, am - a)), torch.nn.functional.pad(u_omega, (0, am - a)))
+    return Z[:, :d], att
+
+
+def _wide_logits(Z, Wc, bc):
+    ops.require_gpu(Z, "Z")
+    return torch.matmul(Z, Wc.mean(0)) + bc.mean(0)          # (1/HC) sum_h (Z Wc[h] + bc[h]), models/gat.py:65-72
+
+
+def classifier_any(Z, Wc, bc):
+    """models/gat.py:65-72 for any embedding width: the kernel (zero-padded to 64 / 128 columns) or,
+    above 128, torch on the GPU."""
+    d = Z.shape[1]
+    if d > K3_WIDTHS[-1]:
+        return _wide_logits(Z, Wc, bc)
+    dm = _pad_to(d)
+    if dm != d:
+        Z, Wc = torch.nn.functional.pad(Z, (0, dm - d)), torch.nn.functional.pad(Wc, (0, 0, 0, dm - d))
+    return classifier(Z, Wc, bc)
+
+
+def classifier_loss_any(Z, Wc, bc, labels, mask, weight):
+    """Classifier + masked softmax cross-entropy + accuracy (models/base_gattn.py:41-48,61-69) for any
+    embedding width; returns (loss, accuracy, logits)."""
+    d = Z.shape[1]
+    if d > K3_WIDTHS[-1]:
+        logits = _wide_logits(Z, Wc, bc)
+        m = mask.to(logits.dtype)
+        ce = torch.nn.functional.cross_entropy(logits, labels.long(), reduction="none")
+        loss = (ce * m).sum() * weight
+        acc = ((logits.argmax(1) == labels.long()).to(logits.dtype) * m).sum() * weight
+        return loss, acc.detach(), logits.detach()
+    dm = _pad_to(d)
+    if dm != d:
+        Z, Wc = torch.nn.functional.pad(Z, (0, dm - d)), torch.nn.functional.pad(Wc, (0, 0, 0, dm - d))
+    return ClassifierLoss.apply(Z, Wc, bc, labels, mask, weight)
+
+
 # ---------------------------------------------------------------------------
 # reference-named functional API
 # ---------------------------------------------------------------------------
@@ -440,8 +504,8 @@ def SimpleAttLayer(inputs, attention_size, time_major=False, return_alphas=False
         inputs = inputs.transpose(0, 1)                  # :138-140
     if params["w_omega"].shape != (inputs.shape[2], attention_size):
         raise ValueError("w_omega must be (hidden_size, attention_size)")
-    out, alphas = SemanticAttention.apply(inputs.contiguous(), params["w_omega"],
-                                          params["b_omega"], params["u_omega"])
+    out, alphas = semantic_attention(inputs.contiguous(), params["w_omega"], params["b_omega"],
+                                     params["u_omega"])
     if not return_alphas:
         return out
     return out, alphas

@@ -66,6 +66,13 @@ def _ws(nbytes: int, device, tag: str = "") -> torch.Tensor:
     return t
 
 
+def require_gpu(t: torch.Tensor, name: str) -> torch.Tensor:
+    """Guard of the (few) torch-level paths around the kernels: no CPU path there either."""
+    if not t.is_cuda:
+        raise ValueError(f"{name}: must be a GPU tensor (han_amd has no CPU path); got {t.device}")
+    return t
+
+
 def _chk(t: torch.Tensor, name: str, shape=None, dtype=torch.float32, device=None, contiguous=True):
     if not isinstance(t, torch.Tensor):
         raise ValueError(f"{name}: expected a tensor, got {type(t)}")

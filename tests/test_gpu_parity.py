@@ -438,7 +438,9 @@ def test_dropout_statistics(dev):
                                     (1, 4, 16), (2, 64, 128),                                        # 4, 128
                                     # head widths that are not a lane-mapped size run at the next one (12 -> 16,
                                     # 20 -> 32, 3 -> 4, 50 -> 64, 10 -> 16) with zero-weight columns
-                                    (5, 12, 128), (3, 20, 64), (2, 3, 32), (1, 50, 100), (10, 10, 128)])
+                                    (5, 12, 128), (3, 20, 64), (2, 3, 32), (1, 50, 100), (10, 10, 128),
+                                    # a last layer wider than the K3 / classifier kernels (256, 192 columns)
+                                    (8, 32, 128), (3, 64, 40)])
 @pytest.mark.parametrize("drop", [0.0, 0.6])
 def test_other_head_shapes_match_oracle(dev, K, FP, A, drop):
     """hid_units=[F'], n_heads=[K,1] other than 8x8 and mp_att_size other than 128 (models/gat.py:37,42-57

@@ -308,8 +308,8 @@ def test_model_variables_and_initialisers():
     assert tuple(m5.W.shape) == (2, 10, 40) and tuple(m5.a1.shape) == (2, 4, 10)
     with pytest.raises(NotImplementedError):
         HeteGAT_multi().build(2, 10, 3, (65,), (1, 1), device="cpu")           # head wider than the 64-column group
-    with pytest.raises(NotImplementedError):
-        HeteGAT_multi().build(2, 10, 3, (32,), (8, 1), device="cpu")           # final width 256 > 128
+    m6 = HeteGAT_multi().build(2, 10, 3, (32,), (8, 1), device="cpu")          # final width 256: K3 / classifier via torch
+    assert tuple(m6.w_omega.shape) == (256, 128) and tuple(m6.Wc.shape) == (1, 256, 3)
     assert tuple(HeteGAT_multi().build(2, 10, 40, device="cpu").Wc.shape) == (1, 64, 40)   # up to 64 classes
     with pytest.raises(NotImplementedError):
         HeteGAT_multi().build(2, 10, 65, device="cpu")
@@ -577,7 +577,8 @@ def test_arbitrary_activation_callable_on_cpu_backend(cpu_ops):
 
 
 @pytest.mark.parametrize("K,FP,A", [(8, 16, 128), (4, 8, 128), (3, 8, 48), (12, 8, 80),
-                                    (5, 12, 128), (3, 20, 64), (2, 3, 32), (1, 50, 100)])
+                                    (5, 12, 128), (3, 20, 64), (2, 3, 32), (1, 50, 100),
+                                    (8, 32, 128), (3, 64, 40)])        # 256 / 192 wide: above the K3 kernels
 @pytest.mark.parametrize("drop", [0.0, 0.6])
 def test_general_head_widths_on_cpu_backend(cpu_ops, K, FP, A, drop):
     """Host logic of the widths other than 8 x 8 (han_amd.gat.node_level / semantic / classifier_loss): head
