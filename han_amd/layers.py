@@ -328,6 +328,7 @@ def classifier(Z, Wc, bc):
 
 
 K3_WIDTHS = (64, 128)      # embedding widths (and attention sizes) the K3 / classifier kernels are built for
+MAX_CLASSES = 64           # classes the classifier kernels take
 
 
 def _pad_to(n: int) -> int:
@@ -338,12 +339,10 @@ def semantic_attention(M, w_omega, b_omega, u_omega):
     """utils/layers.py:152-159 for any embedding width D and attention size A <= 128.
     D, A in {64, 128}: the K3 kernels as they are.  Narrower: zero-padded -- padded columns of
     w_omega / u_omega contribute tanh(.) * 0 = 0 to the scores and padded embedding columns are 0 --
-    which is exact.  D > 128 (a last layer wider than the kernels, e.g. 8 heads x 32): the same
-    arithmetic through torch on the GPU (library GEMM + elementwise, autograd); off the tuned path."""
+    which is exact.  D > 128 (a last layer wider than the kernels, e.g. 8 heads x 32) or A > 128: the
+    same arithmetic through torch on the GPU (library GEMM + elementwise, autograd); off the tuned path."""
     d, a = M.shape[2], w_omega.shape[1]
-    if a > K3_WIDTHS[-1]:
-        raise NotImplementedError(f"attention size {a} > {K3_WIDTHS[-1]}")
-    if d > K3_WIDTHS[-1]:
+    if d > K3_WIDTHS[-1] or a > K3_WIDTHS[-1]:
         ops.require_gpu(M, "inputs")
         v = torch.tanh(torch.matmul(M, w_omega) + b_omega)
         att = torch.softmax(torch.matmul(v, u_omega), dim=1)
@@ -366,7 +365,7 @@ def classifier_any(Z, Wc, bc):
     """models/gat.py:65-72 for any embedding width: the kernel (zero-padded to 64 / 128 columns) or,
     above 128, torch on the GPU."""
     d = Z.shape[1]
-    if d > K3_WIDTHS[-1]:
+    if d > K3_WIDTHS[-1] or Wc.shape[2] > MAX_CLASSES:
         return _wide_logits(Z, Wc, bc)
     dm = _pad_to(d)
     if dm != d:
@@ -378,7 +377,7 @@ def classifier_loss_any(Z, Wc, bc, labels, mask, weight):
     """Classifier + masked softmax cross-entropy + accuracy (models/base_gattn.py:41-48,61-69) for any
     embedding width; returns (loss, accuracy, logits)."""
     d = Z.shape[1]
-    if d > K3_WIDTHS[-1]:
+    if d > K3_WIDTHS[-1] or Wc.shape[2] > MAX_CLASSES:
         logits = _wide_logits(Z, Wc, bc)
         m = mask.to(logits.dtype)
         ce = torch.nn.functional.cross_entropy(logits, labels.long(), reduction="none")

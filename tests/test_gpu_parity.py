@@ -440,7 +440,8 @@ def test_dropout_statistics(dev):
                                     # 20 -> 32, 3 -> 4, 50 -> 64, 10 -> 16) with zero-weight columns
                                     (5, 12, 128), (3, 20, 64), (2, 3, 32), (1, 50, 100), (10, 10, 128),
                                     # a last layer wider than the K3 / classifier kernels (256, 192 columns)
-                                    (8, 32, 128), (3, 64, 40)])
+                                    (8, 32, 128), (3, 64, 40),
+                                    (8, 8, 200)])                                                    # mp_att_size above the K3 kernels
 @pytest.mark.parametrize("drop", [0.0, 0.6])
 def test_other_head_shapes_match_oracle(dev, K, FP, A, drop):
     """hid_units=[F'], n_heads=[K,1] other than 8x8 and mp_att_size other than 128 (models/gat.py:37,42-57
@@ -1463,9 +1464,11 @@ def test_locality_pass_is_a_pure_relabelling(dev):
     assert float((g0 - g1).abs().max()) < 1e-4 * max(1.0, float(g0.abs().max()))
 
 
-def test_many_classes_through_the_model(dev):
-    """nb_classes = 30 (models/gat.py:68 leaves it free): inference and loss + gradients against the oracle."""
-    n, f, p, c = 80, 12, 2, 30
+@pytest.mark.parametrize("c", [30, 100])
+def test_many_classes_through_the_model(dev, c):
+    """nb_classes = 30 (models/gat.py:68 leaves it free; the class-per-lane kernel) and 100 (above the
+    classifier kernels: torch on the GPU): inference and loss + gradients against the oracle."""
+    n, f, p = 80, 12, 2
     prob = make_problem(321, n, f, p, c, [0.06, 0.4])
     model, bp = build_model(prob, dev)
     lg, fe, att = ho.hetegat_multi_inference([prob["x"]] * p, c, n, False, 0.0, 0.0, prob["biases"], [8], [8, 1],

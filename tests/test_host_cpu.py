@@ -311,8 +311,7 @@ def test_model_variables_and_initialisers():
     m6 = HeteGAT_multi().build(2, 10, 3, (32,), (8, 1), device="cpu")          # final width 256: K3 / classifier via torch
     assert tuple(m6.w_omega.shape) == (256, 128) and tuple(m6.Wc.shape) == (1, 256, 3)
     assert tuple(HeteGAT_multi().build(2, 10, 40, device="cpu").Wc.shape) == (1, 64, 40)   # up to 64 classes
-    with pytest.raises(NotImplementedError):
-        HeteGAT_multi().build(2, 10, 65, device="cpu")
+    assert tuple(HeteGAT_multi().build(2, 10, 100, mp_att_size=200, device="cpu").w_omega.shape) == (64, 200)
     with pytest.raises(ValueError):
         HeteGAT_multi().build(2, 10, 3, (8, 8), (8, 1), device="cpu")          # n_heads too short
 
@@ -578,7 +577,8 @@ def test_arbitrary_activation_callable_on_cpu_backend(cpu_ops):
 
 @pytest.mark.parametrize("K,FP,A", [(8, 16, 128), (4, 8, 128), (3, 8, 48), (12, 8, 80),
                                     (5, 12, 128), (3, 20, 64), (2, 3, 32), (1, 50, 100),
-                                    (8, 32, 128), (3, 64, 40)])        # 256 / 192 wide: above the K3 kernels
+                                    (8, 32, 128), (3, 64, 40),         # 256 / 192 wide: above the K3 kernels
+                                    (8, 8, 200)])                      # attention size above the K3 kernels
 @pytest.mark.parametrize("drop", [0.0, 0.6])
 def test_general_head_widths_on_cpu_backend(cpu_ops, K, FP, A, drop):
     """Host logic of the widths other than 8 x 8 (han_amd.gat.node_level / semantic / classifier_loss): head
