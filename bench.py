@@ -138,6 +138,67 @@ def static_traffic(workload, world, table_dtype):
     return per, src
 
 
+K2_PMC_NAMES = {"k2_fwd_eval": "node_attn_fwd_kernel<8, false, 1,", "k2_fwd_train": "node_attn_fwd_kernel<8, true, 1,",
+                "k2_bwd_cols": "node_attn_bwd_cols_kernel<8, 1,"}
+
+
+def live_traffic(args, timeout_s=300):
+    """roofline.traffic measured in THIS run: two child runs of this script (one epoch of the same
+    workload, no warm-up) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes with
+    the kernel trace only, as MI355X_MICROARCH.md prescribes -- and bytes per launch = (2 * FETCH_SIZE +
+    WRITE_SIZE) * 1024 (both counters are in KB; gfx950 tallies 128-B fetch requests as 64 B).  Returns
+    ({k2 tag: bytes per launch}, source) or (None, reason)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="han_pmc_", dir="/tmp")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HAN_BENCH_DIAG")}
+    env["TMPDIR"] = "/tmp"
+    vals = collections.defaultdict(lambda: collections.defaultdict(list))
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", c, "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
+                   "--no-cpu-baseline", "--hbm-regime-nodes", "0", "--traffic", "off",
+                   "--workload", args.workload, "--table-dtype", args.table_dtype]
+            if args.nodes:
+                cmd += ["--nodes", str(args.nodes)]
+            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {c} pass failed (rc {r.returncode}): {r.stderr[-300:]}"
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                for tag, sub in K2_PMC_NAMES.items():
+                    if sub in row["Kernel_Name"]:
+                        vals[tag][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    except subprocess.TimeoutExpired:
+        return None, f"rocprofv3 pass exceeded {timeout_s} s"
+    except Exception as e:      # a profiler problem must not cost the bench line
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    per = {}
+    for tag, d in vals.items():
+        if d["FETCH_SIZE"] and d["WRITE_SIZE"]:
+            fetch = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
+            write = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+            per[tag] = int((2 * fetch + write) * 1024)
+    if not per:
+        return None, "no K2 launches in the counter output"
+    n_l = {t: len(vals[t]["FETCH_SIZE"]) for t in per}
+    return per, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, kernel "
+                 f"trace only) around one-epoch child runs of the same workload, mean over {n_l} launches, "
+                 "(2*FETCH_SIZE + WRITE_SIZE)*1024 B with the gfx950 x2 on FETCH_SIZE (MI355X_MICROARCH.md); "
+                 "fabric-side counter: includes Infinity-Cache hits")
+
+
 def hbm_regime_probe(dev, n, table_dtype, steps, warmup=2, deg=50):
     """A second timed K2 launch set in the SAME run on a table far larger than the 256 MiB Infinity Cache
     (N = 10M rows: 2.56 GB fp32 / 1.28 GB bf16), so that bytes / time is a genuine HBM rate."""
@@ -289,6 +350,10 @@ def main():
     ap.add_argument("--replicate", default="auto", choices=["auto", "all", "eval", "none"],
                     help="multi-GPU: which forward passes project the whole H table on every rank instead of "
                          "exchanging it (auto: both up to 4 ranks, the eval forward beyond)")
+    ap.add_argument("--traffic", choices=("live", "static", "off"), default="live",
+                    help="roofline.traffic: live = PMC passes (rocprofv3 child runs of one epoch) in this run, "
+                         "N = 1 on the syn-1m family; static = the committed profiles/k2_traffic.json when it "
+                         "matches the kernel sources; off = null")
     ap.add_argument("--workload", default="syn-1m")
     ap.add_argument("--nodes", type=int, default=0, help="override N (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -446,7 +511,19 @@ def main():
               + ("largely cache-served -- an effective (fabric/cache-path) rate, NOT an HBM fraction; "
                  "see roofline_hbm_regime" if table_mb < 600 else "HBM-served"))
     roofs, dom = k2_rooflines(timing, esz, regime)
-    traffic_per, traffic_src = static_traffic(args.workload, world, args.table_dtype)
+    traffic_per, traffic_src = None, None
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+    if args.traffic == "live" and profiled:
+        args.traffic = "static"      # already running under a profiler: no nested rocprofv3
+    if args.traffic == "live" and rank == 0 and world == 1 and not use_graph and args.workload.startswith("syn-1m"):
+        traffic_per, traffic_src = live_traffic(args)
+        if traffic_per is None:
+            live_err = traffic_src
+            traffic_per, traffic_src = static_traffic(args.workload, world, args.table_dtype)
+            traffic_src = f"{traffic_src} [live PMC collection failed: {live_err}]" if traffic_src else \
+                f"live PMC collection failed: {live_err}"
+    elif args.traffic != "off":
+        traffic_per, traffic_src = static_traffic(args.workload, world, args.table_dtype)
     tkey = {"eval": "k2_fwd_eval", "train": "k2_fwd_train", "bwd_cols": "k2_bwd_cols"}
     for tag, r in roofs.items():
         r["traffic"] = (traffic_per or {}).get(tkey[tag]) if traffic_per else None

@@ -73,7 +73,7 @@ def test_headline_line_carries_traffic_and_both_cpu_baselines():
     d = dict(_lines())["r02_bench_syn1m_f32_1gpu.json"]
     assert d["n_gpus"] == 1 and d["dtype"].startswith("f32")
     r = d["roofline"]
-    assert r["traffic"] and r["traffic_source"]
+    assert r["traffic"] and r["traffic_source"]      # live PMC passes, or the sha-matched committed figure
     # measured fabric bytes within 2 % of the bytes the kernel requests
     assert abs(r["traffic"] / r["moved_bytes_per_launch"] - 1.0) < 0.02
     c = d["cpu_baseline"]

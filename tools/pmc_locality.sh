@@ -4,8 +4,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 WL=${1:-syn-1m-local-shuffled}
 for R in none bfs; do
-  python3 bench.py --workload $WL --reorder $R --steps 5 --warmup 2 --no-cpu-baseline --hbm-regime-nodes 0 > gpurun_out/loc_${WL}_$R.json 2> gpurun_out/loc_${WL}_$R.err || echo "bench $R failed"
-  timeout -k 10 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/pmc_loc_${WL}_$R -o p -- python3 bench.py --workload $WL --reorder $R --steps 2 --warmup 1 --no-cpu-baseline --hbm-regime-nodes 0 > gpurun_out/pmc_loc_${WL}_$R.log 2>&1 || echo "pmc $R failed"
+  python3 bench.py --workload $WL --reorder $R --steps 5 --warmup 2 --no-cpu-baseline --hbm-regime-nodes 0 --traffic static > gpurun_out/loc_${WL}_$R.json 2> gpurun_out/loc_${WL}_$R.err || echo "bench $R failed"
+  timeout -k 10 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/pmc_loc_${WL}_$R -o p -- python3 bench.py --workload $WL --reorder $R --steps 2 --warmup 1 --no-cpu-baseline --hbm-regime-nodes 0 --traffic static > gpurun_out/pmc_loc_${WL}_$R.log 2>&1 || echo "pmc $R failed"
 done
 python3 - <<PY
 import json, os, sys

@@ -4,6 +4,6 @@
 # Usage (GPU box): bash tools/pmc_traffic.sh && python3 tools/pmc_traffic.py
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_traffic -o $c -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --hbm-regime-nodes 0 > gpurun_out/pmc_traffic_$c.log 2>&1 || echo "pass $c failed"
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_traffic -o $c -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --hbm-regime-nodes 0 --traffic static > gpurun_out/pmc_traffic_$c.log 2>&1 || echo "pass $c failed"
 done
 ls gpurun_out/pmc_traffic

@@ -2,7 +2,7 @@
 # Usage (GPU box): bash tools/prof_stats.sh <tag> [bench args...]  -> gpurun_out/prof_<tag>/
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-run}; shift
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o b -- python3 bench.py --no-cpu-baseline --hbm-regime-nodes 0 "$@" > gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o b -- python3 bench.py --no-cpu-baseline --hbm-regime-nodes 0 --traffic static "$@" > gpurun_out/prof_$TAG.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("gpurun_out/prof_$TAG/*kernel_stats.csv")[0]
