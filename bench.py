@@ -142,7 +142,7 @@ K2_PMC_NAMES = {"k2_fwd_eval": "node_attn_fwd_kernel<8, false, 1,", "k2_fwd_trai
                 "k2_bwd_cols": "node_attn_bwd_cols_kernel<8, 1,"}
 
 
-def live_traffic(args, timeout_s=300):
+def live_traffic(args, timeout_s=150):
     """roofline.traffic measured in THIS run: two child runs of this script (one epoch of the same
     workload, no warm-up) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes with
     the kernel trace only, as MI355X_MICROARCH.md prescribes -- and bytes per launch = (2 * FETCH_SIZE +
