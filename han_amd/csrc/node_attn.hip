@@ -1002,8 +1002,8 @@ bool split_ok(const han_row_split_t *sp) {
         default: { constexpr int FPC = 64; __VA_ARGS__; } break; \
     }
 
-// bf16 tables are built for the reference head shape only (8 heads x 8)
-#define HAN_BF16_OK(FPV) ((FPV) == 8)
+// bf16 tables: every head shape (the configs[4] shape 8 x 8 is the tuned one)
+#define HAN_BF16_OK(FPV) (true)
 
 template <int FPC, bool BF, bool VAL>
 static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split, hipStream_t st) {
@@ -1106,7 +1106,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     hipStream_t st = (hipStream_t)stream;
     const bool low = (double)E < kLowDegree * (double)N;
     if (table_dtype == HAN_DTYPE_BF16) {
-        launch_fwd<8, true>(a, train, low, has_split, st);
+        HAN_DISPATCH_FP(FP, { launch_fwd<FPC, true>(a, train, low, has_split, st); })
     } else {
         HAN_DISPATCH_FP(FP, { launch_fwd<FPC, false>(a, train, low, has_split, st); })
     }
@@ -1147,7 +1147,7 @@ extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, co
     a.slab = (float *)workspace; a.N = N; a.activation = activation;
     const int grid = han_grid_for(N, 16, kReduceBlocks);
     if (table_dtype == HAN_DTYPE_BF16) {
-        node_attn_bwd_rows_kernel<8, true><<<grid, 256, 0, st>>>(a);
+        HAN_DISPATCH_FP(FP, { node_attn_bwd_rows_kernel<FPC, true><<<grid, 256, 0, st>>>(a); })
     } else {
         HAN_DISPATCH_FP(FP, { node_attn_bwd_rows_kernel<FPC, false><<<grid, 256, 0, st>>>(a); })
     }
@@ -1192,7 +1192,7 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
     hipStream_t st = (hipStream_t)stream;
     const bool low = (double)E < kLowDegree * (double)NS;
     if (table_dtype == HAN_DTYPE_BF16) {
-        launch_bwd_cols<8, true>(a, low, has_split, st);
+        HAN_DISPATCH_FP(FP, { launch_bwd_cols<FPC, true>(a, low, has_split, st); })
     } else {
         HAN_DISPATCH_FP(FP, { launch_bwd_cols<FPC, false>(a, low, has_split, st); })
     }
@@ -1214,7 +1214,9 @@ extern "C" int han_score_param_bwd(const void *H, int table_dtype, const float *
     hipStream_t st = (hipStream_t)stream;
     const int grid = han_grid_for(N, 16, kReduceBlocks);
     if (table_dtype == HAN_DTYPE_BF16) {
-        score_param_bwd_kernel<8, true><<<grid, 256, 0, st>>>(H, df1, df2, (float *)workspace, N);
+        HAN_DISPATCH_FP(FP, {
+            score_param_bwd_kernel<FPC, true><<<grid, 256, 0, st>>>(H, df1, df2, (float *)workspace, N);
+        })
     } else {
         HAN_DISPATCH_FP(FP, {
             score_param_bwd_kernel<FPC, false><<<grid, 256, 0, st>>>(H, df1, df2, (float *)workspace, N);

@@ -910,7 +910,7 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
         return HAN_E_BADARG;
     if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
     if ((x_dtype != HAN_DTYPE_F32 && x_dtype != HAN_DTYPE_BF16) ||
-        (table_dtype != HAN_DTYPE_F32 && !(table_dtype == HAN_DTYPE_BF16 && FP == 8)))
+        (table_dtype != HAN_DTYPE_F32 && table_dtype != HAN_DTYPE_BF16))
         return HAN_E_UNSUPPORTED;
     if (in_drop < 0.f || in_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
     if (N == 0) return 0;

@@ -153,8 +153,6 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
     K, FP = a1.shape
     if table_dtype not in DTYPE_CODE:
         raise ValueError(f"table_dtype {table_dtype}: expected float32 or bfloat16")
-    if table_dtype == torch.bfloat16 and (K, FP) != (8, 8):
-        raise NotImplementedError("bf16 tables are built for 8 heads x 8 features")
     _check_heads(K, FP)
     _chk(W, "W", (F, D), device=dev)
     _chk(a1, "a1", (K, FP), device=dev)

@@ -44,7 +44,7 @@ extern "C" {
                                   measured 9 % slower in the HBM regime (eight separate index / output streams). */
 
 /* storage type of X and of the gather tables H / g ("bf16 feats" of the 10M-node
- * config): everything is accumulated in fp32; bf16 tables need K == FP == 8      */
+ * config): everything is accumulated in fp32; any head shape (8 x 8 is the tuned one) */
 #define HAN_DTYPE_F32  0
 #define HAN_DTYPE_BF16 1
 

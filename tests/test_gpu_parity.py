@@ -1234,6 +1234,43 @@ def test_bf16_mode_forward_backward(dev, drop, P):
         assert rel_err(got, gref[k]) < (0.2 if k in ("a1", "b1", "b2") else 6e-2), k
 
 
+@pytest.mark.parametrize("K,FP", [(4, 16), (16, 4), (2, 32), (1, 64), (5, 12), (12, 8)])
+@pytest.mark.parametrize("drop", [0.0, 0.6])
+def test_bf16_mode_other_head_shapes(dev, K, FP, drop):
+    """bf16 tables for head shapes other than 8 x 8 (every lane map of K2 and K1's bf16 epilogue, head
+    groups, padded head widths), against the oracle that restates the bf16 storage."""
+    from han_amd import ops, rng as hrng
+    from han_amd.gat import HeteGAT_multi
+    from tests.helpers import load_params
+    n, f, P = 150, 20, 2
+    prob = make_problem(400 + K, n, f, P, 3, [0.05, 0.3], hid_units=[FP], n_heads=(K, 1))
+    xb = torch.tensor(prob["x"][0], dtype=torch.float32).to(torch.bfloat16)
+    prob["x"] = xb.to(torch.float32).numpy().astype(np.float64)[None]
+    bp = ht.to_batched(prob["params"])
+    model = HeteGAT_multi().build(P, f, 3, (FP,), (K, 1), device=dev, table_dtype=torch.bfloat16)
+    load_params(model, bp)
+    masks, keep = None, 1.0
+    hrng.manual_seed(77)
+    if drop > 0:
+        seeds = [hrng.next_seed() for _ in range(P)]
+        hrng.manual_seed(77)
+        keep = rng_ref.keep_prob32(drop)
+        masks = [group_masks(seeds[q], n, f, K, FP, *ho.bias_to_csr(prob["biases"][q]), drop) for q in range(P)]
+    loss_q, gq, lg_q = _oracle_grads(prob, bp, masks=masks, keep=keep, dense=False, table_bf16=True)
+    _, graphs = gpu_inputs(prob, dev)
+    model.zero_grad_flat()
+    M = model.node_level([xb.to(dev)] * P, graphs, drop, drop, True, ops.ACT_ELU)
+    Z, _ = model.semantic(M)
+    loss, acc, logits = model.classifier_loss(Z, _t(prob["labels"], dev, torch.int32),
+                                              _t(prob["mask"].astype(np.uint8), dev, torch.uint8),
+                                              1.0 / int(prob["mask"].sum()))
+    loss.backward()
+    assert rel_err(logits.cpu().numpy(), lg_q) < 2e-3
+    assert abs(float(loss) - loss_q) < 2e-3 * max(1.0, abs(loss_q))
+    for k in ht.PARAM_ORDER:
+        assert rel_err(getattr(model, k).grad.cpu().numpy(), gq[k]) < 1e-2, k
+
+
 def _bf16_to_f64(t):
     return t.to(torch.float32).cpu().numpy().astype(np.float64)
 
