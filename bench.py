@@ -471,6 +471,7 @@ def main():
               ("eval", "train"): "all-gather (backward only); H projected on every rank in both forwards"}[tuple(rep)]
         exchange = ["halo %.1f%% of the remote rows" % (100.0 * pl.halo_fraction) if pl is not None else ag
                     for pl in plans]
+    trainer_replicate_info = trainer.replicate_info
     wl["graphs"] = None
     torch.cuda.synchronize()
 
@@ -557,6 +558,7 @@ def main():
                        "parallelism": f"node-partition x{world}" if world > 1 else
                        ("single GPU, epoch replayed from a hipGraph" if use_graph else "single GPU"),
                        **({"exchange": exchange} if exchange is not None else {}),
+                       **({"replication": trainer_replicate_info} if trainer_replicate_info else {}),
                        **({"reorder": reorder_info} if reorder_info is not None else {}),
                        "dropout": "0.6/0.6 (train step)", "optimizer": "TF-form Adam lr 0.005, L2 0.001"},
             "final": {"train_loss": round(tl, 5), "train_acc": round(ta, 5),

@@ -11,6 +11,8 @@ all-reduce of the flat gradient buffer.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import layers, ops, rng
@@ -48,7 +50,8 @@ class HANTrainer:
         self.part = part if (part is not None and part.active) else None
         model.partition = self.part
         dev = model.flat.device
-        self.xs_full, self.replicate = None, frozenset()
+        self.xs_full, self.replicate, self.replicate_info = None, frozenset(), None
+        self._replicate_arg = replicate
         if xs_full is not None and self.part is not None:
             from .dist import replication_policy
             pt = self.part
@@ -66,6 +69,7 @@ class HANTrainer:
                     pad[id(x)] = xc
             self.xs_full = tuple(pad[id(x)] for x in xs_full)
             self.replicate = replication_policy(pt.world, replicate)
+            self.replicate_info = {"policy": "static (han_amd.dist.replication_policy)"}
         self.xs = [x.contiguous() for x in xs]
         graphs = [as_graph(g, dev) for g in graphs]     # dense masks / (rowptr, colidx) accepted
         if self.part is not None:
@@ -80,6 +84,8 @@ class HANTrainer:
             self.graphs = list(graphs)
             self.graphs_t = [g.transpose() for g in graphs]
             model.halo_plans = (None, None)
+        if self.xs_full is not None and self._replicate_arg == "auto" and "HAN_REPLICATE" not in os.environ:
+            self._calibrate_replication(ffd_drop)
         self.labels = labels.to(device=dev, dtype=torch.int32).contiguous()
         self.train_mask = train_mask.to(device=dev, dtype=torch.uint8).contiguous()
         self.val_mask = (val_mask if val_mask is not None else train_mask).to(
@@ -107,6 +113,61 @@ class HANTrainer:
             self._step_inc = torch.tensor([-0x61C8864680B583EB, 1], dtype=torch.int64, device=dev)  # 0x9E37...15
             model.step_seed_dev = self.step_state[0:1]
             self.opt.step_dev = self.step_state[1:2]
+
+    def _calibrate_replication(self, ffd_drop, reps=3):
+        """replicate="auto" over RCCL: MEASURE, on this machine and this shape, what a forward table costs to
+        exchange (one all-gather of a rank's projected rows) against what it costs to recompute (K1 over all
+        rows minus K1 over the local rows, with and without dropout), take the maximum over the ranks and
+        replicate exactly the forward passes whose projection is cheaper than their exchange.  Other
+        backends (the gloo rehearsals, whose timings mean nothing) keep the static policy."""
+        import torch.distributed as dist
+        pt = self.part
+        if not (dist.is_available() and dist.is_initialized() and dist.get_backend(pt.group) == "nccl"):
+            return
+        if all(pl is not None for pl in self.model.halo_plans[0]):
+            return                                  # every meta-path has a halo plan: nothing to decide
+        m, dev = self.model, self.model.flat.device
+        Xf, Xl = self.xs_full[0], self.xs[0]
+        F = Xf.shape[1]
+        W = torch.zeros((F, ops.D), device=dev)     # K1's time does not depend on the values
+        a, b = torch.zeros((8, 8), device=dev), torch.zeros(8, device=dev)
+
+        def ms(fn):
+            fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            return sorted(ts)[len(ts) // 2]
+
+        def k1(X, drop, off):
+            return ops.project_fwd(X, W, a, a, b, b, in_drop=drop, fts_drop=drop, seed=1, row_offset=off,
+                                   table_dtype=m.table_dtype)
+
+        with torch.no_grad():
+            t = [ms(lambda: k1(Xl, ffd_drop, pt.row_start)), ms(lambda: k1(Xf, ffd_drop, 0)),
+                 ms(lambda: k1(Xl, 0.0, pt.row_start)), ms(lambda: k1(Xf, 0.0, 0))]
+            H_loc = k1(Xl, 0.0, pt.row_start)[0]
+            t.append(ms(lambda: pt.all_gather_rows_async(H_loc, ("calib",)).wait()))
+        tt = torch.tensor(t, device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=pt.group)
+        loc_tr, full_tr, loc_ev, full_ev, gather = (float(v) for v in tt.tolist())
+        rep = set()
+        if full_tr - loc_tr < gather:
+            rep.add("train")
+        if full_ev - loc_ev < gather:
+            rep.add("eval")
+        self.replicate = frozenset(rep)
+        self.replicate_info = {"policy": "measured at set-up (max over ranks, ms)",
+                               "all_gather_of_one_forward_table": round(gather, 3),
+                               "extra_projection_training": round(full_tr - loc_tr, 3),
+                               "extra_projection_eval": round(full_ev - loc_ev, 3)}
+        pt._bufs = {k: v for k, v in pt._bufs.items() if k[0] != ("calib",)}      # drop the calibration table
 
     def _global_count(self, mask):
         c = mask.sum().to(torch.float32).reshape(1)

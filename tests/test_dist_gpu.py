@@ -34,7 +34,8 @@ def test_two_ranks_match_single_process(dev, tmp_path, drop):
     assert np.abs(a["hist"] - b["hist"]).max() < 2e-5
 
 
-@pytest.mark.parametrize("mode", ["halo", "allgather-local-rows", "allgather-local-rows-bf16"])
+@pytest.mark.parametrize("mode", ["halo", "allgather-local-rows", "allgather-local-rows-bf16",
+                                  "allgather-local-rows-replicate-auto"])
 def test_rccl_collectives_on_a_one_rank_group(dev, tmp_path, mode):
     """The RCCL code path on a 1-rank communicator -- the only way to execute those calls on a single-GPU
     box: all_to_all_single with (empty) uneven splits for the halo plans and their per-step exchange,
@@ -45,13 +46,20 @@ def test_rccl_collectives_on_a_one_rank_group(dev, tmp_path, mode):
     if mode != "halo":
         extra = {"HAN_TEST_ALLGATHER": "1", "HAN_TEST_LOCAL": "1",
                  "HAN_TEST_BF16": "1" if mode.endswith("bf16") else "0"}
+    forced_extra = {}
+    if mode.endswith("replicate-auto"):
+        # replicate="auto" over RCCL measures exchange against recompute at set-up (HANTrainer._calibrate_replication)
+        forced_extra = {"HAN_TEST_REPLICATE": "auto"}
     _launch(1, 2, 0.6, one, 29621, extra)
-    _launch(1, 2, 0.6, forced, 29623, {"HAN_FORCE_COLLECTIVES": "1", "HAN_TEST_BACKEND": "nccl", **extra})
+    _launch(1, 2, 0.6, forced, 29623, {"HAN_FORCE_COLLECTIVES": "1", "HAN_TEST_BACKEND": "nccl", **extra,
+                                       **forced_extra})
     a, b = np.load(one), np.load(forced)
     tol = 5e-6 if not mode.endswith("bf16") else 5e-4      # different kernel instantiations (FAST / generic)
     assert np.abs(a["flat"] - b["flat"]).max() < tol
     assert np.abs(a["hist"] - b["hist"]).max() < max(tol, 1e-6)
     assert int(b["halo_plans"]) == (4 if mode == "halo" else 0)
+    if mode.endswith("replicate-auto"):
+        assert str(b["replicate"]) == "eval,train"      # one rank: projecting "all" rows costs nothing extra
 
 
 def test_halo_exchange_two_ranks_real_kernels(dev, tmp_path):
