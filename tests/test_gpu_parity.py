@@ -767,9 +767,10 @@ def test_return_coef_and_hetegat_class(dev):
 
 
 def test_c_abi_demo_program(dev):
-    """examples/c_abi_demo.cpp drives K1 -> K2 -> K3 through include/han_hip.h from plain
-    C++ (hipMalloc + a HIP stream; no Python, no torch types at the boundary).  Its inputs
-    come from a fixed LCG, rebuilt here; its printed outputs must match the oracle."""
+    """examples/c_abi_demo.cpp drives K1 -> K2 -> K3 and the K2 / K1 backward chain through
+    include/han_hip.h from plain C++ (hipMalloc + a HIP stream; no Python, no torch types at the
+    boundary).  Its inputs come from a fixed LCG, rebuilt here; its printed outputs and gradients must
+    match the oracle."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -806,6 +807,26 @@ def test_c_abi_demo_program(dev):
     assert np.abs(M - ref).max() < TOL
     Zr = ho.simple_att_layer(ref[:, None, :], wo, bo, uo)
     assert np.abs(Z - Zr).max() < TOL
+
+    # the training-side entry points from the same program ("bwd"): K2 forward with the extras ->
+    # han_node_attn_bwd_rows -> han_node_attn_bwd_cols (transposed ring) -> han_score_param_bwd ->
+    # han_project_bwd, against float64 autograd of the oracle for loss = sum(dOut * out)
+    r = subprocess.run([exe, str(n), str(f), str(deg), "bwd"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    vals = np.array([float(t) for t in r.stdout.split()])
+    assert vals.size == 2 * n * 64 + f * 64 + 64 + 64 + 8 + 8 + 64
+    g = vals[2 * n * 64:]
+    got = {"W": g[:f * 64].reshape(f, 64), "a1": g[f * 64:f * 64 + 64].reshape(8, 8),
+           "a2": g[f * 64 + 64:f * 64 + 128].reshape(8, 8), "b1": g[f * 64 + 128:f * 64 + 136],
+           "b2": g[f * 64 + 136:f * 64 + 144], "c": g[f * 64 + 144:]}
+    dOut = lcg(n * 64).reshape(n, 64)
+    tp = {k: torch.tensor(v, requires_grad=True) for k, v in
+          dict(W=W, a1=a1, a2=a2, b1=b1, b2=b2, c=c).items()}
+    out = ht.node_attention_csr(torch.tensor(X), torch.tensor(rp), torch.tensor(ci), tp["W"], tp["a1"], tp["b1"],
+                                tp["a2"], tp["b2"], tp["c"])
+    (out * torch.tensor(dOut)).sum().backward()
+    for k, v in got.items():
+        assert rel_err(v, tp[k].grad.numpy()) < GTOL, k
 
 
 def test_errors_are_loud(dev):
