@@ -56,6 +56,52 @@ class TFAdam:
 
 class BaseGAttN:
     @staticmethod
+    def loss(logits, labels, nb_classes, class_weights):
+        """models/base_gattn.py:5-10: class-weighted sparse softmax cross-entropy (mean over samples).
+        logits (N,C); labels (N,) integer class ids; class_weights (C,)."""
+        sample_wts = (torch.nn.functional.one_hot(labels.long(), nb_classes).to(logits.dtype)
+                      * torch.as_tensor(class_weights, dtype=logits.dtype, device=logits.device)).sum(-1)   # :6-7
+        xent = torch.nn.functional.cross_entropy(logits, labels.long(), reduction="none") * sample_wts     # :8-9
+        return xent.mean()                                                                                   # :10
+
+    @staticmethod
+    def preshape(logits, labels, nb_classes):
+        """models/base_gattn.py:26-31."""
+        return logits.reshape(-1, nb_classes), labels.reshape(-1)
+
+    @staticmethod
+    def confmat(logits, labels):
+        """models/base_gattn.py:33-35: confusion matrix, rows = labels, columns = predictions."""
+        preds = logits.argmax(1)
+        labels = labels.long()
+        n = int(max(int(labels.max()), int(preds.max()))) + 1
+        cm = torch.zeros((n, n), dtype=torch.int64, device=logits.device)
+        cm.index_put_((labels, preds), torch.ones_like(labels), accumulate=True)
+        return cm
+
+    @staticmethod
+    def masked_sigmoid_cross_entropy(logits, labels, mask):
+        """models/base_gattn.py:50-59 (multi-label)."""
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(
+            logits, labels.to(logits.dtype), reduction="none").mean(1)                   # :52-55
+        mask = mask.to(logits.dtype)
+        mask = mask / mask.mean()                                                        # :56-57
+        return (loss * mask).mean()                                                      # :58-59
+
+    @staticmethod
+    def micro_f1(logits, labels, mask):
+        """models/base_gattn.py:71-94."""
+        predicted = torch.round(torch.sigmoid(logits)).to(torch.int64)                   # :73-76 (half to even, as tf.round)
+        labels = labels.to(torch.int64)
+        m = mask.to(torch.int64).unsqueeze(-1)                                           # :78-81
+        tp = torch.count_nonzero(predicted * labels * m)                                 # :84
+        fp = torch.count_nonzero(predicted * (labels - 1) * m)                           # :86
+        fn = torch.count_nonzero((predicted - 1) * labels * m)                           # :87
+        precision = tp.double() / (tp + fp).double()                                     # :90
+        recall = tp.double() / (tp + fn).double()                                        # :91
+        return ((2 * precision * recall) / (precision + recall)).to(torch.float32)       # :92-94
+
+    @staticmethod
     def masked_softmax_cross_entropy(logits, labels, mask):
         """models/base_gattn.py:41-48.  logits, labels (N,C) one-hot; mask (N,)."""
         loss = -(labels.to(logits.dtype) * torch.log_softmax(logits, dim=-1)).sum(-1)   # :43-44

@@ -267,6 +267,49 @@ def masked_accuracy(logits, labels, mask):
     return np.mean(correct * mask)
 
 
+def weighted_loss(logits, labels, nb_classes, class_weights):
+    """models/base_gattn.py:5-10 (`loss`): class-weighted sparse softmax cross-entropy, mean over samples.
+    logits (N,C); labels (N,) int; class_weights (C,)."""
+    z = logits - np.max(logits, axis=-1, keepdims=True)
+    logp = z - np.log(np.sum(np.exp(z), axis=-1, keepdims=True))
+    sample_wts = np.sum(np.eye(nb_classes)[labels] * class_weights, axis=-1)       # :6-7
+    xent = -logp[np.arange(len(labels)), labels] * sample_wts                    # :8-9
+    return np.mean(xent)                                                         # :10
+
+
+def confmat(logits, labels):
+    """models/base_gattn.py:33-35: tf.confusion_matrix(labels, argmax(logits)) -- rows = labels,
+    columns = predictions, size = max(label, prediction) + 1."""
+    preds = np.argmax(logits, axis=1)
+    n = int(max(labels.max(), preds.max())) + 1
+    cm = np.zeros((n, n), dtype=np.int64)
+    np.add.at(cm, (labels, preds), 1)
+    return cm
+
+
+def masked_sigmoid_cross_entropy(logits, labels, mask):
+    """models/base_gattn.py:50-59 (multi-label, PPI).  logits, labels (N,C); mask (N,)."""
+    x, z = logits, labels.astype(logits.dtype)                                    # :52
+    loss = np.maximum(x, 0) - x * z + np.log1p(np.exp(-np.abs(x)))              # :53-54 (TF's stable form)
+    loss = np.mean(loss, axis=1)                                                 # :55
+    mask = mask.astype(logits.dtype)
+    mask = mask / np.mean(mask)                                                  # :56-57
+    return np.mean(loss * mask)                                                  # :58-59
+
+
+def micro_f1(logits, labels, mask):
+    """models/base_gattn.py:71-94.  round() is round-half-to-even, as tf.round."""
+    predicted = np.round(1.0 / (1.0 + np.exp(-logits))).astype(np.int64)         # :73-76
+    labels = labels.astype(np.int64)
+    m = mask.astype(np.int64)[:, None]                                           # :78-81
+    tp = np.count_nonzero(predicted * labels * m)                                # :84
+    fp = np.count_nonzero(predicted * (labels - 1) * m)                          # :86
+    fn = np.count_nonzero((predicted - 1) * labels * m)                          # :87
+    precision = tp / (tp + fp)                                                   # :90
+    recall = tp / (tp + fn)                                                      # :91
+    return np.float32((2 * precision * recall) / (precision + recall))          # :92-94
+
+
 def l2_loss_all(param_arrays, l2_coef):
     """models/base_gattn.py:14-16: l2_coef * sum_v sum(v**2)/2 over ALL trainables
     (the name filter never matches a TF variable name such as 'conv1d/bias:0')."""

@@ -360,6 +360,28 @@ def test_base_gattn_loss_functions():
     assert abs(b - ho.masked_accuracy(logits, labels, mask)) < 1e-12
 
 
+def test_base_gattn_remaining_helpers():
+    """The BaseGAttN members the HAN script never calls (models/base_gattn.py:5-10,26-35,50-59,71-94):
+    class-weighted loss, preshape, confusion matrix, multi-label sigmoid loss, micro-F1 -- against the
+    NumPy restatements."""
+    from han_amd.base_gattn import BaseGAttN
+    rng = np.random.default_rng(4)
+    n, c = 57, 5
+    logits = rng.standard_normal((n, c)) * 2
+    labels = rng.integers(0, c, n)
+    multi = (rng.random((n, c)) < 0.3).astype(np.int64)
+    mask = rng.random(n) < 0.5
+    cw = rng.uniform(0.5, 2.0, c)
+    tl, tlab, tm = torch.tensor(logits), torch.tensor(labels), torch.tensor(mask)
+    assert abs(float(BaseGAttN.loss(tl, tlab, c, torch.tensor(cw))) - ho.weighted_loss(logits, labels, c, cw)) < 1e-12
+    a, b = BaseGAttN.preshape(tl.reshape(1, n, c), tlab.reshape(1, n), c)
+    assert tuple(a.shape) == (n, c) and tuple(b.shape) == (n,)
+    assert np.array_equal(BaseGAttN.confmat(tl, tlab).numpy(), ho.confmat(logits, labels))
+    assert abs(float(BaseGAttN.masked_sigmoid_cross_entropy(tl, torch.tensor(multi), tm))
+               - ho.masked_sigmoid_cross_entropy(logits, multi, mask)) < 1e-12
+    assert abs(float(BaseGAttN.micro_f1(tl, torch.tensor(multi), tm)) - float(ho.micro_f1(logits, multi, mask))) < 1e-6
+
+
 def test_evaluate_matches_the_reference_jhyexp_outputs():
     """tests/golden/jhyexp_ref.npz holds what the reference's OWN jhyexp.my_KNN / my_Kmeans
     (jhyexp.py:20-86, imported by tests/golden/gen_fixtures.py) printed / returned on seeded
