@@ -67,6 +67,10 @@ class NodePartition:
             self._bufs[key] = t
         return t
 
+    def drop_buffers(self, tag) -> None:
+        """Release the persistent buffers registered under `tag`."""
+        self._bufs = {k: v for k, v in self._bufs.items() if k[0] != tag and k[0] != (tag, "pad")}
+
     # ---- graph sharding -------------------------------------------------------
     def shard_graph(self, g: CSRGraph) -> tuple[CSRGraph, CSRGraph]:
         """Global CSR (n_global x n_global) -> (rows_local, cols_local), see shard_local_graph.

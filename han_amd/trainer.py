@@ -167,7 +167,7 @@ class HANTrainer:
                                "all_gather_of_one_forward_table": round(gather, 3),
                                "extra_projection_training": round(full_tr - loc_tr, 3),
                                "extra_projection_eval": round(full_ev - loc_ev, 3)}
-        pt._bufs = {k: v for k, v in pt._bufs.items() if k[0] != ("calib",)}      # drop the calibration table
+        pt.drop_buffers(("calib",))
 
     def _global_count(self, mask):
         c = mask.sum().to(torch.float32).reshape(1)
