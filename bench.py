@@ -152,6 +152,7 @@ def live_traffic(args, timeout_s=150):
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
@@ -170,9 +171,21 @@ def live_traffic(args, timeout_s=150):
                    "--workload", args.workload, "--table-dtype", args.table_dtype]
             if args.nodes:
                 cmd += ["--nodes", str(args.nodes)]
-            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {c} pass failed (rc {r.returncode}): {r.stderr[-300:]}"
+            # own session: on a timeout the whole group goes (rocprofv3 AND the profiled bench.py child), so
+            # that nothing of it is still on the GPU when the HBM-regime probe is timed afterwards
+            pr = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                  start_new_session=True)
+            try:
+                _, err = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                pr.wait()
+                raise
+            if pr.returncode != 0:
+                return None, f"rocprofv3 --pmc {c} pass failed (rc {pr.returncode}): {err[-300:]}"
         for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 for tag, sub in K2_PMC_NAMES.items():

@@ -100,11 +100,11 @@ int main(int argc, char **argv) {
     HIP_OK(hipStreamCreate(&st));
 
     HAN_OK(han_project_fwd(dX, HAN_DTYPE_F32, F, dW, da1, da2, db1, db2, dH, HAN_DTYPE_F32, df1, df2, ws, ws_bytes,
-                           N, F, K, FP, 0.f, 0.f, 0, nullptr, 0, st));
+                           N, F, K, FP, 0.f, 0.f, 0, nullptr, 0, /*keep*/ nullptr, /*flags*/ 0, st));
     HAN_OK(han_node_attn_fwd(drp, dci, nullptr, dH, HAN_DTYPE_F32, nullptr, df1, da2, db2, dc, nullptr, dM, D,
                              nullptr, nullptr, nullptr, nullptr, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0,
                              HAN_ACT_ELU, /*flags*/ 0, nullptr, st));
-    HAN_OK(han_sem_attn_fwd(dM, dwo, dbo, duo, dZ, dbeta, N, 1, D, A, st));
+    HAN_OK(han_sem_attn_fwd(dM, dwo, dbo, duo, dZ, dbeta, N, 1, D, A, /*flags*/ 0, st));
     HIP_OK(hipStreamSynchronize(st));
 
     std::vector<float> M(N * D), Z(N * D);
@@ -161,7 +161,7 @@ int main(int argc, char **argv) {
     HAN_OK(han_node_attn_bwd_cols(dcp, dri, nullptr, dgs, nullptr, dH, HAN_DTYPE_F32, df2, ddf1, da1, da2, ddH,
                                   ddf2, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0, 0, 0, nullptr, st));
     HAN_OK(han_score_param_bwd(dH, HAN_DTYPE_F32, ddf1, ddf2, dda1, dda2, ddb1, ddb2, ws_sp, wb_sp, N, K, FP, st));
-    HAN_OK(han_project_bwd(dX, HAN_DTYPE_F32, F, ddH, ddW, ws_pb, wb_pb, N, F, K, FP, 0.f, 0, nullptr, 0, st));
+    HAN_OK(han_project_bwd(dX, HAN_DTYPE_F32, F, ddH, ddW, ws_pb, wb_pb, N, F, K, FP, 0.f, 0, nullptr, 0, /*keep*/ nullptr, st));
     HIP_OK(hipStreamSynchronize(st));
     auto dump = [](const float *d, size_t n) -> int {
         std::vector<float> h(n);

@@ -33,11 +33,12 @@ SIGNATURES = {
     "han_abi_version": (c_int, []),
     "han_error_string": (c_char_p, [c_int]),
     "han_project_fwd_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
+    "han_project_keep_bytes": (c_size_t, [I64, c_int, I64, c_int, c_int]),
     "han_project_fwd": (c_int, [P, c_int, I64, P, P, P, P, P, P, c_int, P, P, P, c_size_t, I64, c_int, c_int, c_int,
-                                c_float, c_float, c_uint64, P, I64, P]),
+                                c_float, c_float, c_uint64, P, I64, P, c_int, P]),
     "han_project_bwd_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
     "han_project_bwd": (c_int, [P, c_int, I64, P, P, P, c_size_t, I64, c_int, c_int, c_int, c_float,
-                                c_uint64, P, I64, P]),
+                                c_uint64, P, I64, P, P]),
     "han_project_bwd_input": (c_int, [P, P, P, I64, I64, c_int, c_int, c_int, c_float, c_uint64, P, I64, P]),
     "han_row_split_workspace": (c_size_t, [I64]),
     "han_node_attn_fwd": (c_int, [P, P, P, P, c_int, P, P, P, P, P, P, P, I64, P, P, P, P, I64, I64, c_int,
@@ -52,10 +53,10 @@ SIGNATURES = {
                                        c_float, c_float, c_float, c_uint64, P, I64, I64, c_int, P, P]),
     "han_score_param_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
     "han_score_param_bwd": (c_int, [P, c_int, P, P, P, P, P, P, P, c_size_t, I64, c_int, c_int, P]),
-    "han_sem_attn_fwd": (c_int, [P, P, P, P, P, P, I64, c_int, c_int, c_int, P]),
+    "han_sem_attn_fwd": (c_int, [P, P, P, P, P, P, I64, c_int, c_int, c_int, c_int, P]),
     "han_sem_attn_bwd_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
     "han_sem_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_size_t, I64, c_int, c_int,
-                                 c_int, P]),
+                                 c_int, c_int, P]),
     "han_classifier_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
     "han_classifier_loss": (c_int, [P, P, P, P, P, c_float, P, P, P, P, P, P, c_size_t, I64,
                                     c_int, c_int, c_int, P]),
@@ -65,7 +66,7 @@ SIGNATURES = {
     "han_bias_fill_csr": (c_int, [P, I64, I64, P, P, P]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

@@ -12,7 +12,6 @@
 // fp32-MFMA ridge: HBM-bound in eval, MFMA-bound in training where the per-head
 // input dropout (layers.py:18-19 sits inside the per-head call) forces one
 // masked MFMA per head per 16-column tile.
-#include <stdlib.h>
 #include "han_common.h"
 
 namespace {
@@ -45,6 +44,8 @@ struct ProjFwdArgs {
     // (split-F: project_scores_kernel runs after the finish kernel)
     const float *a1, *a2, *b1, *b2;
     float *f1, *f2;
+    // keep table of the per-head input dropout for the backward (han_hip.h: han_project_keep_bytes), or null
+    uint8_t *keep;
 };
 
 // f1 = H_k . a1_k + b1_k, f2 likewise, for the row whose stored elements (row, 16t + l15), t < 4, this lane
@@ -348,13 +349,21 @@ __device__ __forceinline__ uint32_t b6_keep_masks(uint32_t w, uint32_t thr2, uin
     return s;
 }
 
-template <bool DROP, bool XBF>
-__global__ __launch_bounds__(256) void project_fwd_b6_kernel(const ProjFwdArgs a_in) {
+// NW = waves per block (the block always owns 128 rows): 8 waves of one 16-row tile each keep the kernel
+// within 128 registers, i.e. FOUR waves per SIMD -- measured round 3: the 4-wave form (248 registers, two
+// waves per SIMD) spends 55 % of its wave cycles waiting (profiles/r02_pmc_k1_b6.json: each wave alone
+// issues a vector instruction every ~4.8 cycles at best, tools/micro/ubench.hip), and its KEEP variant at
+// 260 registers / ONE wave per SIMD ran 1.17 ms against 0.80 ms.
+template <bool DROP, bool XBF, bool KEEP, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kernel(const ProjFwdArgs a_in) {
     ProjFwdArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     constexpr int NX = XBF ? 1 : 3;       // split terms of X (a bf16 X is its own high term)
     constexpr int HPT = DROP ? 2 : 1;     // heads per 16-column tile (F' = 8 when DROP)
-    constexpr int MT = 2;                 // 16-row tiles per wave
+    constexpr int MT = 8 / NW;            // 16-row tiles per wave
+    constexpr int NT = 64 * NW;           // threads
+    constexpr int XV = 1024 / NT;         // float4 loads of X per thread per tile (128 rows x 32 k)
+    constexpr int WV = 2048 / NT;         // W elements per thread per tile (32 k x 64 columns): WV consecutive k of one column
     __shared__ __attribute__((aligned(16))) unsigned char lds[NX * B6_XBYTES + 3 * B6_WBYTES];
     unsigned char *Xs = lds;                          // [NX][128][96 B]
     unsigned char *Ws = lds + NX * B6_XBYTES;         // [3][64][96 B]   (transposed: [col][k])
@@ -371,16 +380,16 @@ __global__ __launch_bounds__(256) void project_fwd_b6_kernel(const ProjFwdArgs a
 #pragma unroll
             for (int hh = 0; hh < HPT; ++hh) acc[m][t][hh] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // staging registers: X 4 x float4 (row = idx >> 3, k4 = (idx & 7) * 4), W 8 floats (col = tid & 63,
-    // k = (tid >> 6) * 8 + j: 64 lanes read 64 consecutive columns per load)
-    float4_t xr[4];
-    float wr[8];
+    // staging registers: X XV x float4 (row = idx >> 3, k4 = (idx & 7) * 4), W WV floats (col = tid & 63,
+    // k = (tid >> 6) * WV + j: 64 lanes read 64 consecutive columns per load)
+    float4_t xr[XV];
+    float wr[WV];
     auto load_tile = [&](int k0) {
         // unconditional loads from clamped addresses + selects: a predicated load becomes a branch
         // around it with its own s_waitcnt, which serialises the tile's loads
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
+        for (int i = 0; i < XV; ++i) {
+            const int idx = tid + NT * i;
             const int r = idx >> 3, c4 = (idx & 7) * 4;
             const int64_t row = row0 + r;
             const bool ok = row < a.N && k0 + c4 < a.F;
@@ -391,8 +400,8 @@ __global__ __launch_bounds__(256) void project_fwd_b6_kernel(const ProjFwdArgs a
             for (int e = 0; e < 4; ++e) xr[i][e] = ok ? v[e] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int kw = k0 + (tid >> 6) * 8 + j;
+        for (int j = 0; j < WV; ++j) {
+            const int kw = k0 + (tid >> 6) * WV + j;
             const float v = a.W[(int64_t)(kw < a.F ? kw : a.F - 1) * HAN_D + (tid & 63)];
             wr[j] = kw < a.F ? v : 0.f;
         }
@@ -402,8 +411,8 @@ __global__ __launch_bounds__(256) void project_fwd_b6_kernel(const ProjFwdArgs a
     for (int k0 = 0; k0 < a.F; k0 += 32) {
         __syncthreads();   // the previous tile's fragment reads are done
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
+        for (int i = 0; i < XV; ++i) {
+            const int idx = tid + NT * i;
             const int off = (idx >> 3) * B6_LDB + (idx & 7) * 8;
             uint32_t h[4], m[4], l[4];
 #pragma unroll
@@ -415,30 +424,32 @@ __global__ __launch_bounds__(256) void project_fwd_b6_kernel(const ProjFwdArgs a
             }
         }
         {
-            uint32_t h[8], m[8], l[8];
+            uint32_t h[WV], m[WV], l[WV];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) b6_split(wr[j], h[j], m[j], l[j]);
-            const int off = (tid & 63) * B6_LDB + (tid >> 6) * 16;
-            i32x4 v;
+            for (int j = 0; j < WV; ++j) b6_split(wr[j], h[j], m[j], l[j]);
+            const int off = (tid & 63) * B6_LDB + (tid >> 6) * (2 * WV);
+            uint32_t ph[WV / 2], pm[WV / 2], pl[WV / 2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (int)b6_pack(h[2 * i], h[2 * i + 1]);
-            *reinterpret_cast<i32x4 *>(Ws + off) = v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (int)b6_pack(m[2 * i], m[2 * i + 1]);
-            *reinterpret_cast<i32x4 *>(Ws + B6_WBYTES + off) = v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (int)b6_pack(l[2 * i], l[2 * i + 1]);
-            *reinterpret_cast<i32x4 *>(Ws + 2 * B6_WBYTES + off) = v;
+            for (int i = 0; i < WV / 2; ++i) {
+                ph[i] = b6_pack(h[2 * i], h[2 * i + 1]);
+                pm[i] = b6_pack(m[2 * i], m[2 * i + 1]);
+                pl[i] = b6_pack(l[2 * i], l[2 * i + 1]);
+            }
+            if (WV == 8) {
+                *reinterpret_cast<uint4 *>(Ws + off) = make_uint4(ph[0], ph[1], ph[WV / 2 - 2], ph[WV / 2 - 1]);
+                *reinterpret_cast<uint4 *>(Ws + B6_WBYTES + off) = make_uint4(pm[0], pm[1], pm[WV / 2 - 2], pm[WV / 2 - 1]);
+                *reinterpret_cast<uint4 *>(Ws + 2 * B6_WBYTES + off) = make_uint4(pl[0], pl[1], pl[WV / 2 - 2], pl[WV / 2 - 1]);
+            } else {
+                *reinterpret_cast<uint2 *>(Ws + off) = make_uint2(ph[0], ph[1]);
+                *reinterpret_cast<uint2 *>(Ws + B6_WBYTES + off) = make_uint2(pm[0], pm[1]);
+                *reinterpret_cast<uint2 *>(Ws + 2 * B6_WBYTES + off) = make_uint2(pl[0], pl[1]);
+            }
         }
         __syncthreads();
         if (k0 + 32 < a.F) load_tile(k0 + 32);   // in flight under the MFMAs
-        // B fragments of the four column tiles: B[k = 8*l4 + j][col = 16t + l15]
-        i32x4 bf[4][3];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3)
-                bf[t][s3] = *reinterpret_cast<const i32x4 *>(Ws + s3 * B6_WBYTES + (16 * t + l15) * B6_LDB + 16 * l4);
+        auto bfrag = [&](int t, int s3) {        // B[k = 8*l4 + j][col = 16t + l15]
+            return *reinterpret_cast<const i32x4 *>(Ws + s3 * B6_WBYTES + (16 * t + l15) * B6_LDB + 16 * l4);
+        };
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int lr = 16 * (w * MT + m) + l15;
@@ -449,54 +460,71 @@ __global__ __launch_bounds__(256) void project_fwd_b6_kernel(const ProjFwdArgs a
             if (!DROP) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
+                    const i32x4 b0 = bfrag(t, 0), b1 = bfrag(t, 1), b2 = bfrag(t, 2);
                     f32x4 c = acc[m][t][0];
                     if (!XBF) {
-                        c = b6_mfma(af[1], bf[t][1], c);      // small terms first
-                        c = b6_mfma(af[2], bf[t][0], c);
-                        c = b6_mfma(af[1], bf[t][0], c);
+                        c = b6_mfma(af[1], b1, c);      // small terms first
+                        c = b6_mfma(af[2], b0, c);
+                        c = b6_mfma(af[1], b0, c);
                     }
-                    c = b6_mfma(af[0], bf[t][2], c);
-                    c = b6_mfma(af[0], bf[t][1], c);
-                    c = b6_mfma(af[0], bf[t][0], c);
+                    c = b6_mfma(af[0], b2, c);
+                    c = b6_mfma(af[0], b1, c);
+                    c = b6_mfma(af[0], b0, c);
                     acc[m][t][0] = c;
                 }
             } else {
-                // keep masks of this lane's 8 elements (row nglob, k = k0 + 8*l4 + j) for the 8 heads:
+                // keep masks of this lane's 8 elements (row nglob, k = k0 + 8*l4 + j), four heads at a time:
                 // call c serves heads 4c..4c+3: x = fields of heads 4c, 4c+1; y = heads 4c+2, 4c+3
                 const uint32_t nglob = (uint32_t)(row0 + lr + a.row_offset);
-                uint32_t mk[8][2][2];
+                uint32_t kw[2] = {0u, 0u};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t kglob = (uint32_t)(k0 + 8 * l4 + j);
+                for (int c = 0; c < 2; ++c) {
+                    uint32_t mk[8][2];
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t kglob = (uint32_t)(k0 + 8 * l4 + j);
                         const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_SEQ, nglob, kglob * 2u + (uint32_t)c);
-                        mk[j][c][0] = b6_keep_masks(rn.x, thr2, one2);
-                        mk[j][c][1] = b6_keep_masks(rn.y, thr2, one2);
+                        mk[j][0] = b6_keep_masks(rn.x, thr2, one2);
+                        mk[j][1] = b6_keep_masks(rn.y, thr2, one2);
+                        if constexpr (KEEP) {
+                            // this lane's 8 elements are one octet of its row: 64 keep bits (8 elements x 8 heads) in
+                            // the bit order of the dW kernel's A-operand lane mask (han_hip.h): element j = 4q + i,
+                            // head k = 4c + 2wd + half -> bit 32q + 16*half + 4*(2c + wd) + i; a mask word holds the
+                            // two halves (heads 4c+2wd, 4c+2wd+1) in its low / high 16 bits: one and-or per word
+#pragma unroll
+                            for (int wd = 0; wd < 2; ++wd)
+                                kw[j >> 2] |= mk[j][wd] & (0x00010001u << (4 * (2 * c + wd) + (j & 3)));
+                        }
+                    }
+#pragma unroll
+                    for (int hq = 0; hq < 4; ++hq) {
+                        const int head = 4 * c + hq;
+                        const int t = head >> 1, hh = head & 1, wd = hq >> 1;
+                        const uint32_t sel = (head & 1) ? 0x07060302u : 0x05040100u;
+                        i32x4 am[NX];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t pm = __builtin_amdgcn_perm(mk[2 * i + 1][wd], mk[2 * i][wd], sel);
+#pragma unroll
+                            for (int s3 = 0; s3 < NX; ++s3) am[s3][i] = af[s3][i] & (int)pm;
+                        }
+                        const i32x4 b0 = bfrag(t, 0), b1 = bfrag(t, 1), b2 = bfrag(t, 2);
+                        f32x4 cc = acc[m][t][hh];
+                        if (!XBF) {
+                            cc = b6_mfma(am[1], b1, cc);
+                            cc = b6_mfma(am[2], b0, cc);
+                            cc = b6_mfma(am[1], b0, cc);
+                        }
+                        cc = b6_mfma(am[0], b2, cc);
+                        cc = b6_mfma(am[0], b1, cc);
+                        cc = b6_mfma(am[0], b0, cc);
+                        acc[m][t][hh] = cc;
                     }
                 }
-#pragma unroll
-                for (int head = 0; head < 8; ++head) {
-                    const int t = head >> 1, hh = head & 1;
-                    const int c = head >> 2, wd = (head >> 1) & 1;
-                    const uint32_t sel = (head & 1) ? 0x07060302u : 0x05040100u;
-                    i32x4 am[NX];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint32_t pm = __builtin_amdgcn_perm(mk[2 * i + 1][c][wd], mk[2 * i][c][wd], sel);
-#pragma unroll
-                        for (int s3 = 0; s3 < NX; ++s3) am[s3][i] = af[s3][i] & (int)pm;
-                    }
-                    f32x4 cc = acc[m][t][hh];
-                    if (!XBF) {
-                        cc = b6_mfma(am[1], bf[t][1], cc);
-                        cc = b6_mfma(am[2], bf[t][0], cc);
-                        cc = b6_mfma(am[1], bf[t][0], cc);
-                    }
-                    cc = b6_mfma(am[0], bf[t][2], cc);
-                    cc = b6_mfma(am[0], bf[t][1], cc);
-                    cc = b6_mfma(am[0], bf[t][0], cc);
-                    acc[m][t][hh] = cc;
+                if constexpr (KEEP) {
+                    const int64_t krow = row0 + lr;
+                    if (krow < a.N && k0 + 8 * l4 < a.F)
+                        *reinterpret_cast<uint2 *>(a.keep + krow * (int64_t)a.F + k0 + 8 * l4) = make_uint2(kw[0], kw[1]);
                 }
             }
         }
@@ -847,6 +875,187 @@ __global__ __launch_bounds__(256) void project_bwd_input_kernel(const ProjBwdInA
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// dW on v_mfma_f32_4x4x1_16B_f32 with the keep table as the A operand's lane mask.
+//
+// The 16x16x4 kernel above pays the per-head input dropout twice: it regenerates every (row, feature,
+// head) draw (6x the VALU instructions of the kernel without dropout, profiles/r02_pmc_k1_b6.json) and it
+// issues every 16-column tile once per head it covers, discarding half of each product.  The 16-block
+// 4x4x1 form has neither problem: one instruction computes 16 independent 4x4 outer products
+//     D_b[i][j] += A_b[i] * B_b[j]          (b = lane / 4; A: i = lane % 4; B and D: j = lane % 4, D reg = i;
+//                                            map and 8-cycle issue measured with tools/micro/ubench.hip)
+// so a block can carry ONE head: block b = (q, b') takes the 4 features f = oct + 4q + i (q = lane / 32) of
+// head k(b') = 2 (b' % 4) + b' / 4 against 4 of that head's columns.  The A operand of lane l is then
+// X[n][oct + 4q + i] if bit l of the row's 64-bit keep word is set (han_hip.h: the forward wrote the table
+// in exactly this bit order): one v_bfe_i32 + one v_and_b32, no hash, no wasted column, and each masked A
+// register serves two MFMAs (column quads 0-3 and 4-7 of every head).  Same fp32 pipe, same 64 flop / clk /
+// SIMD, but 1024 useful flop per 16 cycles of issue instead of 1024 useful out of 2048 per 32.
+// Block: 128 features (4 waves x 4 octets) x all 64 columns over a chunk of rows; X, dH and the keep words
+// of 32 rows are staged through LDS one tile ahead, laid out so that a row costs a wave three LDS reads:
+//   Xs[n][wave][q][i][octet]      one ds_read_b128 = the lane's 4 A values
+//   Gs[n][b'][j][parity]          one ds_read_b64  = its 2 B values
+//   Ks[n][wave][q][octet]         one ds_read_b128 = the 4 half keep words holding its bits
+// Partial tiles go to a slab (fixed-order second stage, no float atomics).
+// ---------------------------------------------------------------------------------------------
+constexpr int DW_BN = 32;            // rows per staged tile
+constexpr int DW_FB = 128;           // dW rows (features) per block
+
+struct ProjBwdBlkArgs {
+    const void *X;
+    int64_t ldx;
+    const float *dH;
+    const uint8_t *keep;    // N rows of F bytes (+ slack), or null when DROP is false
+    float *slab;            // [nchunks][F][64]
+    int64_t N;
+    int F;
+    int64_t rows_per_chunk;
+    float inv_keep_in;
+};
+
+template <bool DROP, bool XBF>
+__global__ __launch_bounds__(256, 4) void project_bwd_blk_kernel(const ProjBwdBlkArgs a) {
+    __shared__ __attribute__((aligned(16))) float Xs[DW_BN * DW_FB];
+    __shared__ __attribute__((aligned(16))) float Gs[DW_BN * HAN_D];
+    __shared__ __attribute__((aligned(16))) uint32_t Ks[DROP ? DW_BN * 32 : 4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int f0 = blockIdx.x * DW_FB;
+    const int64_t chunk = blockIdx.y;
+    const int64_t n_begin = chunk * a.rows_per_chunk;
+    const int64_t n_end = (n_begin + a.rows_per_chunk < a.N) ? n_begin + a.rows_per_chunk : a.N;
+    const int q = lane >> 5, bq = (lane & 31) >> 2, i4 = lane & 3;
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[o][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging registers: X tile 32 x 128 (4 x float4 per thread), dH tile 32 x 64 (2 x float4), keep tile 32 x 128 B
+    // (2 x 8 B).  Unconditional loads from clamped addresses + selects (a predicated load is a branch with its own wait).
+    float4_t xr[4], gr[2];
+    uint2 kr[2];
+    auto load_tile = [&](int64_t n0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx >> 5, c4 = (idx & 31) * 4;
+            const int64_t row = n0 + r;
+            const bool ok = row < n_end && f0 + c4 < a.F;           // F % 4 == 0
+            const int64_t rc = row < a.N ? row : a.N - 1;
+            const int fc = f0 + c4 < a.F ? f0 + c4 : a.F - 4;
+            const float4_t v = load_x4(a.X, XBF, rc * a.ldx + fc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xr[i][e] = ok ? v[e] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int64_t row = n0 + (idx >> 4);
+            const int64_t rc = row < a.N ? row : a.N - 1;
+            const float4_t v = *reinterpret_cast<const float4_t *>(a.dH + rc * HAN_D + (idx & 15) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gr[i][e] = row < n_end ? v[e] : 0.f;
+        }
+        if (DROP) {      // rows / features beyond the ends meet X == 0, so their (arbitrary) keep bits do not matter
+            const int64_t row = n0 + (tid >> 3);
+            const int64_t rc = row < a.N ? row : a.N - 1;
+            const int fb = f0 + 16 * (tid & 7);
+            const uint8_t *kp = a.keep + rc * (int64_t)a.F + (fb < a.F ? fb : a.F - 8);     // table has 128 B of slack
+            kr[0] = *reinterpret_cast<const uint2 *>(kp);
+            kr[1] = *reinterpret_cast<const uint2 *>(kp + 8);
+        }
+    };
+    // dword offsets of this lane's operands inside a row of the three LDS images
+    const int a_off = 32 * w + 16 * q + 4 * i4;
+    const int b_off = 8 * bq + 2 * i4;
+    const int k_off = 8 * w + 4 * q;
+    const uint32_t my_bit = (uint32_t)(lane & 31);
+
+    load_tile(n_begin);
+    for (int64_t n0 = n_begin; n0 < n_end; n0 += DW_BN) {
+        __syncthreads();      // the previous tile's operand reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx >> 5, k = idx & 31;      // features 4k .. 4k+3: wave k/8, octet (k%8)/2, half k%2, i = e
+            float *dst = Xs + r * DW_FB + 32 * (k >> 3) + 16 * (k & 1) + ((k & 7) >> 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[4 * e] = xr[i][e];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int cq = idx & 15, hd = cq >> 1;                     // column quad -> (head, parity); j = e
+            const int rank = (hd & 1) * 4 + (hd >> 1);                 // b' of that head
+            float *dst = Gs + (idx >> 4) * HAN_D + 8 * rank + (cq & 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[2 * e] = gr[i][e];
+        }
+        if (DROP) {
+            const int seg = tid & 7;                                   // octets 2 seg, 2 seg + 1 of the tile's 16
+            uint32_t *dst = Ks + (tid >> 3) * 32 + 8 * (seg >> 1) + 2 * (seg & 1);
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(kr[0].x, kr[1].x);         // q = 0 halves of the two octets
+            *reinterpret_cast<uint2 *>(dst + 4) = make_uint2(kr[0].y, kr[1].y);     // q = 1 halves
+        }
+        __syncthreads();
+        if (n0 + DW_BN < n_end) load_tile(n0 + DW_BN);     // in flight under the MFMAs
+        // Three-stage software pipeline over the 32 rows of the tile, spelled out because hipcc's own schedule
+        // (reads of two rows, then a wait right behind them, one temporary through every mask / and / MFMA chain)
+        // exposes the LDS latency every other row: row n + 2 is being read, row n + 1's A operands are being
+        // masked, row n's eight MFMAs issue; sched_group_barrier pins that interleave (2 MFMA : 2 VALU).
+        float4_t xa[3];
+        float2 bb[3];
+        uint4 kk[3];
+        auto fetch = [&](int n, int slot) {
+            xa[slot] = *reinterpret_cast<const float4_t *>(Xs + n * DW_FB + a_off);
+            bb[slot] = *reinterpret_cast<const float2 *>(Gs + n * HAN_D + b_off);
+            if (DROP) kk[slot] = *reinterpret_cast<const uint4 *>(Ks + n * 32 + k_off);
+        };
+        auto masked = [&](int slot, int o) -> float {
+            if (!DROP) return xa[slot][o];
+            const uint32_t kwd = o == 0 ? kk[slot].x : o == 1 ? kk[slot].y : o == 2 ? kk[slot].z : kk[slot].w;
+            return __int_as_float(__float_as_int(xa[slot][o]) & __builtin_amdgcn_sbfe((int)kwd, my_bit, 1u));
+        };
+        float am[2][4];
+        fetch(0, 0);
+        fetch(1, 1);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) am[0][o] = masked(0, o);
+#pragma unroll
+        for (int n = 0; n < DW_BN; ++n) {
+            const int cur = n & 1;
+            if (n + 2 < DW_BN) fetch(n + 2, (n + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);      // the reads of row n + 2 go out BEFORE row n's MFMAs, and stay there
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                acc[o][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[cur][o], bb[n % 3].x, acc[o][0], 0, 0, 0);
+                acc[o][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[cur][o], bb[n % 3].y, acc[o][1], 0, 0, 0);
+                if (n + 1 < DW_BN) am[cur ^ 1][o] = masked((n + 1) % 3, o);
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                              // 2 MFMA
+                if (DROP && n + 1 < DW_BN) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU (bfe, and)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // D: lane = 4 b + j, register = i -> dW[f = f0 + 32 w + 8 o + 4 q + i][col = 8 head(b') + 4 parity + j]
+    float *out = a.slab + chunk * (int64_t)a.F * HAN_D;
+    const int head = 2 * (bq & 3) + (bq >> 2);
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = f0 + 32 * w + 8 * o + 4 * q + r;
+                const float v = acc[o][h][r];
+                if (f < a.F) out[(int64_t)f * HAN_D + 8 * head + 4 * h + i4] = DROP ? v * a.inv_keep_in : v;
+            }
+}
+
 bool fp_ok(int K, int FP) {
     return K * FP == HAN_D && (FP == 4 || FP == 8 || FP == 16 || FP == 32 || FP == 64);
 }
@@ -900,11 +1109,23 @@ extern "C" size_t han_project_fwd_workspace(int64_t N, int F, int K, int FP) {
     return nsplit > 1 ? (size_t)nsplit * (size_t)N * HAN_D * sizeof(float) : 0;
 }
 
+// the shapes for which the training forward writes (and dW reads) the keep table: the reference head shape on the
+// matrix-pipe forward (whole-F blocks of 128 rows, no split-F: at least 256 row tiles)
+static bool keep_table_shape(int64_t N, int F, int64_t ldx, int K, int FP) {
+    return K == 8 && FP == 8 && F % 8 == 0 && ldx % 4 == 0 && N >= 128 * 256;
+}
+
+extern "C" size_t han_project_keep_bytes(int64_t N, int F, int64_t ldx, int K, int FP) {
+    if (N <= 0 || F <= 0 || !keep_table_shape(N, F, ldx, K, FP)) return 0;
+    return (size_t)N * (size_t)F + 128;
+}
+
 extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const float *W, const float *a1,
                                const float *a2, const float *b1, const float *b2, void *H, int table_dtype,
                                float *f1, float *f2, void *workspace, size_t workspace_bytes, int64_t N, int F,
                                int K, int FP, float in_drop, float fts_drop, uint64_t seed,
-                               const uint64_t *seed_dev, int64_t row_offset, void *stream) {
+                               const uint64_t *seed_dev, int64_t row_offset, uint8_t *keep, int flags,
+                               void *stream) {
     if (N == 0) return 0;   // nothing to do; row pointers of empty tensors may be null
     if (!X || !W || !a1 || !a2 || !b1 || !b2 || !H || !f1 || !f2 || N < 0 || F <= 0 || ldx < F)
         return HAN_E_BADARG;
@@ -913,7 +1134,7 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
         (table_dtype != HAN_DTYPE_F32 && table_dtype != HAN_DTYPE_BF16))
         return HAN_E_UNSUPPORTED;
     if (in_drop < 0.f || in_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
-    if (N == 0) return 0;
+    if ((flags & HAN_FLAG_K1_EXACT_PIPE) && (flags & HAN_FLAG_K1_MATRIX_PIPE)) return HAN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     ProjFwdArgs a;
     a.X = X; a.ldx = ldx; a.W = W; a.H = H; a.N = N; a.F = F;
@@ -923,6 +1144,7 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
     a.thr_fts = fts_drop > 0.f ? han_keep_threshold(1.f - fts_drop) : HAN_KEEP_ALL;
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
+    a.keep = in_drop > 0.f ? keep : nullptr;
     const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & (a.x_bf16 ? 7 : 15)) == 0);
     int mt, nsplit;
     fwd_geometry(N, F, &mt, &nsplit, &a.f_chunk);
@@ -934,26 +1156,37 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
         a.partial = (float *)workspace;
     }
     // bf16 x 6 matrix-pipe kernel (fp32-class accuracy, see project_fwd_b6_kernel): whole-F blocks of 128
-    // rows with 16-byte X loads; with dropout it is built for the reference head shape (8 x 8)
-    const char *b6env = getenv("HAN_K1_B6");
+    // rows with 16-byte X loads; with dropout it is built for the reference head shape (8 x 8).
     // Used for the training forward (measured at SYN-1M in one process: 0.77 ms against 0.96 ms for the
     // exact-fp32 kernel); without dropout both take the same time (0.48 / 0.50 ms: staging-latency bound), so
-    // the eval forward stays on the exact-fp32 pipe unless HAN_K1_B6=1 asks for this kernel.  (A wave-local
-    // variant -- no LDS staging of X, no barrier per K-step, W chunks of 128 k in LDS -- measured the same:
-    // 0.49 / 0.80 ms against 0.46 / 0.78 ms for this one, eval / training, kernel_bench.py k1.)
+    // the eval forward stays on the exact-fp32 pipe unless HAN_FLAG_K1_MATRIX_PIPE asks for this kernel.  (A
+    // wave-local variant -- no LDS staging of X, no barrier per K-step, W chunks of 128 k in LDS -- measured the
+    // same: 0.49 / 0.80 ms against 0.46 / 0.78 ms for this one, eval / training, kernel_bench.py k1.)
     // bf16 features are their own high term (no split, three products instead of six): there the matrix-pipe
     // kernel is also the faster eval forward
-    const bool b6_want = (in_drop > 0.f || a.x_bf16) ? !(b6env && b6env[0] == '0') : (b6env && b6env[0] == '1');
+    const bool b6_want = (in_drop > 0.f || a.x_bf16) ? !(flags & HAN_FLAG_K1_EXACT_PIPE) : (flags & HAN_FLAG_K1_MATRIX_PIPE) != 0;
     const bool b6 = vec && nsplit == 1 && N >= 64 * 256 && (in_drop == 0.f || (K == 8 && FP == 8)) && b6_want;
+    if (a.keep && !(b6 && keep_table_shape(N, F, ldx, K, FP))) return HAN_E_BADARG;   // no kernel writes a table here
     if (b6) {
         const dim3 g6((unsigned)((N + B6_ROWS - 1) / B6_ROWS));
+#define HAN_LAUNCH_B6(D_, X_, K_)                                                               \
+    do {                                                                                        \
+        if (flags & HAN_FLAG_K1_4WAVE) project_fwd_b6_kernel<D_, X_, K_, 4><<<g6, 256, 0, st>>>(a); \
+        else project_fwd_b6_kernel<D_, X_, K_, 8><<<g6, 512, 0, st>>>(a);                       \
+    } while (0)
         if (in_drop > 0.f) {
-            if (a.x_bf16) project_fwd_b6_kernel<true, true><<<g6, 256, 0, st>>>(a);
-            else project_fwd_b6_kernel<true, false><<<g6, 256, 0, st>>>(a);
+            if (a.keep) {
+                if (a.x_bf16) HAN_LAUNCH_B6(true, true, true);
+                else HAN_LAUNCH_B6(true, false, true);
+            } else {
+                if (a.x_bf16) HAN_LAUNCH_B6(true, true, false);
+                else HAN_LAUNCH_B6(true, false, false);
+            }
         } else {
-            if (a.x_bf16) project_fwd_b6_kernel<false, true><<<g6, 256, 0, st>>>(a);
-            else project_fwd_b6_kernel<false, false><<<g6, 256, 0, st>>>(a);
+            if (a.x_bf16) HAN_LAUNCH_B6(false, true, false);
+            else HAN_LAUNCH_B6(false, false, false);
         }
+#undef HAN_LAUNCH_B6
         HAN_CHECK_LAUNCH();
     }
     const dim3 grid((unsigned)((N + 64 * mt - 1) / (64 * mt)), (unsigned)nsplit);
@@ -981,8 +1214,10 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
     s.H = H; s.a1 = a1; s.a2 = a2; s.b1 = b1; s.b2 = b2; s.f1 = f1; s.f2 = f2;
     s.N = N;
     const int sgrid = han_grid_for(N, 16, 256 * 8);
+    // the lane map of the scores follows the head width for both storage types (a bf16 table with F' != 8 through the
+    // 8 x 8 instantiation wrote f1 / f2 out of bounds for K < 8 and a wrong layout for K = 16)
     if (a.h_bf16) {
-        project_scores_kernel<8, true><<<sgrid, 256, 0, st>>>(s);
+        HAN_DISPATCH_FP(FP, { project_scores_kernel<FPC, true><<<sgrid, 256, 0, st>>>(s); })
     } else {
         HAN_DISPATCH_FP(FP, { project_scores_kernel<FPC, false><<<sgrid, 256, 0, st>>>(s); })
     }
@@ -999,7 +1234,8 @@ extern "C" size_t han_project_bwd_workspace(int64_t N, int F, int K, int FP) {
 
 extern "C" int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const float *dH, float *dW, void *workspace,
                                size_t workspace_bytes, int64_t N, int F, int K, int FP, float in_drop,
-                               uint64_t seed, const uint64_t *seed_dev, int64_t row_offset, void *stream) {
+                               uint64_t seed, const uint64_t *seed_dev, int64_t row_offset, const uint8_t *keep,
+                               void *stream) {
     if (!X || !dH || !dW || !workspace || N < 0 || F <= 0 || ldx < F) return HAN_E_BADARG;
     if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
     if (x_dtype != HAN_DTYPE_F32 && x_dtype != HAN_DTYPE_BF16) return HAN_E_UNSUPPORTED;
@@ -1008,16 +1244,32 @@ extern "C" int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const fl
     hipStream_t st = (hipStream_t)stream;
     int ftiles; int64_t rpc, nch;
     bwd_geometry(N, F, &ftiles, &rpc, &nch);
+    const bool x_bf16 = x_dtype == HAN_DTYPE_BF16;
+    // 16-byte fp32 / 8-byte bf16 X loads (the scalar path costs 1.7x at SYN-10M: 14.3 vs 8.4 ms per launch)
+    const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & (x_bf16 ? 7 : 15)) == 0);
+    if (keep && in_drop > 0.f && !(vec && keep_table_shape(N, F, ldx, K, FP) && ((uintptr_t)keep & 7) == 0))
+        return HAN_E_BADARG;      // a table exists only for the shapes han_project_keep_bytes() names
+    const int width = F * HAN_D;
+    if (keep && in_drop > 0.f && N > 0) {
+        // the 16-block 4x4x1 kernel: the forward's keep words are the A operand's lane masks (no draw is regenerated)
+        ProjBwdBlkArgs b;
+        b.X = X; b.ldx = ldx; b.dH = dH; b.keep = keep; b.slab = (float *)workspace; b.N = N; b.F = F;
+        b.rows_per_chunk = rpc; b.inv_keep_in = 1.f / (1.f - in_drop);
+        const dim3 gb((unsigned)((F + DW_FB - 1) / DW_FB), (unsigned)nch);
+        if (x_bf16) project_bwd_blk_kernel<true, true><<<gb, 256, 0, st>>>(b);
+        else project_bwd_blk_kernel<true, false><<<gb, 256, 0, st>>>(b);
+        HAN_CHECK_LAUNCH();
+        hipError_t e = han_reduce_slabs((const float *)workspace, (int)nch, width, width, han_reduce_to(dW, width), st);
+        return e != hipSuccess ? (int)e : 0;
+    }
     ProjBwdArgs a;
-    a.X = X; a.x_bf16 = x_dtype == HAN_DTYPE_BF16; a.ldx = ldx; a.dH = dH; a.slab = (float *)workspace; a.N = N; a.F = F;
+    a.X = X; a.x_bf16 = x_bf16; a.ldx = ldx; a.dH = dH; a.slab = (float *)workspace; a.N = N; a.F = F;
     a.rows_per_chunk = rpc;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : HAN_KEEP_ALL;
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
     dim3 grid(ftiles, (unsigned)nch);
-    // 16-byte fp32 / 8-byte bf16 X loads (the scalar path costs 1.7x at SYN-10M: 14.3 vs 8.4 ms per launch)
-    const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & (a.x_bf16 ? 7 : 15)) == 0);
     // (dW on the bf16 x 6 matrix pipe was built and measured in round 2 -- coalesced loads + on-chip transpose:
     // 0.55 ms without / 0.83 ms with dropout against 0.41 / 0.84 ms for this exact-fp32 kernel at SYN-1M --
     // and not kept: the transposition of both operands through LDS costs what the shorter matrix time saves.)
@@ -1031,7 +1283,6 @@ extern "C" int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const fl
         }
     })
     HAN_CHECK_LAUNCH();
-    const int width = F * HAN_D;
     hipError_t e = han_reduce_slabs((const float *)workspace, (int)nch, width, width, han_reduce_to(dW, width), st);
     if (e != hipSuccess) return (int)e;
     return 0;

@@ -28,7 +28,6 @@
 //
 // Roofline: MFMA fp32 (155 TF): forward 2*R*64*A flop = 65.5 GF at N = 1M, P = 4
 // (0.42 ms at peak), backward 3x that; the M / Z / dM streams are 1-2 GB (HBM, ~0.3 ms).
-#include <stdlib.h>
 #include "han_common.h"
 
 namespace {
@@ -1402,15 +1401,14 @@ size_t bwd_lds() {
 
 template <int CA>
 int launch_fwd(const float *M, const float *w, const float *b, const float *u, float *Z, float *beta,
-               int64_t N, int P, hipStream_t st) {
+               int64_t N, int P, int flags, hipStream_t st) {
     const size_t lds = fwd_lds<CA>();
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)sem_attn_fwd_kernel<CA>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    const char *b6env = getenv("HAN_K3_B6");
-    if ((P == 1 || P == 2 || P == 4 || P == 8 || P == 16) && N * P >= 64 * 1024 && !(b6env && b6env[0] == '0')) {
+    if ((P == 1 || P == 2 || P == 4 || P == 8 || P == 16) && N * P >= 64 * 1024 && !(flags & HAN_FLAG_K3_EXACT_PIPE)) {
         // large inputs: the contraction on the bf16 matrix pipe (exact 3-way split, fp32-class accuracy)
         const size_t blds = (size_t)3 * 64 * CA * SA_WLDB;
         const int grid = han_grid_for(N * P, 64, 256 * 2);
@@ -1452,13 +1450,12 @@ int launch_fwd(const float *M, const float *w, const float *b, const float *u, f
 
 template <int CA>
 int launch_bwd(const float *M, const float *w, const float *b, const float *u, const float *beta,
-               const float *dZ, float *dM, float *slab, int64_t N, int P, int *grid_out, hipStream_t st) {
+               const float *dZ, float *dM, float *slab, int64_t N, int P, int *grid_out, int flags, hipStream_t st) {
     const size_t lds = bwd_lds<CA>();
     hipError_t e = hipFuncSetAttribute((const void *)sem_attn_bwd_kernel<CA>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    const char *b6env = getenv("HAN_K3_B6");
-    if ((P == 1 || P == 2 || P == 4 || P == 8 || P == 16) && N * P >= 64 * 1024 && !(b6env && b6env[0] == '0')) {
+    if ((P == 1 || P == 2 || P == 4 || P == 8 || P == 16) && N * P >= 64 * 1024 && !(flags & HAN_FLAG_K3_EXACT_PIPE)) {
         const int grid = han_grid_for(N * P, 64, kSemBwdBlocks);
         *grid_out = grid;
         constexpr int A6 = 64 * CA;
@@ -1545,7 +1542,7 @@ int launch_bwd_gen(const float *M, const float *w, const float *b, const float *
 
 extern "C" int han_sem_attn_fwd(const float *M, const float *w_omega, const float *b_omega,
                                 const float *u_omega, float *Z, float *beta, int64_t N, int P, int D, int A,
-                                void *stream) {
+                                int flags, void *stream) {
     if (N == 0) return 0;   // nothing to do; row pointers of empty tensors may be null
     if (!M || !w_omega || !b_omega || !u_omega || !Z || !beta || N < 0 || P <= 0) return HAN_E_BADARG;
     if ((D != 64 && D != 128) || P > 64 || (A != 64 && A != 128)) return HAN_E_UNSUPPORTED;
@@ -1555,8 +1552,8 @@ extern "C" int han_sem_attn_fwd(const float *M, const float *w_omega, const floa
         if (A == 64) return launch_fwd_gen<1, 8>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
         return launch_fwd_gen<2, 8>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
     }
-    if (A == 64) return launch_fwd<1>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
-    return launch_fwd<2>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
+    if (A == 64) return launch_fwd<1>(M, w_omega, b_omega, u_omega, Z, beta, N, P, flags, st);
+    return launch_fwd<2>(M, w_omega, b_omega, u_omega, Z, beta, N, P, flags, st);
 }
 
 extern "C" size_t han_sem_attn_bwd_workspace(int64_t N, int P, int D, int A) {
@@ -1567,7 +1564,7 @@ extern "C" size_t han_sem_attn_bwd_workspace(int64_t N, int P, int D, int A) {
 extern "C" int han_sem_attn_bwd(const float *M, const float *w_omega, const float *b_omega,
                                 const float *u_omega, const float *beta, const float *dZ, float *dM,
                                 float *dw_omega, float *db_omega, float *du_omega, void *workspace,
-                                size_t workspace_bytes, int64_t N, int P, int D, int A, void *stream) {
+                                size_t workspace_bytes, int64_t N, int P, int D, int A, int flags, void *stream) {
     if (!M || !w_omega || !b_omega || !u_omega || !beta || !dZ || !dM || !dw_omega || !db_omega || !du_omega ||
         !workspace || N < 0 || P <= 0)
         return HAN_E_BADARG;
@@ -1579,8 +1576,8 @@ extern "C" int han_sem_attn_bwd(const float *M, const float *w_omega, const floa
     int rc;
     if (D == 128) rc = launch_bwd_gen<8>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, A, &grid, st);
     else rc = (A == 64)
-                 ? launch_bwd<1>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, &grid, st)
-                 : launch_bwd<2>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, &grid, st);
+                 ? launch_bwd<1>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, &grid, flags, st)
+                 : launch_bwd<2>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, &grid, flags, st);
     if (rc != 0) return rc;
     const int width = D * A + 2 * A;
     HanReduceOut o = han_reduce_to(dw_omega, width);

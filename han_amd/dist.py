@@ -94,7 +94,7 @@ class NodePartition:
         colptr = torch.zeros(self.n_local + 1, dtype=torch.int64, device=dev)
         torch.cumsum(counts, 0, out=colptr[1:])
         vals = g.values[sel][order].contiguous() if g.values is not None else None
-        return rows_local, CSRGraph(colptr, rowidx, self.n_table, validate=False, values=vals)
+        return rows_local, CSRGraph(colptr, rowidx, self.n_table, validate=False, values=vals, row_base=self.row_start)
 
     def shard_local_graph(self, rows_local: CSRGraph) -> tuple[CSRGraph, CSRGraph]:
         """rows_local: CSR of THIS rank's destination rows [row_start, row_end) with GLOBAL column ids.
@@ -108,7 +108,7 @@ class NodePartition:
             raise ValueError(f"expected this rank's {self.n_local} rows, got {rows_local.n_rows}")
         dev = rows_local.device
         rows_local = CSRGraph(rows_local.rowptr, rows_local.colidx, self.n_table, validate=False,
-                              values=rows_local.values)
+                              values=rows_local.values, row_base=self.row_start)
         col = rows_local.colidx
         if col.numel() and (int(col.min()) < 0 or int(col.max()) >= self.n_global):
             raise ValueError("rows_local.colidx must hold global node ids")
@@ -141,7 +141,7 @@ class NodePartition:
         colptr = torch.zeros(self.n_local + 1, dtype=torch.int64, device=dev)
         torch.cumsum(counts, 0, out=colptr[1:])
         cols_local = CSRGraph(colptr, rowidx, self.n_table, validate=False,
-                              values=vals[order2].contiguous() if vals is not None else None)
+                              values=vals[order2].contiguous() if vals is not None else None, row_base=self.row_start)
         return rows_local, cols_local
 
     def local_rows(self, t: torch.Tensor) -> torch.Tensor:
@@ -338,4 +338,4 @@ def _row_block(g: CSRGraph, r0: int, r1: int, n_cols: int) -> CSRGraph:
     rp = g.rowptr[r0:r1 + 1]
     s, e = int(rp[0]), int(rp[-1])
     return CSRGraph((rp - rp[0]).contiguous(), g.colidx[s:e].contiguous(), n_cols, validate=False,
-                    values=g.values[s:e].contiguous() if g.values is not None else None)
+                    values=g.values[s:e].contiguous() if g.values is not None else None, row_base=r0)

@@ -31,7 +31,7 @@ class CSRGraph:
     """
 
     def __init__(self, rowptr: torch.Tensor, colidx: torch.Tensor, n_cols: int | None = None,
-                 validate: bool = True, values: torch.Tensor | None = None):
+                 validate: bool = True, values: torch.Tensor | None = None, row_base: int = 0):
         if rowptr.dtype != torch.int64 or colidx.dtype != torch.int32:
             raise ValueError("rowptr must be int64 and colidx int32")
         if rowptr.dim() != 1 or colidx.dim() != 1 or rowptr.numel() < 1:
@@ -48,6 +48,9 @@ class CSRGraph:
                 raise ValueError("values must be (nnz,) on the graph's device")
             values = values.to(torch.float32).contiguous()
         self.values = values
+        # id, in the numbering of the columns, of row 0: the row / transposed shards of a node partition hold
+        # local rows [0, n_local) against global column ids (has_locality compares like with like)
+        self.row_base = int(row_base)
         self._t = None
         self._split = {}
         self._locality = None
@@ -84,7 +87,7 @@ class CSRGraph:
                 step = max(1, self.nnz // 2_000_000)
                 pos = torch.arange(0, self.nnz, step, device=self.device)
                 rows = torch.searchsorted(self.rowptr, pos, right=True) - 1
-                dist = (self.colidx[pos].long() - rows).abs().double().mean()
+                dist = (self.colidx[pos].long() - (rows + self.row_base)).abs().double().mean()
                 self._locality = bool(float(dist) < 0.05 * max(self.n_cols, 1))
         return self._locality
 
@@ -93,7 +96,7 @@ class CSRGraph:
 
     def to(self, device) -> "CSRGraph":
         g = CSRGraph(self.rowptr.to(device), self.colidx.to(device), self.n_cols, validate=False,
-                     values=self.values.to(device) if self.values is not None else None)
+                     values=self.values.to(device) if self.values is not None else None, row_base=self.row_base)
         return g
 
     # ---- row splitting for skewed degree distributions ---------------------------

@@ -102,12 +102,12 @@ class NodeLevelAttention(torch.autograd.Function):
         plans_f = cfg.get("plans_f") if multi else None      # per meta-path HaloPlan or None
         # all projections first, each table's all-gather started as soon as it exists:
         # the exchange of meta-path p+1.. overlaps the node attention of meta-path p
-        proj = []
+        proj, proj_keep = [], []
         xs_full = cfg.get("xs_full") if (multi and Xin is None) else None
         for p in range(P):
             seed = int(cfg["seeds"][p])
             plan = plans_f[p] if plans_f is not None else None
-            handle = None
+            handle = keep = None
             if xs_full is not None and plan is None:
                 # replicated projection: every rank holds the features of ALL rows and projects the whole
                 # table itself instead of receiving (G-1)/G of it -- a point-to-point xGMI link moves a
@@ -121,10 +121,12 @@ class NodeLevelAttention(torch.autograd.Function):
                 H, f1, f2 = Hf[r0:r1], f1f[r0:r1], f2f[r0:r1]
                 handle = _Ready(Hf)
             else:
-                H, f1, f2 = ops.project_fwd(xs[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
-                                            fts_drop=in_drop, seed=seed, row_offset=row_offset,
-                                            table_dtype=cfg.get("table_dtype", torch.float32),
-                                            seed_dev=seed_dev)
+                # training: the forward also writes the keep table of its per-head input dropout, which dW
+                # reads instead of regenerating the draws (None for shapes without a table)
+                H, f1, f2, keep = ops.project_fwd(xs[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
+                                                  fts_drop=in_drop, seed=seed, row_offset=row_offset,
+                                                  table_dtype=cfg.get("table_dtype", torch.float32),
+                                                  seed_dev=seed_dev, want_keep=True)
             if multi and handle is None:      # halo rows only (HaloPlan) or the whole shard (all-gather)
                 tag = ("f", cfg.get("layer", 0), cfg.get("group", 0), p)   # persistent exchange table of this (layer, head group, meta-path)
                 handle = plan.exchange_async(H, tag) if plan is not None else part.all_gather_rows_async(H, tag)
@@ -140,6 +142,7 @@ class NodeLevelAttention(torch.autograd.Function):
                                           fts_drop=0.0, seed=seed, row_offset=row_offset, seed_dev=seed_dev)
                 R = R + br[p]
             proj.append((H, f1, f2, handle, R))
+            proj_keep.append(keep)
         for p in range(P):
             H, f1, f2, handle, R = proj[p]
             H_tab = handle.wait() if multi else H
@@ -151,7 +154,7 @@ class NodeLevelAttention(torch.autograd.Function):
                                       table_gid=plan.gid if plan is not None else None, res=R,
                                       seed_dev=seed_dev)
             if train:
-                saved.append((H, f1, f2) + sv + (R,))
+                saved.append((H, f1, f2) + sv + (R, proj_keep[p]))
         del proj
         ctx.cfg, ctx.xs, ctx.graphs = cfg, xs, graphs
         ctx.xin_shape = tuple(Xin.shape) if Xin is not None else None
@@ -199,7 +202,7 @@ class NodeLevelAttention(torch.autograd.Function):
         rows = []
         dres_in = []
         for p in range(P):      # row-local halves first; their tables go out while we continue
-            H, f1, f2, pre, lse, aggp, tsum, R = ctx.saved_per_p[p]
+            H, f1, f2, pre, lse, aggp, tsum, R, _keep = ctx.saved_per_p[p]
             gs, df1, dcp = ops.node_attn_bwd_rows(dM[:, p, :], pre, aggp, tsum, f1, lse, c[p],
                                                   activation=cfg["act"], K=K, FP=FP,
                                                   table_dtype=H.dtype, res=R, dc_out=dc[p])
@@ -220,7 +223,7 @@ class NodeLevelAttention(torch.autograd.Function):
             else:
                 rows.append((gs, df1))
         for p in range(P):
-            H, f1, f2, pre, lse, aggp, tsum, R = ctx.saved_per_p[p]
+            H, f1, f2, pre, lse, aggp, tsum, R, keep = ctx.saved_per_p[p]
             seed = int(cfg["seeds"][p])
             gs_h, df1 = rows[p]
             gs_tab = gs_h.wait() if multi else gs_h
@@ -234,7 +237,7 @@ class NodeLevelAttention(torch.autograd.Function):
             rows[p] = None
             ops.score_param_bwd(H, df1, df2, K=K, FP=FP, out=(da1[p], da2[p], db1[p], db2[p]))
             ops.project_bwd(xs[p], dH, K, FP, in_drop=ctx.in_drop, seed=seed,
-                            row_offset=row_offset, seed_dev=seed_dev, out=dW[p])
+                            row_offset=row_offset, seed_dev=seed_dev, out=dW[p], keep=keep)
             if dXin is not None:
                 ops.project_bwd_input(dH, W[p], K, FP, out=dXin[:, p, :], in_drop=ctx.in_drop,
                                       seed=seed, row_offset=row_offset, seed_dev=seed_dev)

@@ -16,6 +16,10 @@ from .graph import CSRGraph
 ACT_IDENTITY = 0
 ACT_ELU = 1
 FLAG_XCD_ORDER = 1         # HAN_FLAG_XCD_ORDER: XCD-aware work order for graphs with locality
+FLAG_K1_EXACT_PIPE = 2     # HAN_FLAG_K1_EXACT_PIPE / _MATRIX_PIPE: force one of the two K1 forward kernels (tests, measurements)
+FLAG_K1_MATRIX_PIPE = 4
+FLAG_K1_4WAVE = 16         # HAN_FLAG_K1_4WAVE (measurements: the two-waves-per-SIMD form of the bf16 x 6 kernel)
+FLAG_K3_EXACT_PIPE = 8     # HAN_FLAG_K3_EXACT_PIPE: fp32 MFMA K3 kernels also for large inputs
 LEAKY_SLOPE = 0.2          # tf.nn.leaky_relu default (utils/layers.py:27)
 D = 64                     # K * F' of this build
 STATS_ROW_BYTES = 128      # per destination row: the (f1, lse, s, 0) records of the K = 8 heads inside the fused gs row (bench.py byte model)
@@ -135,12 +139,15 @@ def _check_drop(p: float, name: str):
 
 # --------------------------------------------------------------------------- K1
 def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_offset=0,
-                table_dtype=torch.float32, seed_dev=None):
+                table_dtype=torch.float32, seed_dev=None, flags=0, want_keep=False):
     """utils/layers.py:18-24,31-32 for the K heads of one meta-path.
     X (N,F) fp32 or bf16 [row stride >= F]; W (F,D); a1,a2 (K,F'); b1,b2 (K,).
     H is stored in `table_dtype` (float32 or bfloat16; f1/f2 come from the stored rows).
     Returns H (N,D), f1 (N,K), f2 (N,K).  With fts_drop > 0 the keep bit of the
-    projected-row dropout rides in mantissa bit 0 of every H element."""
+    projected-row dropout rides in mantissa bit 0 of every H element.
+    want_keep=True returns a 4th value: the keep table of the per-head input dropout for
+    project_bwd (uint8, han_project_keep_bytes() long), or None when this shape has none
+    (small inputs, in_drop == 0, head shapes other than 8 x 8): dW then regenerates the draws."""
     lib = _lib.load()
     if X.dim() != 2:
         raise ValueError(f"X: expected (N,F), got {tuple(X.shape)}")
@@ -166,17 +173,27 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
     f2 = torch.empty((N, K), dtype=torch.float32, device=dev)
     nbytes = lib.han_project_fwd_workspace(N, F, K, FP)      # > 0 only for short inputs (split-F)
     ws = _ws(nbytes, dev, "projf") if nbytes else None
+    ldx = X.stride(0) if N > 1 else max(F, X.stride(0))
+    keep = None
+    if want_keep and in_drop > 0 and not (flags & FLAG_K1_EXACT_PIPE) and X.data_ptr() % 16 == 0:
+        kb = lib.han_project_keep_bytes(N, F, ldx, K, FP)
+        if kb:
+            keep = torch.empty(kb, dtype=torch.uint8, device=dev)
     _lib.check(lib.han_project_fwd(
-        X.data_ptr(), xcode, X.stride(0) if N > 1 else max(F, X.stride(0)), W.data_ptr(), a1.data_ptr(),
+        X.data_ptr(), xcode, ldx, W.data_ptr(), a1.data_ptr(),
         a2.data_ptr(), b1.data_ptr(), b2.data_ptr(), H.data_ptr(), DTYPE_CODE[table_dtype],
         f1.data_ptr(), f2.data_ptr(), ws.data_ptr() if ws is not None else None,
         ws.numel() if ws is not None else 0, N, F, K, FP,
-        in_drop, fts_drop, int(seed), _dev_word(seed_dev), int(row_offset), _stream()), "han_project_fwd")
+        in_drop, fts_drop, int(seed), _dev_word(seed_dev), int(row_offset),
+        keep.data_ptr() if keep is not None else None, int(flags), _stream()), "han_project_fwd")
+    if want_keep:
+        return H, f1, f2, keep
     return H, f1, f2
 
 
-def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0, seed_dev=None, out=None):
-    """dW (F,D) = dropout_k(X)^T dH (written to `out` when given)."""
+def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0, seed_dev=None, out=None, keep=None):
+    """dW (F,D) = dropout_k(X)^T dH (written to `out` when given).  keep: the table project_fwd(want_keep=True)
+    returned for the same X / seed (the draws are then read, not regenerated), or None."""
     lib = _lib.load()
     _chk(X, "X", contiguous=False, dtype=X.dtype)
     xcode = _dtype_code(X, "X")
@@ -186,10 +203,13 @@ def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0, seed_dev=None, 
     dW = _out(out, "out", (F, D), X.device)
     nbytes = lib.han_project_bwd_workspace(N, F, K, FP)
     ws = _ws(nbytes, X.device, "proj")
+    ldx = X.stride(0) if N > 1 else max(F, X.stride(0))
+    if keep is not None:
+        _chk(keep, "keep", (lib.han_project_keep_bytes(N, F, ldx, K, FP),), dtype=torch.uint8, device=X.device)
     _lib.check(lib.han_project_bwd(
-        X.data_ptr(), xcode, X.stride(0) if N > 1 else max(F, X.stride(0)), dH.data_ptr(), dW.data_ptr(),
+        X.data_ptr(), xcode, ldx, dH.data_ptr(), dW.data_ptr(),
         ws.data_ptr(), ws.numel(), N, F, K, FP, _check_drop(in_drop, "in_drop"), int(seed), _dev_word(seed_dev),
-        int(row_offset), _stream()), "han_project_bwd")
+        int(row_offset), keep.data_ptr() if keep is not None else None, _stream()), "han_project_bwd")
     return dW
 
 
@@ -428,7 +448,7 @@ def score_param_bwd(H, df1, df2, K=8, FP=8, out=None):
 
 
 # --------------------------------------------------------------------------- K3
-def sem_attn_fwd(M, w_omega, b_omega, u_omega):
+def sem_attn_fwd(M, w_omega, b_omega, u_omega, flags=0):
     """utils/layers.py:152-159.  M (N,P,D) -> Z (N,D), beta (N,P)."""
     lib = _lib.load()
     _chk(M, "M")
@@ -444,11 +464,11 @@ def sem_attn_fwd(M, w_omega, b_omega, u_omega):
     beta = torch.empty((N, P), dtype=torch.float32, device=dev)
     _lib.check(lib.han_sem_attn_fwd(M.data_ptr(), w_omega.data_ptr(), b_omega.data_ptr(),
                                     u_omega.data_ptr(), Z.data_ptr(), beta.data_ptr(), N, P, Dm, A,
-                                    _stream()), "han_sem_attn_fwd")
+                                    int(flags), _stream()), "han_sem_attn_fwd")
     return Z, beta
 
 
-def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ, out=None):
+def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ, out=None, flags=0):
     """dM, dw, db, du [the last three written to the tensors of `out` when given]."""
     lib = _lib.load()
     N, P, Dm = M.shape
@@ -466,7 +486,7 @@ def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ, out=None):
     _lib.check(lib.han_sem_attn_bwd(
         M.data_ptr(), w_omega.data_ptr(), b_omega.data_ptr(), u_omega.data_ptr(), beta.data_ptr(),
         dZ.data_ptr(), dM.data_ptr(), dw.data_ptr(), db.data_ptr(), du.data_ptr(), ws.data_ptr(),
-        ws.numel(), N, P, Dm, A, _stream()), "han_sem_attn_bwd")
+        ws.numel(), N, P, Dm, A, int(flags), _stream()), "han_sem_attn_bwd")
     return dM, dw, db, du
 
 

@@ -58,17 +58,31 @@ def bfs_order(graphs, start: int | None = None) -> torch.Tensor:
     """Breadth-first (Cuthill-McKee style) order over the union of the meta-path graphs: perm[new] = old.
     Levels are expanded on the graphs' device with tensor ops; inside a level nodes keep the order of
     their first discoverer (neighbours of one node stay adjacent), components are taken in order of their
-    smallest unvisited id, isolated nodes last within their turn."""
+    smallest unvisited id.  Nodes without any neighbour but themselves (real meta-path graphs have many) are
+    not walked one by one: they are appended at the end in id order, as one batch; and the next component's
+    seed is found with a monotone cursor over the ids (one small slice per lookup), not a pass over all n."""
     g0 = graphs[0]
     n, dev = g0.n_rows, g0.device
-    visited = torch.zeros(n, dtype=torch.bool, device=dev)
+    ids = torch.arange(n, device=dev)
+    has_nb = torch.zeros(n, dtype=torch.bool, device=dev)
+    for g in graphs:
+        rows = torch.repeat_interleave(ids, g.degrees())
+        has_nb[rows[g.colidx.long() != rows]] = True
+    isolated = torch.nonzero(~has_nb).flatten()
+    visited = ~has_nb                       # isolated nodes are placed at the end
     order = []
-    done = 0
+    done = int(isolated.numel())
+    cursor, chunk = 0, 1 << 16
     next_seed = 0 if start is None else int(start)
     while done < n:
         if visited[next_seed]:
-            rest = torch.nonzero(~visited).flatten()
-            next_seed = int(rest[0])
+            while True:                     # smallest unvisited id >= cursor (ids below it are all visited)
+                rest = torch.nonzero(~visited[cursor:cursor + chunk]).flatten()
+                if rest.numel():
+                    next_seed = cursor + int(rest[0])
+                    cursor = next_seed
+                    break
+                cursor += chunk
         frontier = torch.tensor([next_seed], dtype=torch.int64, device=dev)
         visited[frontier] = True
         while frontier.numel():
@@ -89,6 +103,7 @@ def bfs_order(graphs, start: int | None = None) -> torch.Tensor:
             first.scatter_reduce_(0, inverse, torch.arange(c.numel(), device=dev), reduce="amin")
             frontier = uniq[torch.sort(first).indices]
             visited[frontier] = True
+    order.append(isolated)
     return torch.cat(order)
 
 

@@ -33,7 +33,9 @@ def _row_range(n, rows):
 
 
 def _blocks(r0, r1):
-    """(block id, first row, last row + 1, slice within the block) for the blocks overlapping [r0, r1)."""
+    """(block id, first row, last row + 1) -- the rows as offsets inside the block -- for the 65 536-row
+    blocks overlapping [r0, r1).  (Block-seeded generation dates from round 2: bench lines of round 1 were
+    produced by a different generator and are not comparable row for row.)"""
     for b in range(r0 // ROW_BLOCK, (r1 + ROW_BLOCK - 1) // ROW_BLOCK if r1 > r0 else r0 // ROW_BLOCK):
         lo, hi = b * ROW_BLOCK, (b + 1) * ROW_BLOCK
         yield b, max(lo, r0) - lo, min(hi, r1) - lo

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HAN_ABI_VERSION 3
+#define HAN_ABI_VERSION 4
 
 #define HAN_E_BADARG   (-1)   /* null pointer, negative size, inconsistent shape.  The forward
                               * entry points return 0 at once for N == 0 (empty tensors may
@@ -42,6 +42,16 @@ extern "C" {
                                   XCD a contiguous share of the rows in flight, so that the eight L2s cache eight
                                   different source windows.  Speed only; off for graphs without structure, where it
                                   measured 9 % slower in the HBM regime (eight separate index / output streams). */
+
+/* `flags` of han_project_fwd: which matrix pipe runs the projection (default 0: the library chooses --
+ * the bf16 x 6 kernel for training forwards and bf16 features, the exact-fp32 kernel otherwise).
+ * Both have fp32-class accuracy; the switches exist for measurements and tests.                     */
+#define HAN_FLAG_K1_EXACT_PIPE  2   /* v_mfma_f32_16x16x4_f32 kernels only                                 */
+#define HAN_FLAG_K1_MATRIX_PIPE 4   /* the bf16 x 6 kernel wherever it applies (also the fp32 eval forward) */
+#define HAN_FLAG_K1_4WAVE      16   /* measurements only: the round-2 form of the bf16 x 6 kernel (4 waves x 2 row tiles,
+                                       two waves per SIMD) instead of 8 waves x 1 tile (four per SIMD)                     */
+/* `flags` of han_sem_attn_fwd / han_sem_attn_bwd */
+#define HAN_FLAG_K3_EXACT_PIPE  8   /* fp32 MFMA kernels also for large inputs (default: bf16 x 6 from 65 536 rows) */
 
 /* storage type of X and of the gather tables H / g ("bf16 feats" of the 10M-node
  * config): everything is accumulated in fp32; any head shape (8 x 8 is the tuned one) */
@@ -75,19 +85,31 @@ const char *han_error_string(int code);
  * fewer 128-row tiles than CUs -- split the reduction over F and sum partial tiles
  * from it in a fixed order); may be NULL when that is 0.                            */
 size_t han_project_fwd_workspace(int64_t N, int F, int K, int FP);
+/* Keep table of the per-head input dropout (layers.py:18-19), written by the training forward and
+ * read by han_project_bwd so that dW does not regenerate the draws: N rows of F bytes (F % 8 == 0);
+ * the 8 bytes of features 8o .. 8o+7 of row n form one little-endian 64-bit word whose bit
+ *     32*q + 16*(k % 2) + 4*(k / 2) + i        (q = 0,1; i = 0..3; head k = 0..7)
+ * is 1 iff head k keeps feature f = 8o + 4q + i of row n -- i.e. the word IS the 64-lane mask of the
+ * dW kernel's v_mfma_f32_4x4x1_16B_f32 A operand.  han_project_keep_bytes() returns the size the
+ * caller allocates (N*F + 128 B of slack for the kernel's whole-tile mask loads), or 0 when this
+ * shape has no table (then pass NULL and the backward regenerates the draws from the seed):
+ * built for K == 8, FP == 8, F % 8 == 0, ldx % 4 == 0, N >= 32768 (the matrix-pipe forward).        */
+size_t han_project_keep_bytes(int64_t N, int F, int64_t ldx, int K, int FP);
 int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const float *W, const float *a1,
                     const float *a2, const float *b1, const float *b2, void *H,
                     int table_dtype, float *f1, float *f2, void *workspace,
                     size_t workspace_bytes, int64_t N, int F, int K, int FP,
                     float in_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset,
-                    void *stream);
+                    uint8_t *keep, int flags, void *stream);
 
-/* dW = Xk^T dH (per head dropout masks regenerated from the seed).
+/* dW = Xk^T dH.  keep: the table the forward of the SAME seed wrote (then no draw is regenerated), or
+ * NULL: per head dropout masks regenerated from the seed.
  * workspace: han_project_bwd_workspace() bytes, any contents.              */
 size_t han_project_bwd_workspace(int64_t N, int F, int K, int FP);
 int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const float *dH, float *dW,
                     void *workspace, size_t workspace_bytes, int64_t N, int F, int K,
-                    int FP, float in_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset, void *stream);
+                    int FP, float in_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset,
+                    const uint8_t *keep, void *stream);
 
 /* dX = sum_k mask_k/keep * (dH_k W_k^T): gradient w.r.t. the layer INPUT, needed only
  * for layers >= 1 of a multi-layer stack (models/gat.py:48-57).  dH (N,D); W (F,D);
@@ -209,7 +231,7 @@ int han_score_param_bwd(const void *H, int table_dtype, const float *df1, const 
  * M (N,P,D); Womega (D,A); bomega,uomega (A); Z (N,D); beta (N,P).          */
 int han_sem_attn_fwd(const float *M, const float *w_omega, const float *b_omega,
                      const float *u_omega, float *Z, float *beta, int64_t N, int P,
-                     int D, int A, void *stream);
+                     int D, int A, int flags, void *stream);
 
 /* dZ (N,D) -> dM (N,P,D), dWomega (D,A), dbomega (A), duomega (A).
  * beta is the forward's output.                                            */
@@ -217,7 +239,7 @@ size_t han_sem_attn_bwd_workspace(int64_t N, int P, int D, int A);
 int han_sem_attn_bwd(const float *M, const float *w_omega, const float *b_omega,
                      const float *u_omega, const float *beta, const float *dZ, float *dM,
                      float *dw_omega, float *db_omega, float *du_omega, void *workspace,
-                     size_t workspace_bytes, int64_t N, int P, int D, int A, void *stream);
+                     size_t workspace_bytes, int64_t N, int P, int D, int A, int flags, void *stream);
 
 /* ---- classifier + masked loss ----------------------------------------------
  * models/gat.py:65-72: logits = (1/HC) sum_h (Z Wc[h] + bc[h]);  Wc (HC,D,C).

@@ -32,7 +32,7 @@ def _rows_of(graph):
 
 
 def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_offset=0,
-                table_dtype=torch.float32, seed_dev=None):
+                table_dtype=torch.float32, seed_dev=None, flags=0, want_keep=False):
     seed = _eff(seed, seed_dev)
     N, F = X.shape
     K, FP = a1.shape
@@ -53,6 +53,8 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
     hk = _f64(H).view(N, K, FP)
     f1 = (hk * _f64(a1)[None]).sum(-1) + _f64(b1)
     f2 = (hk * _f64(a2)[None]).sum(-1) + _f64(b2)
+    if want_keep:       # the keep table exists for large inputs only: the host logic must cope with None
+        return H, f1.to(torch.float32), f2.to(torch.float32), None
     return H, f1.to(torch.float32), f2.to(torch.float32)
 
 
@@ -63,7 +65,7 @@ def _put(out, val):
     return out
 
 
-def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0, seed_dev=None, out=None):
+def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0, seed_dev=None, out=None, keep=None):
     seed = _eff(seed, seed_dev)
     N, F = X.shape
     x, d = _f64(X), _f64(dH)
@@ -228,14 +230,14 @@ def score_param_bwd(H, df1, df2, K=8, FP=8, out=None):
     return tuple(_put(o[i], res[i]) for i in range(4))
 
 
-def sem_attn_fwd(M, w_omega, b_omega, u_omega):
+def sem_attn_fwd(M, w_omega, b_omega, u_omega, flags=0):
     m = _f64(M)
     v = torch.tanh(m @ _f64(w_omega) + _f64(b_omega))
     beta = torch.softmax(v @ _f64(u_omega), dim=-1)
     return (m * beta[..., None]).sum(1).to(torch.float32), beta.to(torch.float32)
 
 
-def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ, out=None):
+def sem_attn_bwd(M, w_omega, b_omega, u_omega, beta, dZ, out=None, flags=0):
     m, w, b, u = (_f64(t).requires_grad_(True) for t in (M, w_omega, b_omega, u_omega))
     with torch.enable_grad():
         v = torch.tanh(m @ w + b)

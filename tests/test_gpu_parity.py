@@ -90,10 +90,8 @@ def test_project_matrix_pipe_kernel_fp32_class_accuracy(dev, n, f, xbf, variant,
     args = (xt, _t(W, dev), _t(a[0], dev), _t(a[1], dev), _t(a[2], dev), _t(a[3], dev))
     Href = x @ W.astype(np.float32).astype(np.float64)
     scale = np.abs(x) @ np.abs(W)                    # sum |x w|: what an fp32 dot product's error scales with
-    monkeypatch.setenv("HAN_K1_B6", "0")
-    H32, _, _ = ops.project_fwd(*args)
-    monkeypatch.setenv("HAN_K1_B6", variant)
-    H6, f1, f2 = ops.project_fwd(*args)
+    H32, _, _ = ops.project_fwd(*args, flags=ops.FLAG_K1_EXACT_PIPE)
+    H6, f1, f2 = ops.project_fwd(*args, flags=ops.FLAG_K1_MATRIX_PIPE)
     e32 = np.abs(H32.cpu().numpy() - Href) / scale
     e6 = np.abs(H6.cpu().numpy() - Href) / scale
     assert e6.max() < 4e-7, (e6.max(), e32.max())      # a few fp32 ulps of sum |x w|, like the fp32 pipe
@@ -109,7 +107,6 @@ def test_project_matrix_pipe_kernel_dropout_masks(dev, f, xbf, variant, monkeypa
     the A fragments) and the projected-row keep bits, against the NumPy-regenerated hash masks -- and
     bit-for-bit the same keep decisions as the fp32 kernel."""
     from han_amd import ops
-    monkeypatch.setenv("HAN_K1_B6", variant)
     n = 16384 + 130
     rng = np.random.default_rng(f)
     seed, drop, off = 0x0BADC0DE1234, 0.6, 977
@@ -151,6 +148,72 @@ def test_project_bwd_no_dropout(dev, n, f):
     x, dH = rng.standard_normal((n, f)), rng.standard_normal((n, 64))
     dW = ops.project_bwd(_t(x, dev), _t(dH, dev), 8, 8)
     assert rel_err(dW.cpu().numpy(), x.T @ dH) < 1e-4
+
+
+@pytest.mark.parametrize("n,f,xbf", [(32768 + 77, 256, False), (40000, 72, False), (33000, 264, True)])
+def test_project_keep_table_and_block_mfma_dw(dev, n, f, xbf):
+    """Round 3: the training forward writes the keep table of the per-head input dropout (one 64-bit word per
+    row and feature octet, bit order of han_hip.h) and dW reads it as the lane mask of its 4x4x1 16-block MFMA
+    A operand.  The table must hold exactly the regenerated hash draws, dW through it must equal the float64
+    product with those masks AND the hash-regenerating dW kernel (same draws, other kernel)."""
+    from han_amd import ops
+    rng = np.random.default_rng(n + f)
+    seed, drop, off = 0x5EED0000 + f, 0.6, 4242
+    x = rng.standard_normal((n, f))
+    W = rng.standard_normal((f, 64)) * 0.2
+    a = [rng.standard_normal((8, 8)) for _ in range(2)] + [rng.standard_normal(8) for _ in range(2)]
+    xt = _t(x, dev)
+    if xbf:
+        xt = xt.to(torch.bfloat16)
+        x = xt.to(torch.float32).cpu().numpy().astype(np.float64)
+    H, f1, f2, keep = ops.project_fwd(xt, _t(W, dev), _t(a[0], dev), _t(a[1], dev), _t(a[2], dev), _t(a[3], dev),
+                                      in_drop=drop, fts_drop=drop, seed=seed, row_offset=off, want_keep=True)
+    assert keep is not None and keep.numel() == n * f + 128
+    H0, _, _ = ops.project_fwd(xt, _t(W, dev), _t(a[0], dev), _t(a[1], dev), _t(a[2], dev), _t(a[3], dev),
+                               in_drop=drop, fts_drop=drop, seed=seed, row_offset=off)
+    assert torch.equal(H, H0)                                    # writing the table changes nothing else
+    sm = rng_ref.seq_mask(seed, n, f, 8, drop, row_offset=off)   # (8, n, f) 0/1
+    words = keep[:n * f].cpu().numpy().view("<u8").reshape(n, f // 8)
+    for k in range(8):
+        for q in range(2):
+            for i in range(4):
+                bit = 32 * q + 16 * (k % 2) + 4 * (k // 2) + i
+                got = ((words >> np.uint64(bit)) & np.uint64(1)).astype(np.float64)
+                assert np.array_equal(got, sm[k][:, 4 * q + i::8]), (k, q, i)
+    kp = rng_ref.keep_prob32(drop)
+    dH = rng.standard_normal((n, 64))
+    dW = ops.project_bwd(xt, _t(dH, dev), 8, 8, in_drop=drop, seed=seed, row_offset=off, keep=keep)
+    dWref = np.concatenate([(x / kp * sm[k]).T @ dH[:, 8 * k:8 * k + 8] for k in range(8)], 1)
+    assert rel_err(dW.cpu().numpy(), dWref) < 2e-6
+    dWh = ops.project_bwd(xt, _t(dH, dev), 8, 8, in_drop=drop, seed=seed, row_offset=off)
+    assert rel_err(dW.cpu().numpy(), dWh.cpu().numpy().astype(np.float64)) < 2e-6
+    # no table for small inputs / other head shapes: the wrapper returns None and dW regenerates the draws
+    assert ops.project_fwd(xt[:5000], _t(W, dev), _t(a[0], dev), _t(a[1], dev), _t(a[2], dev), _t(a[3], dev),
+                           in_drop=drop, seed=seed, want_keep=True)[3] is None
+
+
+@pytest.mark.parametrize("K,FP", [(4, 16), (16, 4), (2, 32)])
+@pytest.mark.parametrize("n,f,xbf", [(3000, 256, False), (16500, 64, True)])
+def test_bf16_table_scores_follow_the_head_width(dev, K, FP, n, f, xbf):
+    """with a bf16 H table the separate scores launch (split-F path: few rows, F >= 128; and
+    the matrix-pipe eval forward: bf16 features, N >= 16384) used the 8 x 8 lane map for every head shape --
+    out-of-bounds f1 / f2 writes for K < 8, a wrong layout for K = 16.  f1 / f2 against the rows as stored."""
+    from han_amd import ops
+    rng = np.random.default_rng(K * 1000 + n)
+    x = rng.standard_normal((n, f))
+    W = rng.standard_normal((f, 64)) * 0.2
+    a1, a2, b1, b2 = rng.standard_normal((K, FP)), rng.standard_normal((K, FP)), rng.standard_normal(K), rng.standard_normal(K)
+    xt = _t(x, dev).to(torch.bfloat16) if xbf else _t(x, dev)
+    H, f1, f2 = ops.project_fwd(xt, _t(W, dev), _t(a1, dev), _t(a2, dev), _t(b1, dev), _t(b2, dev),
+                                table_dtype=torch.bfloat16)
+    Hs = H.to(torch.float32).cpu().numpy().astype(np.float64).reshape(n, K, FP)
+    f1ref = (Hs * a1[None]).sum(-1) + b1
+    f2ref = (Hs * a2[None]).sum(-1) + b2
+    assert f1.shape == (n, K) and np.abs(f1.cpu().numpy() - f1ref).max() < 1e-4 * max(1.0, np.abs(f1ref).max())
+    assert np.abs(f2.cpu().numpy() - f2ref).max() < 1e-4 * max(1.0, np.abs(f2ref).max())
+    xf = xt.to(torch.float32).cpu().numpy().astype(np.float64)
+    Href = xf @ W.astype(np.float32).astype(np.float64)
+    assert np.abs(H.to(torch.float32).cpu().numpy() - Href).max() < 1e-2 * max(1.0, np.abs(Href).max())
 
 
 # ----------------------------------------------------------------------------- K2

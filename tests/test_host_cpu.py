@@ -676,6 +676,37 @@ def test_locality_pass_relabelling_roundtrip():
     rp = torch.tensor([0, 2, 4, 5, 7, 9], dtype=torch.int64)
     ci = torch.tensor([0, 1, 0, 1, 2, 3, 4, 3, 4], dtype=torch.int32)
     assert sorted(reorder.bfs_order([CSRGraph(rp, ci, 5)]).tolist()) == [0, 1, 2, 3, 4]
+    # many small components and isolated nodes (real meta-path graphs): still a permutation, every component
+    # contiguous, the nodes without a neighbour as one batch at the end in id order
+    m = 400
+    pairs = torch.randperm(m, generator=torch.Generator().manual_seed(5))[:300].reshape(150, 2)
+    adj = torch.eye(m, dtype=torch.bool)
+    adj[pairs[:, 0], pairs[:, 1]] = True
+    adj[pairs[:, 1], pairs[:, 0]] = True
+    gm = CSRGraph.from_bias(torch.where(adj, 0.0, -1e9)[None])
+    pm = reorder.bfs_order([gm]).tolist()
+    assert sorted(pm) == list(range(m))
+    lonely = sorted(set(range(m)) - set(pairs.flatten().tolist()))
+    assert pm[m - len(lonely):] == lonely
+    pos = {v: i for i, v in enumerate(pm)}
+    assert all(abs(pos[int(a)] - pos[int(b)]) == 1 for a, b in pairs)
+
+
+def test_shard_graphs_measure_locality_against_their_own_rows():
+    """CSRGraph.has_locality() on the shards of a node partition: rows are local (0..n_local), columns
+    global -- the estimate subtracts the shard's first row (row_base), so every rank decides alike."""
+    from han_amd import synth
+    from han_amd.dist import NodePartition
+    n = 4000
+    g = synth.banded_graph(n, 8, 20, 3)
+    assert g.has_locality()
+    for r in range(4):
+        part = NodePartition(n, r, 4)
+        rl, cl = part.shard_graph(g)
+        assert rl.row_base == part.row_start == cl.row_base
+        assert rl.has_locality() and cl.has_locality(), r
+    gr = synth.random_regular_graph(n, 10, 3)
+    assert not any(x.has_locality() for x in NodePartition(n, 3, 4).shard_graph(gr))
 
 
 def test_locality_pass_is_a_pure_relabelling_on_cpu_backend(cpu_ops):

@@ -82,12 +82,21 @@ def main():
         a1, a2, b1, b2 = rnd(8, 8), rnd(8, 8), rnd(8), rnd(8)
         dH = rnd(n, 64)
         fl = 2.0 * n * f * 64
+        fl_ = int(kv.get("flags", 0))
         for drop in (0.0, 0.6):
-            t = timeit(lambda: ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=drop, fts_drop=drop, seed=5))
-            print(json.dumps({"kernel": f"project_fwd drop={drop}", "ms": round(t, 4),
+            t = timeit(lambda: ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=drop, fts_drop=drop, seed=5, flags=fl_))
+            print(json.dumps({"kernel": f"project_fwd drop={drop} flags={fl_}", "ms": round(t, 4),
                               "TFLOPs": round(fl / t / 1e9, 1), "X_GBs": round(n * f * 4 / t / 1e6, 1)}))
             t = timeit(lambda: ops.project_bwd(X, dH, 8, 8, in_drop=drop, seed=5))
-            print(json.dumps({"kernel": f"project_bwd drop={drop}", "ms": round(t, 4),
+            print(json.dumps({"kernel": f"project_bwd drop={drop} (draws regenerated)", "ms": round(t, 4),
+                              "TFLOPs": round(fl / t / 1e9, 1)}))
+        # round 3: the forward writes the keep table, dW reads it (4x4x1 16-block MFMA kernel)
+        t = timeit(lambda: ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.6, fts_drop=0.6, seed=5, want_keep=True, flags=fl_))
+        print(json.dumps({"kernel": f"project_fwd drop=0.6 + keep table flags={fl_}", "ms": round(t, 4)}))
+        keep = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.6, fts_drop=0.6, seed=5, want_keep=True)[3]
+        if keep is not None:
+            t = timeit(lambda: ops.project_bwd(X, dH, 8, 8, in_drop=0.6, seed=5, keep=keep))
+            print(json.dumps({"kernel": "project_bwd drop=0.6 from the keep table", "ms": round(t, 4),
                               "TFLOPs": round(fl / t / 1e9, 1)}))
 
 
