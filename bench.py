@@ -19,7 +19,7 @@ Cache, so those rates are cache-path rates; `roofline_hbm_regime` re-times the s
 kernels in the same run on one meta-path of N = 10M rows (2.56 GB table): THAT is the HBM
 fraction.  `cpu_baseline` is the torch-CPU port of the reference algorithm
 (oracle/han_oracle_torch.py, CSR form) timed on this host on a bounded sample, with all
-usable cores and with one thread.
+usable cores and with one thread on the same sample (`cores_effective` = the measured ratio).
 """
 import argparse
 import json
@@ -73,7 +73,7 @@ K2_KERNEL_NAME = {"eval": "node_attn_fwd_kernel<FP=8,TRAIN=0> (K2 forward, eval)
                   "bwd_cols": "node_attn_bwd_cols_kernel<FP=8,FAST> (K2 backward, transposed-graph gather)"}
 
 
-def k2_rooflines(timing, esz, regime):
+def k2_rooflines(timing, esz, regime, cache_served=False):
     """Per K2 kernel: mean launch duration (HIP events on the launch stream) -> GB/s of moved
     bytes against the 8 TB/s HBM peak.  Returns {tag: dict} and the tag with the largest total time."""
     ms, shape = {}, {}
@@ -99,6 +99,12 @@ def k2_rooflines(timing, esz, regime):
                     "avg_launch_ms": round(avg, 4), "launches_timed": len(v),
                     "total_ms_in_timed_region": round(total[tag], 3), "rows": nr, "edges": nnz,
                     "regime": regime}
+        if cache_served:
+            # gather table <= ~2x the 256 MiB Infinity Cache: bytes / time is a fabric / cache-path rate, priced
+            # against the HBM peak only for scale -- the HBM statement of the SAME kernel is `hbm_frac`
+            # (filled in from roofline_hbm_regime), never `frac`
+            out[tag]["bound"] = "fabric / infinity cache"
+            out[tag]["hbm_frac"] = None
         if ach > HBM_PEAK_GBS:
             # e.g. power-law graphs: a few hub rows take most of the gathers and stay in the L2s
             out[tag]["bound"] = "l2 / infinity cache"
@@ -250,6 +256,52 @@ def hbm_regime_probe(dev, n, table_dtype, steps, warmup=2, deg=50):
     return roofs
 
 
+def skew_variant(dev, args, tdt, esz, warmup=2):
+    """SURVEY.md 8d's second line: the same model on the power-law variant of the workload (alpha = 2.1, the same
+    N, E, F, P; rows far longer than 8192 edges are cut into chunks) -- graph generation + `warmup` + --skew-steps
+    epochs in this process, after the headline's timed region.  Hub rows stay in the L2s, so a K2 rate above the
+    HBM peak is labelled a cache rate (k2_rooflines)."""
+    from han_amd import ops, rng, synth
+    from han_amd.gat import HeteGAT_multi
+    from han_amd.trainer import HANTrainer
+    t_gen = time.perf_counter()
+    wl = synth.make_workload("syn-1m-skew", device=dev)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    if tdt == torch.bfloat16:
+        wl["x"] = wl["x"].to(torch.bfloat16)
+    rng.manual_seed(2024)
+    model = HeteGAT_multi().build(wl["p"], wl["f"], wl["c"], (8,), (8, 1), 128, device=dev,
+                                  generator=torch.Generator().manual_seed(0), table_dtype=tdt)
+    max_deg = max(int(g.degrees().max()) for g in wl["graphs"])
+    e_total = sum(g.nnz for g in wl["graphs"])
+    tr = HANTrainer(model, [wl["x"]] * wl["p"], wl["graphs"], wl["labels"], wl["train_mask"], wl["val_mask"],
+                    lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6)
+    wl["graphs"] = None
+    for _ in range(warmup):
+        tr.epoch()
+    torch.cuda.synchronize()
+    ops.K2_TIMING = []
+    t0 = time.perf_counter()
+    for _ in range(args.skew_steps):
+        last = tr.epoch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timing, ops.K2_TIMING = ops.K2_TIMING, None
+    roofs, dom = k2_rooflines(timing, esz, "power-law degrees: the hub rows are served from the L2s / Infinity Cache",
+                              cache_served=True)
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "moved_bytes_per_launch", "note")
+    tl, ta, vl, va = tr.reduce_metrics(*last)
+    del tr, model
+    torch.cuda.empty_cache()
+    return {"workload": f"syn-1m-skew: N={wl['n']}, P={wl['p']}, E={e_total} (power-law degrees, alpha 2.1, max degree "
+                        f"{max_deg}), F={wl['f']}", "value": round(args.skew_steps / dt, 4), "unit": "epochs/s",
+            "ms_per_step": round(dt / args.skew_steps * 1e3, 3), "steps": args.skew_steps, "warmup": warmup,
+            "graph_generation_s": round(t_gen, 2),
+            "k2": {tag: {k: r[k] for k in keep if k in r} for tag, r in roofs.items()},
+            "final": {"train_loss": round(tl, 5), "val_loss": round(vl, 5)}}
+
+
 # --------------------------------------------------------------------------- CPU baseline
 def host_cores():
     """Cores this process may really use: affinity mask, capped by the cgroup CPU quota when one is set."""
@@ -280,73 +332,118 @@ def _cpu_model():
     return ""
 
 
-def _time_cpu_epochs(workload_name, sample_n, threads, min_epochs, budget_s, seed=1234, dense=False):
-    """Median seconds per reference epoch of the torch-CPU restatement at N = sample_n with `threads` threads."""
-    from han_amd import synth
-    from oracle import han_oracle as ho
-    from oracle import han_oracle_torch as ht
-    import numpy as np
-    torch.set_num_threads(threads)
-    wl = synth.make_workload(workload_name, device="cpu", seed=seed, n_override=sample_n)
-    rng = np.random.default_rng(0)
-    params = ho.init_params(rng, wl["p"], wl["f"], wl["c"])
-    bp = ht.to_batched(params, dtype=torch.float32)
-    state = ht.new_adam_state(bp)
-    if dense:       # the reference's own form: materialised N x N additive masks (utils/layers.py:26-27)
-        graphs = [g.to_bias()[0] for g in wl["graphs"]]
-    else:
-        graphs = [(g.rowptr, g.colidx) for g in wl["graphs"]]
-    onehot = torch.nn.functional.one_hot(wl["labels"].long(), wl["c"]).float()
-    xs = [wl["x"]] * wl["p"]
-    gen = torch.Generator().manual_seed(0)
-    n, f = sample_n, wl["f"]
-
-    def one_epoch():
-        mk = []                  # the dropout draws are part of the timed work, as in TF
-        for gr in wl["graphs"]:
-            coef_shape = (8, n, n) if dense else (gr.nnz, 8)
-            mk.append({"seq": (torch.rand((8, n, f), generator=gen) < 0.4).float(),
-                       "coef": (torch.rand(coef_shape, generator=gen) < 0.4).float(),
-                       "fts": (torch.rand((n, 64), generator=gen) < 0.4).float()})
-        ht.train_epoch(xs, graphs, bp, state, onehot, wl["train_mask"].bool(), wl["val_mask"].bool(),
-                       keep=0.4, masks=mk, dense=dense)
-
-    one_epoch()                  # warm-up
-    times = []
-    t_start = time.perf_counter()
-    while len(times) < min_epochs or (time.perf_counter() - t_start < budget_s and len(times) < 3 * min_epochs):
-        t0 = time.perf_counter()
-        one_epoch()
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_start > 3 * budget_s:
-            break
-    times.sort()
-    return times[len(times) // 2], len(times)
+_MALLOC_TUNED = False
 
 
-def cpu_baseline(workload_name, n_full, sample_all, sample_one):
+def _tune_host_malloc():
+    """glibc returns every large tensor to the kernel on free (mmap threshold), so a torch-CPU training step
+    that allocates ~100 fresh 50 MB temporaries per epoch spends most of its time in page faults -- serial
+    kernel work that no thread count helps (measured here: 31 s per epoch at N = 50 000 with 8 threads, 10.7 s
+    with the two mallopt calls below, and the 1-thread / 8-thread ratio goes from 1.0 to 6.3).  TensorFlow, the
+    reference's runtime, keeps its memory in a BFC arena; M_MMAP_MAX = 0 + no trimming is the closest glibc
+    has.  Only the CPU-baseline leg (the last thing bench.py does) runs under it."""
+    global _MALLOC_TUNED
+    if _MALLOC_TUNED:
+        return True
+    try:
+        import ctypes
+        libc = ctypes.CDLL("libc.so.6")
+        ok = libc.mallopt(-4, 0) == 1 and libc.mallopt(-1, 0x7FFFFFFF) == 1      # M_MMAP_MAX, M_TRIM_THRESHOLD
+    except Exception:
+        ok = False
+    _MALLOC_TUNED = ok
+    return ok
+
+
+class _CpuEpochs:
+    """The torch-CPU restatement of one reference epoch on a sample of the workload (same degree / feature
+    width / meta-path count, fewer nodes); the dropout draws are part of the timed work, as in TF."""
+
+    def __init__(self, workload_name, sample_n, seed=1234, dense=False):
+        from han_amd import synth
+        from oracle import han_oracle as ho
+        from oracle import han_oracle_torch as ht
+        import numpy as np
+        self.ht, self.dense, self.n = ht, dense, sample_n
+        wl = synth.make_workload(workload_name, device="cpu", seed=seed, n_override=sample_n)
+        params = ho.init_params(np.random.default_rng(0), wl["p"], wl["f"], wl["c"])
+        self.bp = ht.to_batched(params, dtype=torch.float32)
+        self.state = ht.new_adam_state(self.bp)
+        if dense:       # the reference's own form: materialised N x N additive masks (utils/layers.py:26-27)
+            self.graphs = [g.to_bias()[0] for g in wl["graphs"]]
+        else:
+            self.graphs = [(g.rowptr, g.colidx) for g in wl["graphs"]]
+        self.nnz = [g.nnz for g in wl["graphs"]]
+        self.onehot = torch.nn.functional.one_hot(wl["labels"].long(), wl["c"]).float()
+        self.xs = [wl["x"]] * wl["p"]
+        self.f = wl["f"]
+        self.train_mask, self.val_mask = wl["train_mask"].bool(), wl["val_mask"].bool()
+        self.gens = [torch.Generator().manual_seed(p) for p in range(wl["p"])]
+
+    def _masks_of(self, p):
+        n, f, gen = self.n, self.f, self.gens[p]
+        coef_shape = (8, n, n) if self.dense else (self.nnz[p], 8)
+        return {"seq": (torch.rand((8, n, f), generator=gen) < 0.4).float(),
+                "coef": (torch.rand(coef_shape, generator=gen) < 0.4).float(),
+                "fts": (torch.rand((n, 64), generator=gen) < 0.4).float()}
+
+    def one_epoch(self, threads):
+        if threads > 1:      # torch's CPU generator is serial: one stream per meta-path, drawn concurrently
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=len(self.gens)) as ex:
+                mk = list(ex.map(self._masks_of, range(len(self.gens))))
+        else:
+            mk = [self._masks_of(p) for p in range(len(self.gens))]
+        self.ht.train_epoch(self.xs, self.graphs, self.bp, self.state, self.onehot, self.train_mask, self.val_mask,
+                            keep=0.4, masks=mk, dense=self.dense)
+
+    def time(self, threads, min_epochs, budget_s, warmup=True):
+        """Median seconds per epoch with `threads` threads."""
+        torch.set_num_threads(threads)
+        if warmup:
+            self.one_epoch(threads)
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < min_epochs or (time.perf_counter() - t_start < budget_s and len(times) < 3 * min_epochs):
+            t0 = time.perf_counter()
+            self.one_epoch(threads)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > 3 * budget_s:
+                break
+        times.sort()
+        return times[len(times) // 2], len(times)
+
+
+def cpu_baseline(workload_name, n_full, sample_n):
     """The reference algorithm (CSR restatement, torch CPU fp32) on a bounded sample of the same
-    workload: same degree / feature width / meta-path count, fewer nodes; epochs/s is scaled by
-    sample_n / n_full (every term of the algorithm is linear in N at fixed degree).  Timed with all
-    usable host cores and with 1 thread; `value` is the all-cores figure."""
+    workload; epochs/s is scaled by sample_n / n_full (every term of the algorithm is linear in N at fixed
+    degree).  Timed with all usable host cores and with ONE thread ON THE SAME SAMPLE (SURVEY.md 8d);
+    `value` is the all-cores figure, `cores` the threads it used, `cores_effective` the measured speed-up
+    over one thread (what the cores really buy)."""
     cores, affinity, quota = host_cores()
     prev = torch.get_num_threads()
-    t_all, reps_all = _time_cpu_epochs(workload_name, sample_all, cores, 5, 40.0)
-    t_one, reps_one = _time_cpu_epochs(workload_name, sample_one, 1, 3, 30.0)
-    out = {"value": (1.0 / t_all) * sample_all / n_full, "unit": "epochs/s", "cores": cores, "kind": "port",
-           "sample": f"{workload_name} shape at N={sample_all} (deg/F/P unchanged), median of {reps_all} epochs "
-                     f"({t_all:.2f} s each) after one warm-up, {cores} threads, scaled by {sample_all}/{n_full} "
-                     f"(extrapolation factor {n_full / sample_all:.0f}x); torch-CPU fp32 CSR restatement of the "
-                     f"reference (not TensorFlow)",
-           "all_cores": {"threads": cores, "sample_n": sample_all, "epoch_s": round(t_all, 3), "epochs_timed": reps_all,
-                         "epochs_per_s_scaled": (1.0 / t_all) * sample_all / n_full},
-           "one_thread": {"threads": 1, "sample_n": sample_one, "epoch_s": round(t_one, 3), "epochs_timed": reps_one,
-                          "epochs_per_s_scaled": (1.0 / t_one) * sample_one / n_full},
+    tuned = _tune_host_malloc()
+    run = _CpuEpochs(workload_name, sample_n)
+    t_all, reps_all = run.time(cores, 3, 12.0)
+    t_one, reps_one = run.time(1, 1, 1.0, warmup=False)       # the all-cores epochs were the warm-up
+    out = {"value": (1.0 / t_all) * sample_n / n_full, "unit": "epochs/s", "cores": cores,
+           "cores_effective": round(t_one / t_all, 2), "kind": "port",
+           "sample": f"{workload_name} shape at N={sample_n} (deg/F/P unchanged), median of {reps_all} epochs "
+                     f"({t_all:.2f} s each) after one warm-up, {cores} threads, scaled by {sample_n}/{n_full} "
+                     f"(extrapolation factor {n_full / sample_n:.0f}x); the same sample with ONE thread: {t_one:.2f} s "
+                     f"per epoch; torch-CPU fp32 CSR restatement of the reference (not TensorFlow)",
+           "all_cores": {"threads": cores, "sample_n": sample_n, "epoch_s": round(t_all, 3), "epochs_timed": reps_all,
+                         "epochs_per_s_scaled": (1.0 / t_all) * sample_n / n_full},
+           "one_thread": {"threads": 1, "sample_n": sample_n, "epoch_s": round(t_one, 3), "epochs_timed": reps_one,
+                          "epochs_per_s_scaled": (1.0 / t_one) * sample_n / n_full},
+           "host_allocator": ("glibc malloc with M_MMAP_MAX = 0 and trimming off (a caching arena, like TF's BFC "
+                              "allocator): without it the port is page-fault-bound and no thread count helps"
+                              if tuned else "glibc default (mallopt unavailable)"),
            "host": {"cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "affinity": affinity,
                     "cgroup_quota_cores": quota}}
     if workload_name == "acm-like":
         # the reference's actual algorithm on its own dataset shape: dense N x N masks, full size
-        t_d, reps_d = _time_cpu_epochs(workload_name, n_full, cores, 2, 20.0, dense=True)
+        t_d, reps_d = _CpuEpochs(workload_name, n_full, dense=True).time(cores, 2, 20.0)
         out["dense_reference_form"] = {"threads": cores, "sample_n": n_full, "epoch_s": round(t_d, 3),
                                        "epochs_timed": reps_d, "epochs_per_s": 1.0 / t_d,
                                        "note": "materialised N x N logits + additive -1e9 mask, op for op with "
@@ -372,13 +469,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="capture the epoch into a hipGraph and replay it (single GPU; small graphs)")
-    ap.add_argument("--cpu-sample", type=int, default=50000,
-                    help="nodes of the CPU-baseline sample timed with all usable cores")
-    ap.add_argument("--cpu-sample-1t", type=int, default=5000,
-                    help="nodes of the CPU-baseline sample timed with one thread")
+    ap.add_argument("--cpu-sample", type=int, default=10000,
+                    help="nodes of the CPU-baseline sample (timed with all usable cores AND with one thread)")
     ap.add_argument("--hbm-regime-nodes", type=int, default=10_000_000,
                     help="rows of the extra single-meta-path table on which the K2 kernels are re-timed in the "
                          "HBM-served regime after the timed region (0 = skip; single GPU only)")
+    ap.add_argument("--skew-steps", type=int, default=5,
+                    help="epochs timed on the power-law variant of the headline workload (syn-1m-skew, same N / E / F / P) "
+                         "in the same process after the timed region; reported as `skew` (0 = skip; N = 1, syn-1m only)")
     ap.add_argument("--reorder", choices=("none", "bfs"), default="none",
                     help="locality pass (han_amd.reorder): breadth-first relabelling of the nodes before training "
                          "(single GPU; the pass itself is timed separately and reported)")
@@ -524,7 +622,8 @@ def main():
     regime = (f"gather table {table_mb:.0f} MB per meta-path vs the 256 MiB Infinity Cache: "
               + ("largely cache-served -- an effective (fabric/cache-path) rate, NOT an HBM fraction; "
                  "see roofline_hbm_regime" if table_mb < 600 else "HBM-served"))
-    roofs, dom = k2_rooflines(timing, esz, regime)
+    cache_served = table_mb < 600
+    roofs, dom = k2_rooflines(timing, esz, regime, cache_served=cache_served)
     traffic_per, traffic_src = None, None
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
     if args.traffic == "live" and profiled:
@@ -543,11 +642,18 @@ def main():
         r["traffic"] = (traffic_per or {}).get(tkey[tag]) if traffic_per else None
         r["traffic_source"] = traffic_src
     hbm = None
+    skew = None
     if rank == 0 and world == 1 and args.hbm_regime_nodes > 0 and not use_graph and table_mb < 600 \
             and args.workload.startswith("syn-1m"):      # the headline family; other workloads are not priced against HBM
         del trainer, model
         torch.cuda.empty_cache()
         hbm = hbm_regime_probe(dev, args.hbm_regime_nodes, args.table_dtype, min(max(args.steps, 5), 20))
+        for tag, r in roofs.items():                     # the HBM fraction of the same kernel, same run
+            if "hbm_frac" in r and tag in hbm:
+                r["hbm_frac"] = hbm[tag]["frac"]
+    if rank == 0 and world == 1 and args.skew_steps > 0 and not use_graph and args.workload == "syn-1m" \
+            and not args.nodes:
+        skew = skew_variant(dev, args, tdt, esz)
 
     if rank == 0:
         out = {
@@ -585,12 +691,15 @@ def main():
             out["roofline"] = None
             out["roofline_note"] = ("no per-kernel HIP events in this run (an epoch replayed from a hipGraph "
                                     "records none); run without --graph for the K2 rooflines")
+        if skew is not None:
+            # "a second, skewed variant must be reported beside it" (real meta-path graphs are skewed)
+            out["skew"] = skew
         if hbm is not None:
             # the >= 50 % HBM target of BASELINE.json is read off THIS object: same kernels, same run,
             # a table 10x larger than the Infinity Cache
             out["roofline_hbm_regime"] = hbm
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.workload, n, min(args.cpu_sample, n), min(args.cpu_sample_1t, n))
+            cb = cpu_baseline(args.workload, n, min(args.cpu_sample, n))
             out["cpu_baseline"] = cb
             out["vs_cpu_baseline"] = round(out["value"] / cb["value"], 1)
         print(json.dumps(out), flush=True)

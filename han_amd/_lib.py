@@ -36,6 +36,8 @@ SIGNATURES = {
     "han_project_keep_bytes": (c_size_t, [I64, c_int, I64, c_int, c_int]),
     "han_project_fwd": (c_int, [P, c_int, I64, P, P, P, P, P, P, c_int, P, P, P, c_size_t, I64, c_int, c_int, c_int,
                                 c_float, c_float, c_uint64, P, I64, P, c_int, P]),
+    "han_project_fwd_multi": (c_int, [P, c_int, I64, P, P, P, P, P, P, c_int, P, P, P, c_size_t, I64, c_int, c_int, c_int,
+                                      c_int, c_float, c_float, P, P, I64, P, c_int, P]),
     "han_project_bwd_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
     "han_project_bwd": (c_int, [P, c_int, I64, P, P, P, c_size_t, I64, c_int, c_int, c_int, c_float,
                                 c_uint64, P, I64, P, P]),

@@ -364,13 +364,31 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
     constexpr int NT = 64 * NW;           // threads
     constexpr int XV = 1024 / NT;         // float4 loads of X per thread per tile (128 rows x 32 k)
     constexpr int WV = 2048 / NT;         // W elements per thread per tile (32 k x 64 columns): WV consecutive k of one column
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NX * B6_XBYTES + 3 * B6_WBYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NX * B6_XBYTES + 3 * B6_WBYTES + (KEEP ? B6_ROWS * 128 : 0)];
     unsigned char *Xs = lds;                          // [NX][128][96 B]
     unsigned char *Ws = lds + NX * B6_XBYTES;         // [3][64][96 B]   (transposed: [col][k])
+    // KEEP: the keep words of four K-steps (128 features = one 128-B line per row) are collected here and leave
+    // as whole lines; 8-byte stores per lane and K-step (32-B pieces, queued in front of the next tile's loads)
+    // cost the training forward 0.12 ms
+    unsigned char *Kacc = lds + NX * B6_XBYTES + 3 * B6_WBYTES;      // [128 rows][128 B]
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * B6_ROWS;
+    auto flush_keep = [&](int kbase) {                // rows x features [kbase, kbase + 128) of the table
+#pragma unroll
+        for (int i = 0; i < 1024 / NT; ++i) {
+            const int c = tid + NT * i;
+            const int r = c >> 3, sg = c & 7;
+            const int64_t krow = row0 + r;
+            if (krow < a.N && kbase + 16 * sg < a.F) {      // F % 8 == 0: a 16-B piece may end 8 B past the row
+                const uint4 v = *reinterpret_cast<const uint4 *>(Kacc + r * 128 + 16 * sg);
+                uint8_t *dst = a.keep + krow * (int64_t)a.F + kbase + 16 * sg;
+                if (kbase + 16 * sg + 8 < a.F) *reinterpret_cast<uint4 *>(dst) = v;
+                else *reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
+            }
+        }
+    };
 
     f32x4 acc[MT][4][HPT];
 #pragma unroll
@@ -392,31 +410,31 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
             const int idx = tid + NT * i;
             const int r = idx >> 3, c4 = (idx & 7) * 4;
             const int64_t row = row0 + r;
-            const bool ok = row < a.N && k0 + c4 < a.F;
             const int64_t rc = row < a.N ? row : a.N - 1;
             const int kc = k0 + c4 < a.F ? k0 + c4 : a.F - 4;       // F % 4 == 0 (vec path)
-            const float4_t v = load_x4(a.X, XBF, rc * a.ldx + kc);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xr[i][e] = ok ? v[e] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < WV; ++j) {
+            xr[i] = load_x4(a.X, XBF, rc * a.ldx + kc);             // RAW: out-of-range elements are zeroed when the
+        }                                                           // tile is staged -- a select here makes the wave
+#pragma unroll                                                      // wait for the load BEFORE its MFMA phase (round 3:
+        for (int j = 0; j < WV; ++j) {                              // that was the case, every K-step paid the HBM latency)
             const int kw = k0 + (tid >> 6) * WV + j;
-            const float v = a.W[(int64_t)(kw < a.F ? kw : a.F - 1) * HAN_D + (tid & 63)];
-            wr[j] = kw < a.F ? v : 0.f;
+            wr[j] = a.W[(int64_t)(kw < a.F ? kw : a.F - 1) * HAN_D + (tid & 63)];
         }
     };
     const uint32_t thr2 = (a.thr_in & 0xFFFFu) * 0x00010001u, one2 = 0x00010001u;   // keep iff field < thr_in
     load_tile(0);
     for (int k0 = 0; k0 < a.F; k0 += 32) {
         __syncthreads();   // the previous tile's fragment reads are done
+        if constexpr (KEEP) {
+            if (k0 > 0 && (k0 & 96) == 0) flush_keep(k0 - 128);      // the four K-steps before this one are complete
+        }
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int idx = tid + NT * i;
             const int off = (idx >> 3) * B6_LDB + (idx & 7) * 8;
+            const bool ok = row0 + (idx >> 3) < a.N && k0 + (idx & 7) * 4 < a.F;
             uint32_t h[4], m[4], l[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b6_split(xr[i][e], h[e], m[e], l[e]);
+            for (int e = 0; e < 4; ++e) b6_split(ok ? xr[i][e] : 0.f, h[e], m[e], l[e]);
             *reinterpret_cast<uint2 *>(Xs + off) = make_uint2(b6_pack(h[0], h[1]), b6_pack(h[2], h[3]));
             if (!XBF) {
                 *reinterpret_cast<uint2 *>(Xs + B6_XBYTES + off) = make_uint2(b6_pack(m[0], m[1]), b6_pack(m[2], m[3]));
@@ -426,7 +444,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
         {
             uint32_t h[WV], m[WV], l[WV];
 #pragma unroll
-            for (int j = 0; j < WV; ++j) b6_split(wr[j], h[j], m[j], l[j]);
+            for (int j = 0; j < WV; ++j) b6_split(k0 + (tid >> 6) * WV + j < a.F ? wr[j] : 0.f, h[j], m[j], l[j]);
             const int off = (tid & 63) * B6_LDB + (tid >> 6) * (2 * WV);
             uint32_t ph[WV / 2], pm[WV / 2], pl[WV / 2];
 #pragma unroll
@@ -446,7 +464,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
             }
         }
         __syncthreads();
-        if (k0 + 32 < a.F) load_tile(k0 + 32);   // in flight under the MFMAs
+        // UNCONDITIONAL (clamped addresses): under an `if` the loaded registers meet the not-loaded path in a phi, whose
+        // copies make the wave wait for the loads right here instead of after the MFMA phase
+        load_tile(k0 + 32);   // in flight under the MFMAs
         auto bfrag = [&](int t, int s3) {        // B[k = 8*l4 + j][col = 16t + l15]
             return *reinterpret_cast<const i32x4 *>(Ws + s3 * B6_WBYTES + (16 * t + l15) * B6_LDB + 16 * l4);
         };
@@ -521,13 +541,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
                         acc[m][t][hh] = cc;
                     }
                 }
-                if constexpr (KEEP) {
-                    const int64_t krow = row0 + lr;
-                    if (krow < a.N && k0 + 8 * l4 < a.F)
-                        *reinterpret_cast<uint2 *>(a.keep + krow * (int64_t)a.F + k0 + 8 * l4) = make_uint2(kw[0], kw[1]);
-                }
+                if constexpr (KEEP)
+                    *reinterpret_cast<uint2 *>(Kacc + lr * 128 + (k0 & 96) + 8 * l4) = make_uint2(kw[0], kw[1]);
             }
         }
+    }
+    if constexpr (KEEP) {
+        __syncthreads();
+        flush_keep(((a.F - 1) >> 7) << 7);      // the last (possibly partial) group of K-steps
     }
     // epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg (as the fp32 kernel's)
     const int myhh = HPT > 1 ? l15 / 8 : 0;
@@ -570,6 +591,168 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
                 }
             }
             if (DROP && a.f1) tile_scores<8>(a, row, row < a.N, vst, a1c, a2c, l15);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Eval forward of SEVERAL meta-paths that share one feature matrix (the reference feeds ONE matrix to every
+// meta-path: ex_acm3025.py:86, models/gat.py:39), on the bf16 x 6 matrix pipe: the X tile is read from HBM,
+// split into its three bf16 terms and staged ONCE for NP x 64 output columns (round 2 read, split and staged
+// it once per meta-path: 4 launches of 0.40 ms at SYN-1M, each bound by the staging of a tile that feeds
+// only 64 columns).  8 waves x one 16-row tile, all NP x 4 column tiles per wave; W_p tiles side by side in LDS.
+// blockIdx.y = group of NP meta-paths.  Scores (F' = 8) in the epilogue from the rows as stored.
+// ---------------------------------------------------------------------------------------------
+struct ProjMultiArgs {
+    const void *X;
+    int64_t ldx;
+    const float *W;          // (P, F, 64)
+    void *H;                 // (P, N, 64) fp32 or bf16
+    int h_bf16;
+    int64_t N;
+    int F;
+    int p_first;             // first meta-path of this launch
+    const float *a1, *a2, *b1, *b2;     // (P, K, FP), (P, K)
+    float *f1, *f2;          // (P, N, K)
+    int K;
+    int fuse_scores;         // F' == 8: scores in the epilogue
+};
+
+// MT = 16-row tiles per wave: a B fragment read from LDS serves MT row tiles (at MT = 1 the 8 waves re-read the whole W
+// image for 16 rows each and the kernel is bound by LDS bandwidth: 1.37 ms for four meta-paths at SYN-1M)
+template <bool XBF, int NP, int MT>
+__global__ __launch_bounds__(512) void project_fwd_b6_multi_kernel(const ProjMultiArgs a) {
+    constexpr int NX = XBF ? 1 : 3;
+    constexpr int NT = 512;
+    constexpr int WB = NP * B6_WBYTES;           // bytes of one term's W image: NP x 64 columns x 96 B
+    constexpr int ROWS = 128 * MT;               // rows per block
+    constexpr int XB = ROWS * B6_LDB;            // bytes of one term's X image
+    extern __shared__ __attribute__((aligned(16))) unsigned char mlds[];
+    unsigned char *Xs = mlds;                    // [NX][ROWS][96 B]
+    unsigned char *Ws = mlds + NX * XB;          // [3][NP * 64][96 B]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    const int p0 = a.p_first + (int)blockIdx.y * NP;
+    const float *Wp = a.W + (int64_t)p0 * a.F * HAN_D;
+
+    f32x4 acc[MT][NP * 4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NP * 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4_t xr[2 * MT];
+    float wr[NP][4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2 * MT; ++i) {
+            const int idx = tid + NT * i;
+            const int r = idx >> 3, c4 = (idx & 7) * 4;
+            const int64_t row = row0 + r;
+            const int64_t rc = row < a.N ? row : a.N - 1;
+            const int kc = k0 + c4 < a.F ? k0 + c4 : a.F - 4;
+            xr[i] = load_x4(a.X, XBF, rc * a.ldx + kc);      // raw; zeroed when staged (no use before the MFMA phase)
+        }
+#pragma unroll
+        for (int pi = 0; pi < NP; ++pi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kw = k0 + (tid >> 6) * 4 + j;
+                wr[pi][j] = Wp[((int64_t)pi * a.F + (kw < a.F ? kw : a.F - 1)) * HAN_D + (tid & 63)];
+            }
+    };
+    load_tile(0);
+    for (int k0 = 0; k0 < a.F; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2 * MT; ++i) {
+            const int idx = tid + NT * i;
+            const int off = (idx >> 3) * B6_LDB + (idx & 7) * 8;
+            const bool ok = row0 + (idx >> 3) < a.N && k0 + (idx & 7) * 4 < a.F;
+            uint32_t h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b6_split(ok ? xr[i][e] : 0.f, h[e], m[e], l[e]);
+            *reinterpret_cast<uint2 *>(Xs + off) = make_uint2(b6_pack(h[0], h[1]), b6_pack(h[2], h[3]));
+            if (!XBF) {
+                *reinterpret_cast<uint2 *>(Xs + XB + off) = make_uint2(b6_pack(m[0], m[1]), b6_pack(m[2], m[3]));
+                *reinterpret_cast<uint2 *>(Xs + 2 * XB + off) = make_uint2(b6_pack(l[0], l[1]), b6_pack(l[2], l[3]));
+            }
+        }
+#pragma unroll
+        for (int pi = 0; pi < NP; ++pi) {
+            uint32_t h[4], m[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b6_split(k0 + (tid >> 6) * 4 + j < a.F ? wr[pi][j] : 0.f, h[j], m[j], l[j]);
+            const int off = (pi * 64 + (tid & 63)) * B6_LDB + (tid >> 6) * 8;
+            *reinterpret_cast<uint2 *>(Ws + off) = make_uint2(b6_pack(h[0], h[1]), b6_pack(h[2], h[3]));
+            *reinterpret_cast<uint2 *>(Ws + WB + off) = make_uint2(b6_pack(m[0], m[1]), b6_pack(m[2], m[3]));
+            *reinterpret_cast<uint2 *>(Ws + 2 * WB + off) = make_uint2(b6_pack(l[0], l[1]), b6_pack(l[2], l[3]));
+        }
+        __syncthreads();
+        load_tile(k0 + 32);      // unconditional, clamped: see project_fwd_b6_kernel
+        i32x4 af[MT][NX];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int s3 = 0; s3 < NX; ++s3)
+                af[m][s3] = *reinterpret_cast<const i32x4 *>(Xs + s3 * XB + (16 * (w * MT + m) + l15) * B6_LDB + 16 * l4);
+#pragma unroll
+        for (int t = 0; t < NP * 4; ++t) {
+            const unsigned char *bp = Ws + (16 * t + l15) * B6_LDB + 16 * l4;
+            const i32x4 b0 = *reinterpret_cast<const i32x4 *>(bp);
+            const i32x4 b1 = *reinterpret_cast<const i32x4 *>(bp + WB);
+            const i32x4 b2 = *reinterpret_cast<const i32x4 *>(bp + 2 * WB);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 c = acc[m][t];
+                if (!XBF) {
+                    c = b6_mfma(af[m][1], b1, c);      // small terms first
+                    c = b6_mfma(af[m][2], b0, c);
+                    c = b6_mfma(af[m][1], b0, c);
+                }
+                c = b6_mfma(af[m][0], b2, c);
+                c = b6_mfma(af[m][0], b1, c);
+                c = b6_mfma(af[m][0], b0, c);
+                acc[m][t] = c;
+            }
+        }
+    }
+    // epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) {
+        const int p = p0 + pi;
+        ProjFwdArgs pa;       // what tile_scores reads
+        pa.f1 = a.f1 + (int64_t)p * a.N * a.K; pa.f2 = a.f2 + (int64_t)p * a.N * a.K;
+        pa.b1 = a.b1 + p * a.K; pa.b2 = a.b2 + p * a.K;
+        float a1c[4], a2c[4];
+        if (a.fuse_scores) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a1c[t] = a.a1[p * HAN_D + 16 * t + l15];
+                a2c[t] = a.a2[p * HAN_D + 16 * t + l15];
+            }
+        }
+#pragma unroll
+        for (int mr = 0; mr < MT * 4; ++mr) {
+            const int m = mr >> 2, r = mr & 3;
+            const int64_t row = row0 + 16 * (w * MT + m) + l4 * 4 + r;
+            float vst[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float v = acc[m][pi * 4 + t][r];
+                const int64_t o = ((int64_t)p * a.N + row) * HAN_D + 16 * t + l15;
+                if (a.h_bf16) {
+                    const uint32_t b = han_f32_to_bf16_bits(v);
+                    if (row < a.N) reinterpret_cast<uint16_t *>(a.H)[o] = (uint16_t)b;
+                    vst[t] = __uint_as_float(b << 16);
+                } else {
+                    if (row < a.N) reinterpret_cast<float *>(a.H)[o] = v;
+                    vst[t] = v;
+                }
+            }
+            if (a.fuse_scores) tile_scores<8>(pa, row, row < a.N, vst, a1c, a2c, l15);
         }
     }
 }
@@ -931,39 +1114,56 @@ __global__ __launch_bounds__(256, 4) void project_bwd_blk_kernel(const ProjBwdBl
 #pragma unroll
         for (int h = 0; h < 2; ++h) acc[o][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // staging registers: X tile 32 x 128 (4 x float4 per thread), dH tile 32 x 64 (2 x float4), keep tile 32 x 128 B
-    // (2 x 8 B).  Unconditional loads from clamped addresses + selects (a predicated load is a branch with its own wait).
+    // staging registers: X tile 32 x 128 (4 x 16 B per thread), dH tile 32 x 64 (2 x 16 B), keep tile 32 x 128 B (2 x 8 B).
+    // Buffer loads: the range check of the descriptor returns 0 for rows beyond the chunk, a thread whose
+    // columns lie beyond F carries an out-of-range offset for good, and the step advance is a scalar offset --
+    // the tile costs no vector ALU work (the selects and 64-bit address arithmetic of plain loads were 58 % of
+    // this kernel's vector instructions, and a 2-pass MFMA does not share its issue cycles with them:
+    // profiles/r03_pmc_k1.json)
+    constexpr int XE = XBF ? 2 : 4;                    // bytes per X element
+    const int64_t nrows = n_end - n_begin;
+    const uint32_t OOB = 0x7FFFFFF0u;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(reinterpret_cast<const char *>(a.X) + (n_begin * a.ldx + f0) * XE), 0,
+        (int)(((nrows - 1) * a.ldx + (a.F - f0 < DW_FB ? a.F - f0 : DW_FB)) * XE), 0x00020000);
+    const auto rs_g = __builtin_amdgcn_make_buffer_rsrc((void *)(a.dH + n_begin * HAN_D), 0, (int)(nrows * HAN_D * 4), 0x00020000);
+    const auto rs_k = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(DROP ? a.keep + n_begin * (int64_t)a.F + f0 : (const uint8_t *)a.X), 0,
+        DROP ? (int)((nrows - 1) * a.F + (a.F - f0 < DW_FB ? a.F - f0 : DW_FB)) : 0, 0x00020000);
+    const int xc4 = (tid & 31) * 4;
+    const uint32_t vx = f0 + xc4 < a.F ? (uint32_t)(((tid >> 5) * a.ldx + xc4) * XE) : OOB;      // + 8 i rows
+    const uint32_t vg = (uint32_t)((tid >> 4) * (HAN_D * 4) + (tid & 15) * 16);               // + 16 i rows
+    const uint32_t vk = f0 + 16 * (tid & 7) < a.F ? (uint32_t)((tid >> 3) * a.F + 16 * (tid & 7)) : OOB;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     float4_t xr[4], gr[2];
-    uint2 kr[2];
+    u32x2 kr[2];
+    // The whole offset travels in the VECTOR offset: the descriptor's range check covers inst_offset + voffset only
+    // (an SGPR offset is added after the check), and the check is what zeroes the rows beyond the chunk.
     auto load_tile = [&](int64_t n0) {
+        const uint32_t step = (uint32_t)(n0 - n_begin);
+        const uint32_t in_x = vx == OOB ? 0u : 1u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int r = idx >> 5, c4 = (idx & 31) * 4;
-            const int64_t row = n0 + r;
-            const bool ok = row < n_end && f0 + c4 < a.F;           // F % 4 == 0
-            const int64_t rc = row < a.N ? row : a.N - 1;
-            const int fc = f0 + c4 < a.F ? f0 + c4 : a.F - 4;
-            const float4_t v = load_x4(a.X, XBF, rc * a.ldx + fc);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xr[i][e] = ok ? v[e] : 0.f;
+            const uint32_t vo = in_x ? vx + (step + 8 * i) * (uint32_t)(a.ldx * XE) : OOB;
+            if (XBF) {
+                const u32x2 wv = __builtin_amdgcn_raw_buffer_load_b64(rs_x, vo, 0, 0);
+                xr[i][0] = __uint_as_float(wv.x << 16);
+                xr[i][1] = __uint_as_float(wv.x & 0xFFFF0000u);
+                xr[i][2] = __uint_as_float(wv.y << 16);
+                xr[i][3] = __uint_as_float(wv.y & 0xFFFF0000u);
+            } else {
+                const u32x4 wv = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, 0, 0);
+                xr[i] = __builtin_bit_cast(float4_t, wv);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            const int64_t row = n0 + (idx >> 4);
-            const int64_t rc = row < a.N ? row : a.N - 1;
-            const float4_t v = *reinterpret_cast<const float4_t *>(a.dH + rc * HAN_D + (idx & 15) * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gr[i][e] = row < n_end ? v[e] : 0.f;
-        }
-        if (DROP) {      // rows / features beyond the ends meet X == 0, so their (arbitrary) keep bits do not matter
-            const int64_t row = n0 + (tid >> 3);
-            const int64_t rc = row < a.N ? row : a.N - 1;
-            const int fb = f0 + 16 * (tid & 7);
-            const uint8_t *kp = a.keep + rc * (int64_t)a.F + (fb < a.F ? fb : a.F - 8);     // table has 128 B of slack
-            kr[0] = *reinterpret_cast<const uint2 *>(kp);
-            kr[1] = *reinterpret_cast<const uint2 *>(kp + 8);
+        for (int i = 0; i < 2; ++i)
+            gr[i] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_g, vg + (step + 16 * i) * (HAN_D * 4), 0, 0));
+        if (DROP) {      // features beyond F meet X == 0, so their (arbitrary) keep bits do not matter
+            const uint32_t vo = vk == OOB ? OOB : vk + step * (uint32_t)a.F;
+            kr[0] = __builtin_amdgcn_raw_buffer_load_b64(rs_k, vo, 0, 0);
+            kr[1] = __builtin_amdgcn_raw_buffer_load_b64(rs_k, vo == OOB ? OOB : vo + 8, 0, 0);
         }
     };
     // dword offsets of this lane's operands inside a row of the three LDS images
@@ -999,7 +1199,7 @@ __global__ __launch_bounds__(256, 4) void project_bwd_blk_kernel(const ProjBwdBl
             *reinterpret_cast<uint2 *>(dst + 4) = make_uint2(kr[0].y, kr[1].y);     // q = 1 halves
         }
         __syncthreads();
-        if (n0 + DW_BN < n_end) load_tile(n0 + DW_BN);     // in flight under the MFMAs
+        load_tile(n0 + DW_BN);     // in flight under the MFMAs (unconditional: beyond the chunk the descriptor returns 0)
         // Three-stage software pipeline over the 32 rows of the tile, spelled out because hipcc's own schedule
         // (reads of two rows, then a wait right behind them, one temporary through every mask / and / MFMA chain)
         // exposes the LDS latency every other row: row n + 2 is being read, row n + 1's A operands are being
@@ -1222,6 +1422,85 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
         HAN_DISPATCH_FP(FP, { project_scores_kernel<FPC, false><<<sgrid, 256, 0, st>>>(s); })
     }
     HAN_CHECK_LAUNCH();
+    return 0;
+}
+
+// multi-meta-path eval forward on the fused kernel: groups of 4, then 2 meta-paths per block
+template <bool XBF>
+static int launch_multi(ProjMultiArgs m, int P, int np_max, hipStream_t st) {
+    constexpr int MT = 2;
+    const unsigned tiles = (unsigned)((m.N + 128 * MT - 1) / (128 * MT));
+    const size_t xb = (size_t)(XBF ? 1 : 3) * 128 * MT * B6_LDB;
+    int p = 0;
+    while (P - p >= 2) {
+        const int np = (P - p >= 4 && np_max >= 4) ? 4 : 2;
+        const int groups = (P - p) / np;
+        const size_t lds = xb + (size_t)3 * np * B6_WBYTES;
+        m.p_first = p;
+        hipError_t e;
+        if (np == 4) {
+            e = hipFuncSetAttribute((const void *)project_fwd_b6_multi_kernel<XBF, 4, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            project_fwd_b6_multi_kernel<XBF, 4, MT><<<dim3(tiles, groups), 512, lds, st>>>(m);
+        } else {
+            e = hipFuncSetAttribute((const void *)project_fwd_b6_multi_kernel<XBF, 2, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            project_fwd_b6_multi_kernel<XBF, 2, MT><<<dim3(tiles, groups), 512, lds, st>>>(m);
+        }
+        HAN_CHECK_LAUNCH();
+        p += groups * np;
+    }
+    return p;      // meta-paths done (>= 0); a last odd one is left to the caller
+}
+
+extern "C" int han_project_fwd_multi(const void *X, int x_dtype, int64_t ldx, const float *W, const float *a1,
+                                     const float *a2, const float *b1, const float *b2, void *H, int table_dtype,
+                                     float *f1, float *f2, void *workspace, size_t workspace_bytes, int64_t N,
+                                     int F, int K, int FP, int P, float in_drop, float fts_drop,
+                                     const uint64_t *seeds, const uint64_t *seed_dev, int64_t row_offset,
+                                     uint8_t *keep, int flags, void *stream) {
+    if (P <= 0 || (in_drop > 0.f && !seeds)) return HAN_E_BADARG;
+    if (N == 0) return 0;
+    if (!X || !W || !a1 || !a2 || !b1 || !b2 || !H || !f1 || !f2 || N < 0 || F <= 0 || ldx < F) return HAN_E_BADARG;
+    if (!fp_ok(K, FP)) return HAN_E_UNSUPPORTED;
+    const bool x_bf16 = x_dtype == HAN_DTYPE_BF16, h_bf16 = table_dtype == HAN_DTYPE_BF16;
+    const size_t hb = (size_t)N * HAN_D * (h_bf16 ? 2 : 4), kb = han_project_keep_bytes(N, F, ldx, K, FP);
+    int mt, nsplit, fch;
+    fwd_geometry(N, F, &mt, &nsplit, &fch);
+    const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & (x_bf16 ? 7 : 15)) == 0);
+    int done = 0;
+    if (in_drop == 0.f && fts_drop == 0.f && P >= 2 && vec && nsplit == 1 && N >= 64 * 256 &&
+        !(flags & HAN_FLAG_K1_EXACT_PIPE) && (x_dtype == HAN_DTYPE_F32 || x_dtype == HAN_DTYPE_BF16) &&
+        (table_dtype == HAN_DTYPE_F32 || h_bf16)) {
+        hipStream_t st = (hipStream_t)stream;
+        ProjMultiArgs m;
+        m.X = X; m.ldx = ldx; m.W = W; m.H = H; m.h_bf16 = h_bf16; m.N = N; m.F = F; m.p_first = 0;
+        m.a1 = a1; m.a2 = a2; m.b1 = b1; m.b2 = b2; m.f1 = f1; m.f2 = f2; m.K = K; m.fuse_scores = FP == 8;
+        const int np_max = (flags & HAN_FLAG_K1_PAIRS) ? 2 : 4;
+        done = x_bf16 ? launch_multi<true>(m, P, np_max, st) : launch_multi<false>(m, P, np_max, st);
+        if (done < 0 || done > P) return done;      // an error code
+        if (FP != 8) {                               // other head widths: scores from the stored rows
+            for (int p = 0; p < done; ++p) {
+                ScoreArgs s;
+                s.H = (const char *)H + (size_t)p * hb; s.a1 = a1 + (size_t)p * HAN_D; s.a2 = a2 + (size_t)p * HAN_D;
+                s.b1 = b1 + (size_t)p * K; s.b2 = b2 + (size_t)p * K;
+                s.f1 = f1 + (size_t)p * N * K; s.f2 = f2 + (size_t)p * N * K; s.N = N;
+                const int sgrid = han_grid_for(N, 16, 256 * 8);
+                if (h_bf16) { HAN_DISPATCH_FP(FP, { project_scores_kernel<FPC, true><<<sgrid, 256, 0, st>>>(s); }) }
+                else { HAN_DISPATCH_FP(FP, { project_scores_kernel<FPC, false><<<sgrid, 256, 0, st>>>(s); }) }
+                HAN_CHECK_LAUNCH();
+            }
+        }
+    }
+    for (int p = done; p < P; ++p) {                 // everything else: one meta-path at a time
+        const int rc = han_project_fwd(X, x_dtype, ldx, W + (size_t)p * F * HAN_D, a1 + (size_t)p * HAN_D,
+                                       a2 + (size_t)p * HAN_D, b1 + (size_t)p * K, b2 + (size_t)p * K,
+                                       (char *)H + (size_t)p * hb, table_dtype, f1 + (size_t)p * N * K,
+                                       f2 + (size_t)p * N * K, workspace, workspace_bytes, N, F, K, FP, in_drop,
+                                       fts_drop, seeds ? seeds[p] : 0, seed_dev, row_offset,
+                                       (keep && kb) ? keep + (size_t)p * kb : nullptr, flags, stream);
+        if (rc != 0) return rc;
+    }
     return 0;
 }
 

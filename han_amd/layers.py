@@ -47,6 +47,13 @@ def _direct(p) -> bool:
     return bool(getattr(p, "_han_direct_grad", False)) and p.grad is not None
 
 
+def _same_tensor(ts) -> bool:
+    """True when every entry is the same view of the same storage (the meta-paths share their features)."""
+    t0 = ts[0]
+    return all(t.data_ptr() == t0.data_ptr() and t.shape == t0.shape and t.stride() == t0.stride()
+               and t.dtype == t0.dtype for t in ts[1:])
+
+
 class _Ready:
     """A table that needs no exchange (same interface as the async exchange handles)."""
 
@@ -104,29 +111,45 @@ class NodeLevelAttention(torch.autograd.Function):
         # the exchange of meta-path p+1.. overlaps the node attention of meta-path p
         proj, proj_keep = [], []
         xs_full = cfg.get("xs_full") if (multi and Xin is None) else None
+        tdt = cfg.get("table_dtype", torch.float32)
+        # the reference feeds ONE feature matrix to every meta-path (ex_acm3025.py:86): all P projections then go
+        # through ONE call -- the eval forward of long inputs as one fused launch that reads, splits and stages
+        # every X tile once for four meta-paths (ops.project_fwd_multi)
+        replicated = [xs_full is not None and (plans_f is None or plans_f[p] is None) for p in range(P)]
+        pj = [None] * P
+        src = xs_full if all(replicated) else (xs if not any(replicated) else None)
+        if P > 1 and src is not None and _same_tensor(src) and W.is_contiguous() and src[0].stride(-1) == 1:
+            full = all(replicated)
+            Hs, f1s, f2s, keeps = ops.project_fwd_multi(src[0], W, a1, a2, b1, b2, in_drop=in_drop, fts_drop=in_drop,
+                                                        seeds=[int(v) for v in cfg["seeds"]],
+                                                        row_offset=0 if full else row_offset, table_dtype=tdt,
+                                                        seed_dev=seed_dev, want_keep=True)
+            pj = [(Hs[p], f1s[p], f2s[p], keeps[p]) for p in range(P)]
         for p in range(P):
             seed = int(cfg["seeds"][p])
             plan = plans_f[p] if plans_f is not None else None
             handle = keep = None
-            if xs_full is not None and plan is None:
+            if replicated[p]:
                 # replicated projection: every rank holds the features of ALL rows and projects the whole
                 # table itself instead of receiving (G-1)/G of it -- a point-to-point xGMI link moves a
                 # 256-B row slower than K1 recomputes it (dist.replication_policy).  Masks are keyed by
                 # global row ids, so the rows are bit-identical to what their owners compute.
-                Hf, f1f, f2f = ops.project_fwd(xs_full[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
-                                               fts_drop=in_drop, seed=seed, row_offset=0,
-                                               table_dtype=cfg.get("table_dtype", torch.float32),
-                                               seed_dev=seed_dev)
+                Hf, f1f, f2f, keepf = pj[p] if pj[p] is not None else ops.project_fwd(
+                    xs_full[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop, fts_drop=in_drop, seed=seed,
+                    row_offset=0, table_dtype=tdt, seed_dev=seed_dev, want_keep=True)
                 r0, r1 = part.row_start, part.row_end
                 H, f1, f2 = Hf[r0:r1], f1f[r0:r1], f2f[r0:r1]
+                if keepf is not None:      # the local rows of the table (+ its slack) when they form a table themselves
+                    Fw = xs_full[p].shape[1]
+                    kb_loc = ops.keep_bytes(r1 - r0, Fw, xs[p].stride(0), K, FP)
+                    keep = keepf[r0 * Fw:r0 * Fw + kb_loc] if kb_loc and (r0 * Fw) % 8 == 0 else None
                 handle = _Ready(Hf)
             else:
                 # training: the forward also writes the keep table of its per-head input dropout, which dW
                 # reads instead of regenerating the draws (None for shapes without a table)
-                H, f1, f2, keep = ops.project_fwd(xs[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop,
-                                                  fts_drop=in_drop, seed=seed, row_offset=row_offset,
-                                                  table_dtype=cfg.get("table_dtype", torch.float32),
-                                                  seed_dev=seed_dev, want_keep=True)
+                H, f1, f2, keep = pj[p] if pj[p] is not None else ops.project_fwd(
+                    xs[p], W[p], a1[p], a2[p], b1[p], b2[p], in_drop=in_drop, fts_drop=in_drop, seed=seed,
+                    row_offset=row_offset, table_dtype=tdt, seed_dev=seed_dev, want_keep=True)
             if multi and handle is None:      # halo rows only (HaloPlan) or the whole shard (all-gather)
                 tag = ("f", cfg.get("layer", 0), cfg.get("group", 0), p)   # persistent exchange table of this (layer, head group, meta-path)
                 handle = plan.exchange_async(H, tag) if plan is not None else part.all_gather_rows_async(H, tag)

@@ -19,6 +19,7 @@ FLAG_XCD_ORDER = 1         # HAN_FLAG_XCD_ORDER: XCD-aware work order for graphs
 FLAG_K1_EXACT_PIPE = 2     # HAN_FLAG_K1_EXACT_PIPE / _MATRIX_PIPE: force one of the two K1 forward kernels (tests, measurements)
 FLAG_K1_MATRIX_PIPE = 4
 FLAG_K1_4WAVE = 16         # HAN_FLAG_K1_4WAVE (measurements: the two-waves-per-SIMD form of the bf16 x 6 kernel)
+FLAG_K1_PAIRS = 32         # HAN_FLAG_K1_PAIRS (measurements: project_fwd_multi fuses 2 meta-paths per block, not 4)
 FLAG_K3_EXACT_PIPE = 8     # HAN_FLAG_K3_EXACT_PIPE: fp32 MFMA K3 kernels also for large inputs
 LEAKY_SLOPE = 0.2          # tf.nn.leaky_relu default (utils/layers.py:27)
 D = 64                     # K * F' of this build
@@ -26,6 +27,9 @@ STATS_ROW_BYTES = 128      # per destination row: the (f1, lse, s, 0) records of
 
 _workspaces: dict = {}
 _retired_workspaces: list = []      # superseded buffers stay alive: a captured hipGraph may have baked their pointers in
+
+FLAG_K2_LANES16 = 64       # HAN_FLAG_K2_LANES16: bf16 8 x 8 tables through the 16-lane map (tests / measurements)
+K2_EXTRA_FLAGS = 0         # or-ed into the flags of node_attn_fwd / node_attn_bwd_cols (tests / tools set FLAG_K2_LANES16)
 
 # Optional timing hook (bench.py): a list to which node_attn_fwd / node_attn_bwd_cols
 # append (tag, start_event, end_event, N, E) recorded on the launch stream.
@@ -191,6 +195,63 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
     return H, f1, f2
 
 
+def keep_bytes(N, F, ldx, K=8, FP=8) -> int:
+    """han_project_keep_bytes: size of the keep table of an (N, F) input, 0 when the shape has none."""
+    return int(_lib.load().han_project_keep_bytes(int(N), int(F), int(ldx), int(K), int(FP)))
+
+
+def project_fwd_multi(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seeds=None, row_offset=0,
+                      table_dtype=torch.float32, seed_dev=None, flags=0, want_keep=False):
+    """project_fwd for all P meta-paths of ONE shared feature matrix (the reference feeds the same matrix to
+    every meta-path: ex_acm3025.py:86, models/gat.py:39).  W (P,F,D), a1/a2 (P,K,F'), b1/b2 (P,K) -- the
+    model's own parameter tensors.  Returns H (P,N,D), f1, f2 (P,N,K) and, with want_keep, a list of P keep
+    tables (or Nones).  The eval forward of long inputs runs as ONE fused launch (X read, split and staged
+    once for 4 meta-paths per block); every other case is the per-meta-path kernel, P times."""
+    lib = _lib.load()
+    if X.dim() != 2 or W.dim() != 3:
+        raise ValueError(f"X: expected (N,F) and W (P,F,D), got {tuple(X.shape)}, {tuple(W.shape)}")
+    _chk(X, "X", contiguous=False, dtype=X.dtype)
+    xcode = _dtype_code(X, "X")
+    if X.stride(1) != 1:
+        raise ValueError("X: rows must be contiguous")
+    N, F = X.shape
+    dev = X.device
+    P, K, FP = a1.shape
+    if table_dtype not in DTYPE_CODE:
+        raise ValueError(f"table_dtype {table_dtype}: expected float32 or bfloat16")
+    _check_heads(K, FP)
+    _chk(W, "W", (P, F, D), device=dev)
+    _chk(a1, "a1", (P, K, FP), device=dev)
+    _chk(a2, "a2", (P, K, FP), device=dev)
+    _chk(b1, "b1", (P, K), device=dev)
+    _chk(b2, "b2", (P, K), device=dev)
+    in_drop = _check_drop(in_drop, "in_drop")
+    fts_drop = _check_drop(fts_drop, "fts_drop")
+    if (in_drop > 0 or fts_drop > 0) and (seeds is None or len(seeds) != P):
+        raise ValueError("dropout needs one seed per meta-path")
+    H = torch.empty((P, N, D), dtype=table_dtype, device=dev)
+    f1 = torch.empty((P, N, K), dtype=torch.float32, device=dev)
+    f2 = torch.empty((P, N, K), dtype=torch.float32, device=dev)
+    nbytes = lib.han_project_fwd_workspace(N, F, K, FP)
+    ws = _ws(nbytes, dev, "projf") if nbytes else None
+    ldx = X.stride(0) if N > 1 else max(F, X.stride(0))
+    keep, kb = None, 0
+    if want_keep and in_drop > 0 and not (flags & FLAG_K1_EXACT_PIPE) and X.data_ptr() % 16 == 0:
+        kb = lib.han_project_keep_bytes(N, F, ldx, K, FP)
+        if kb:
+            keep = torch.empty((P, kb), dtype=torch.uint8, device=dev)
+    seed_arr = (ctypes.c_uint64 * P)(*[int(x) & ((1 << 64) - 1) for x in (seeds if seeds is not None else [0] * P)])
+    _lib.check(lib.han_project_fwd_multi(
+        X.data_ptr(), xcode, ldx, W.data_ptr(), a1.data_ptr(), a2.data_ptr(), b1.data_ptr(), b2.data_ptr(),
+        H.data_ptr(), DTYPE_CODE[table_dtype], f1.data_ptr(), f2.data_ptr(),
+        ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, N, F, K, FP, P,
+        in_drop, fts_drop, seed_arr, _dev_word(seed_dev), int(row_offset),
+        keep.data_ptr() if keep is not None else None, int(flags), _stream()), "han_project_fwd_multi")
+    if want_keep:
+        return H, f1, f2, [keep[p] if keep is not None else None for p in range(P)]
+    return H, f1, f2
+
+
 def project_bwd(X, dH, K, FP, in_drop=0.0, seed=0, row_offset=0, seed_dev=None, out=None, keep=None):
     """dW (F,D) = dropout_k(X)^T dH (written to `out` when given).  keep: the table project_fwd(want_keep=True)
     returned for the same X / seed (the draws are then read, not regenerated), or None."""
@@ -297,7 +358,7 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         a2.data_ptr(), b2.data_ptr(), c.data_ptr(), res.data_ptr() if res is not None else None,
         out.data_ptr(), out.stride(0) if N > 1 else D,
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
-        int(seed), _dev_word(seed_dev), int(row_offset), int(activation), FLAG_XCD_ORDER if graph.has_locality() else 0,
+        int(seed), _dev_word(seed_dev), int(row_offset), int(activation), (FLAG_XCD_ORDER if graph.has_locality() else 0) | K2_EXTRA_FLAGS,
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_fwd")
     if timing is not None:
         ev1.record()
@@ -416,7 +477,7 @@ def node_attn_bwd_cols(graph_t: CSRGraph, gs_tab, H, f2, df1, a1, a2, coef_drop=
         table_gid.data_ptr() if table_gid is not None else None, H.data_ptr(),
         tcode, f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
         NS, graph_t.nnz, K, FP, LEAKY_SLOPE, _check_drop(coef_drop, "coef_drop"), fts_drop,
-        int(seed), _dev_word(seed_dev), int(src_offset), int(dst_offset), FLAG_XCD_ORDER if graph_t.has_locality() else 0,
+        int(seed), _dev_word(seed_dev), int(src_offset), int(dst_offset), (FLAG_XCD_ORDER if graph_t.has_locality() else 0) | K2_EXTRA_FLAGS,
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_bwd_cols")
     if timing is not None:
         ev1.record()

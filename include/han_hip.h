@@ -43,11 +43,14 @@ extern "C" {
                                   different source windows.  Speed only; off for graphs without structure, where it
                                   measured 9 % slower in the HBM regime (eight separate index / output streams). */
 
+#define HAN_FLAG_K2_LANES16 64  /* measurements / tests: bf16 8 x 8 tables through the 16-lane map of the fp32 kernels
+                                  instead of one lane per head (round 3)                                             */
 /* `flags` of han_project_fwd: which matrix pipe runs the projection (default 0: the library chooses --
  * the bf16 x 6 kernel for training forwards and bf16 features, the exact-fp32 kernel otherwise).
  * Both have fp32-class accuracy; the switches exist for measurements and tests.                     */
 #define HAN_FLAG_K1_EXACT_PIPE  2   /* v_mfma_f32_16x16x4_f32 kernels only                                 */
 #define HAN_FLAG_K1_MATRIX_PIPE 4   /* the bf16 x 6 kernel wherever it applies (also the fp32 eval forward) */
+#define HAN_FLAG_K1_PAIRS      32   /* measurements only: han_project_fwd_multi fuses 2 meta-paths per block, not 4 */
 #define HAN_FLAG_K1_4WAVE      16   /* measurements only: the round-2 form of the bf16 x 6 kernel (4 waves x 2 row tiles,
                                        two waves per SIMD) instead of 8 waves x 1 tile (four per SIMD)                     */
 /* `flags` of han_sem_attn_fwd / han_sem_attn_bwd */
@@ -101,6 +104,19 @@ int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const float *W, con
                     size_t workspace_bytes, int64_t N, int F, int K, int FP,
                     float in_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset,
                     uint8_t *keep, int flags, void *stream);
+
+/* All P meta-paths of ONE shared feature matrix in one call (the reference feeds the same matrix to every
+ * meta-path: ex_acm3025.py:86, models/gat.py:39).  W (P,F,D), a1/a2 (P,K,FP), b1/b2 (P,K), H (P,N,D),
+ * f1/f2 (P,N,K), all contiguous over p; seeds: HOST array of P seeds (may be NULL when in_drop == fts_drop == 0);
+ * keep: NULL or P tables, han_project_keep_bytes() apart.  The eval forward of long inputs (no dropout,
+ * N >= 16384, 16-byte aligned rows) runs fused: X is read, split and staged once for 4 (or 2) meta-paths per
+ * block; every other case is a loop over han_project_fwd, with the same results.                      */
+int han_project_fwd_multi(const void *X, int x_dtype, int64_t ldx, const float *W, const float *a1,
+                          const float *a2, const float *b1, const float *b2, void *H, int table_dtype,
+                          float *f1, float *f2, void *workspace, size_t workspace_bytes, int64_t N,
+                          int F, int K, int FP, int P, float in_drop, float fts_drop,
+                          const uint64_t *seeds, const uint64_t *seed_dev, int64_t row_offset,
+                          uint8_t *keep, int flags, void *stream);
 
 /* dW = Xk^T dH.  keep: the table the forward of the SAME seed wrote (then no draw is regenerated), or
  * NULL: per head dropout masks regenerated from the seed.

@@ -58,6 +58,19 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
     return H, f1.to(torch.float32), f2.to(torch.float32)
 
 
+def project_fwd_multi(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seeds=None, row_offset=0,
+                      table_dtype=torch.float32, seed_dev=None, flags=0, want_keep=False):
+    P = W.shape[0]
+    r = [project_fwd(X, W[p], a1[p], a2[p], b1[p], b2[p], in_drop, fts_drop, seeds[p] if seeds is not None else 0,
+                     row_offset, table_dtype, seed_dev) for p in range(P)]
+    out = tuple(torch.stack([v[i] for v in r]) for i in range(3))
+    return out + ([None] * P,) if want_keep else out
+
+
+def keep_bytes(N, F, ldx, K=8, FP=8):
+    return 0
+
+
 def _put(out, val):
     if out is None:
         return val
@@ -286,7 +299,7 @@ def require_gpu(t, name):
     return t
 
 
-_NAMES = ("require_gpu", "project_fwd", "project_bwd", "project_bwd_input", "node_attn_fwd", "node_attn_bwd_rows", "node_attn_bwd_cols",
+_NAMES = ("require_gpu", "project_fwd", "project_fwd_multi", "keep_bytes", "project_bwd", "project_bwd_input", "node_attn_fwd", "node_attn_bwd_rows", "node_attn_bwd_cols",
           "gs_row_bytes", "gs_views",
           "score_param_bwd", "sem_attn_fwd", "sem_attn_bwd", "classifier_loss", "adam_step",
           "l2_half_sumsq")

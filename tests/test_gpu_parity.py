@@ -192,6 +192,43 @@ def test_project_keep_table_and_block_mfma_dw(dev, n, f, xbf):
                            in_drop=drop, seed=seed, want_keep=True)[3] is None
 
 
+@pytest.mark.parametrize("P,n,f,xbf,K,FP,tdt", [(4, 16384 + 200, 256, False, 8, 8, torch.float32),
+                                                (3, 17000, 72, False, 8, 8, torch.float32),
+                                                (2, 20000, 132, True, 8, 8, torch.bfloat16),
+                                                (5, 16500, 64, False, 4, 16, torch.float32),
+                                                (2, 3000, 256, False, 8, 8, torch.float32)])
+@pytest.mark.parametrize("flags", [0, 32])
+def test_project_fwd_multi_matches_the_per_meta_path_kernel(dev, P, n, f, xbf, K, FP, tdt, flags):
+    """Round 3: the eval forward of all P meta-paths of a shared X in one fused launch (X read, split and staged once
+    for 4 or 2 meta-paths per block; odd P leaves one to the single kernel; short inputs and other cases loop):
+    H against the float64 product, and H / f1 / f2 against the per-meta-path kernel on the same matrix pipe."""
+    from han_amd import ops
+    rng = np.random.default_rng(P * 100 + f)
+    x = rng.standard_normal((n, f)) * np.exp(0.5 * rng.standard_normal((n, 1)))
+    W = rng.standard_normal((P, f, 64)) * 0.2
+    a1, a2 = rng.standard_normal((P, K, FP)), rng.standard_normal((P, K, FP))
+    b1, b2 = rng.standard_normal((P, K)), rng.standard_normal((P, K))
+    xt = _t(x, dev).to(torch.bfloat16) if xbf else _t(x, dev)
+    xf = xt.to(torch.float32).cpu().numpy().astype(np.float64)
+    Wt, a1t, a2t, b1t, b2t = (_t(v, dev) for v in (W, a1, a2, b1, b2))
+    H, f1, f2 = ops.project_fwd_multi(xt, Wt, a1t, a2t, b1t, b2t, table_dtype=tdt, flags=flags)
+    assert H.shape == (P, n, 64) and f1.shape == (P, n, K)
+    for p in range(P):
+        Href = xf @ W[p].astype(np.float32).astype(np.float64)
+        Hp = H[p].to(torch.float32).cpu().numpy()
+        tol = 1e-2 if tdt == torch.bfloat16 else 2e-6
+        assert np.abs(Hp - Href).max() < tol * max(1.0, np.abs(Href).max()), p
+        Hs, g1, g2 = ops.project_fwd(xt, Wt[p], a1t[p], a2t[p], b1t[p], b2t[p], table_dtype=tdt,
+                                     flags=ops.FLAG_K1_MATRIX_PIPE)
+        if n >= 16384 and p < P - P % 2:      # fused: the same six products in the same order, bit-identical rows
+            assert torch.equal(H[p], Hs), p      # (an odd last meta-path runs the single-path kernel)
+        st = Hp.astype(np.float64).reshape(n, K, FP)
+        f1ref = (st * a1[p][None]).sum(-1) + b1[p]
+        f2ref = (st * a2[p][None]).sum(-1) + b2[p]
+        assert np.abs(f1[p].cpu().numpy() - f1ref).max() < 1e-4 * max(1.0, np.abs(f1ref).max()), p
+        assert np.abs(f2[p].cpu().numpy() - f2ref).max() < 1e-4 * max(1.0, np.abs(f2ref).max()), p
+
+
 @pytest.mark.parametrize("K,FP", [(4, 16), (16, 4), (2, 32)])
 @pytest.mark.parametrize("n,f,xbf", [(3000, 256, False), (16500, 64, True)])
 def test_bf16_table_scores_follow_the_head_width(dev, K, FP, n, f, xbf):
@@ -1316,6 +1353,47 @@ def test_bf16_mode_forward_backward(dev, drop, P):
     for k in ht.PARAM_ORDER:
         got = getattr(model, k).grad.cpu().numpy()
         assert rel_err(got, gref[k]) < (0.2 if k in ("a1", "b1", "b2") else 6e-2), k
+
+
+@pytest.mark.parametrize("deg", [13, 40, 64, 150, 700])
+@pytest.mark.parametrize("cd,fd", [(0.0, 0.0), (0.6, 0.6), (0.6, 0.0), (0.0, 0.6)])
+def test_bf16_one_lane_per_head_map_matches_the_16_lane_map(dev, deg, cd, fd):
+    """Round 3: bf16 8 x 8 tables run K2 with ONE LANE PER HEAD (8 groups of 8 lanes, 16-byte loads, 8 neighbours
+    per step; node_attn_fwd_h8_kernel / node_attn_bwd_cols_h8_kernel).  Same tables, same draws, same arithmetic
+    as the 16-lane map (HAN_FLAG_K2_LANES16) up to the order of fp32 sums: eval forward, training forward with
+    its saved statistics, and the transposed-graph backward, on degrees with full steps, tails and several
+    64-edge batches (and a weighted adjacency)."""
+    from han_amd import ops, synth
+    from han_amd.graph import CSRGraph
+    n = 1500
+    g = synth.random_regular_graph(n, deg, 5, dev)
+    rng = np.random.default_rng(deg)
+    gens = lambda *sh: _t(rng.standard_normal(sh), dev)
+    x = gens(n, 64)
+    a1, a2, b1, b2, c = gens(8, 8) * 0.3, gens(8, 8) * 0.3, gens(8) * 0.1, gens(8) * 0.1, gens(64) * 0.1
+    H, f1, f2 = ops.project_fwd(x, torch.eye(64, device=dev), a1, a2, b1, b2, in_drop=0.0, fts_drop=fd, seed=9,
+                                table_dtype=torch.bfloat16)
+    dOut = gens(n, 64)
+    res = {}
+    for vals in (None, _t(rng.uniform(0.5, 1.5, g.nnz), dev)):
+        gg = CSRGraph(g.rowptr, g.colidx, n, validate=False, values=vals)
+        gt = gg.transpose()
+        for flag in (0, ops.FLAG_K2_LANES16):
+            ops.K2_EXTRA_FLAGS = flag
+            try:
+                out_e, _ = ops.node_attn_fwd(gg, H, f1, a2, b2, c) if fd == 0 else (None, None)
+                out_t, sv = ops.node_attn_fwd(gg, H, f1, a2, b2, c, train=True, coef_drop=cd, fts_drop=fd, seed=77)
+                pre, lse, aggp, tsum = sv
+                gs, df1, _ = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, table_dtype=torch.bfloat16)
+                dH, df2 = ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, coef_drop=cd, fts_drop=fd, seed=77)
+            finally:
+                ops.K2_EXTRA_FLAGS = 0
+            res[flag] = (out_e, out_t, pre, lse, aggp, tsum, dH, df2)
+        for a_, b_, nm in zip(res[0], res[ops.FLAG_K2_LANES16], ("eval", "train", "pre", "lse", "aggp", "tsum", "dH", "df2")):
+            if a_ is None:
+                continue
+            d = float((a_ - b_).abs().max())
+            assert d < 2e-5 * max(1.0, float(b_.abs().max())), (nm, d, vals is not None)
 
 
 @pytest.mark.parametrize("K,FP", [(4, 16), (16, 4), (2, 32), (1, 64), (5, 12), (12, 8)])

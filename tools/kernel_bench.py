@@ -90,6 +90,15 @@ def main():
             t = timeit(lambda: ops.project_bwd(X, dH, 8, 8, in_drop=drop, seed=5))
             print(json.dumps({"kernel": f"project_bwd drop={drop} (draws regenerated)", "ms": round(t, 4),
                               "TFLOPs": round(fl / t / 1e9, 1)}))
+        # round 3: all P meta-paths of the shared X in one fused eval launch
+        Wp = rnd(p, f, 64) * 0.1
+        ap1, ap2, bp1, bp2 = rnd(p, 8, 8), rnd(p, 8, 8), rnd(p, 8), rnd(p, 8)
+        for mf in (0, 32):
+            t = timeit(lambda: ops.project_fwd_multi(X, Wp, ap1, ap2, bp1, bp2, flags=mf))
+            print(json.dumps({"kernel": f"project_fwd_multi eval P={p} flags={mf}", "ms": round(t, 4),
+                              "TFLOPs": round(p * fl / t / 1e9, 1)}))
+        t = timeit(lambda: [ops.project_fwd(X, Wp[i], ap1[i], ap2[i], bp1[i], bp2[i]) for i in range(p)])
+        print(json.dumps({"kernel": f"project_fwd eval x{p} (one launch per meta-path)", "ms": round(t, 4)}))
         # round 3: the forward writes the keep table, dW reads it (4x4x1 16-block MFMA kernel)
         t = timeit(lambda: ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.6, fts_drop=0.6, seed=5, want_keep=True, flags=fl_))
         print(json.dumps({"kernel": f"project_fwd drop=0.6 + keep table flags={fl_}", "ms": round(t, 4)}))
