@@ -173,7 +173,7 @@ def live_traffic(args, timeout_s=150):
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", c, "--",
                    sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
-                   "--no-cpu-baseline", "--hbm-regime-nodes", "0", "--traffic", "off",
+                   "--no-cpu-baseline", "--hbm-regime-nodes", "0", "--traffic", "off", "--skew-steps", "0",
                    "--workload", args.workload, "--table-dtype", args.table_dtype]
             if args.nodes:
                 cmd += ["--nodes", str(args.nodes)]
@@ -469,7 +469,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="capture the epoch into a hipGraph and replay it (single GPU; small graphs)")
-    ap.add_argument("--cpu-sample", type=int, default=10000,
+    ap.add_argument("--cpu-sample", type=int, default=50000,
                     help="nodes of the CPU-baseline sample (timed with all usable cores AND with one thread)")
     ap.add_argument("--hbm-regime-nodes", type=int, default=10_000_000,
                     help="rows of the extra single-meta-path table on which the K2 kernels are re-timed in the "
@@ -477,6 +477,11 @@ def main():
     ap.add_argument("--skew-steps", type=int, default=5,
                     help="epochs timed on the power-law variant of the headline workload (syn-1m-skew, same N / E / F / P) "
                          "in the same process after the timed region; reported as `skew` (0 = skip; N = 1, syn-1m only)")
+    ap.add_argument("--masked-backward", action="store_true",
+                    help="ALSO time the opt-in masked backward (HANTrainer.set_masked_backward: destinations outside the "
+                         "train mask are skipped in the transposed-graph pass and, under a partition, only the live rows "
+                         "of the backward table travel) after the headline region; reported as `masked_backward`, never "
+                         "as `value`")
     ap.add_argument("--reorder", choices=("none", "bfs"), default="none",
                     help="locality pass (han_amd.reorder): breadth-first relabelling of the nodes before training "
                          "(single GPU; the pass itself is timed separately and reported)")
@@ -610,6 +615,32 @@ def main():
                                                             ms1["allocated_bytes.all.peak"] / 1e9), file=sys.stderr)
     timing, ops.K2_TIMING = ops.K2_TIMING or [], None
     use_graph = trainer.use_graph
+    masked_info = None
+    if args.masked_backward and not use_graph:
+        # the extra, never the headline: same model state, same steps, the backward restricted to the live rows
+        trainer.set_masked_backward(True)
+        for _ in range(max(args.warmup, 1)):
+            trainer.epoch()
+        barrier()
+        t0m = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.epoch()
+        barrier()
+        dtm = time.perf_counter() - t0m
+        if use_dist:
+            tm = torch.tensor([dtm], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dtm = float(tm.item())
+        rb = ops.gs_row_bytes(8, 8, tdt)
+        plans_m = trainer._masked_plans
+        masked_info = {"value": round(args.steps / dtm, 4), "unit": "epochs/s",
+                       "ms_per_step": round(dtm / args.steps * 1e3, 3),
+                       "live_fraction": round(float(trainer.train_mask.float().mean()), 4),
+                       "bytes_on_wire": {"backward_table_per_rank_per_step_masked": int(sum(pl.rows_on_wire for pl in plans_m) * rb),
+                                         "backward_table_per_rank_per_step_full": int((world - 1) * (part.shard if part is not None else 0) * rb * p)},
+                       "note": "opt-in: bit-identical results (dead entries of the transposed graph skipped in place); "
+                               "the headline `value` is the full pass"}
+        trainer.set_masked_backward(False)
     if use_dist:
         t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -691,6 +722,8 @@ def main():
             out["roofline"] = None
             out["roofline_note"] = ("no per-kernel HIP events in this run (an epoch replayed from a hipGraph "
                                     "records none); run without --graph for the K2 rooflines")
+        if masked_info is not None:
+            out["masked_backward"] = masked_info
         if skew is not None:
             # "a second, skewed variant must be reported beside it" (real meta-path graphs are skewed)
             out["skew"] = skew

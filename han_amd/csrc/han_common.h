@@ -162,9 +162,9 @@ struct HanReduceOut {
     float *ptr[4];
     int seg_end[4];
     int nseg;
-    float scale;
-    int rep;
-    int64_t rep_stride;
+    float scale[4];          // per segment
+    int rep[4];              // per segment: replicas written at stride rep_stride[seg]
+    int64_t rep_stride[4];
 };
 
 static __global__ __launch_bounds__(256) void han_reduce_slabs_kernel(const float *slab, int nblocks,
@@ -182,10 +182,10 @@ static __global__ __launch_bounds__(256) void han_reduce_slabs_kernel(const floa
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += part[r][nn];
-        t *= o.scale;
         int seg = 0, base = 0;
         while (seg < o.nseg - 1 && n >= o.seg_end[seg]) { base = o.seg_end[seg]; ++seg; }
-        for (int r = 0; r < o.rep; ++r) o.ptr[seg][(int64_t)r * o.rep_stride + (n - base)] = t;
+        t *= o.scale[seg];
+        for (int r = 0; r < o.rep[seg]; ++r) o.ptr[seg][(int64_t)r * o.rep_stride[seg] + (n - base)] = t;
     }
 }
 
@@ -200,7 +200,8 @@ static inline HanReduceOut han_reduce_to(float *out, int width) {
     HanReduceOut o;
     o.ptr[0] = out; o.ptr[1] = o.ptr[2] = o.ptr[3] = nullptr;
     o.seg_end[0] = width; o.seg_end[1] = o.seg_end[2] = o.seg_end[3] = width;
-    o.nseg = 1; o.scale = 1.f; o.rep = 1; o.rep_stride = 0;
+    o.nseg = 1;
+    for (int i = 0; i < 4; ++i) { o.scale[i] = 1.f; o.rep[i] = 1; o.rep_stride[i] = 0; }
     return o;
 }
 

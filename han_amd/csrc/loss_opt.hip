@@ -396,19 +396,21 @@ extern "C" int han_classifier_loss(const float *Z, const float *Wc, const float 
     else launch_classifier<1>(a, bwd, grid, st);
     HAN_CHECK_LAUNCH();
     const int width = D * C + C + 2;
-    // loss / accuracy (the last two slab columns), then the head gradients: every
-    // head receives the same (1/HC)-scaled gradient (models/gat.py:72 averages them)
+    // one second-stage launch: the head gradients (every head receives the same (1/HC)-scaled gradient,
+    // models/gat.py:72 averages them) and loss / accuracy (the last two slab columns)
     const float *slab = (const float *)workspace;
-    hipError_t e = han_reduce_slabs(slab + D * C + C, grid, width, 2, han_reduce_to(loss_acc, 2), st);
-    if (e != hipSuccess) return (int)e;
     if (bwd) {
-        HanReduceOut ow = han_reduce_to(dWc, D * C);
-        ow.scale = 1.f / (float)HC; ow.rep = HC; ow.rep_stride = (int64_t)D * C;
-        e = han_reduce_slabs(slab, grid, width, D * C, ow, st);
+        HanReduceOut o = han_reduce_to(dWc, width);
+        o.nseg = 3;
+        o.ptr[1] = dbc; o.ptr[2] = loss_acc;
+        o.seg_end[0] = D * C; o.seg_end[1] = D * C + C; o.seg_end[2] = width;
+        o.scale[0] = o.scale[1] = 1.f / (float)HC;
+        o.rep[0] = o.rep[1] = HC;
+        o.rep_stride[0] = (int64_t)D * C; o.rep_stride[1] = C;
+        hipError_t e = han_reduce_slabs(slab, grid, width, width, o, st);
         if (e != hipSuccess) return (int)e;
-        HanReduceOut ob = han_reduce_to(dbc, C);
-        ob.scale = 1.f / (float)HC; ob.rep = HC; ob.rep_stride = C;
-        e = han_reduce_slabs(slab + D * C, grid, width, C, ob, st);
+    } else {
+        hipError_t e = han_reduce_slabs(slab + D * C + C, grid, width, 2, han_reduce_to(loss_acc, 2), st);
         if (e != hipSuccess) return (int)e;
     }
     return 0;

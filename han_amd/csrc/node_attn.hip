@@ -57,7 +57,7 @@ __device__ __forceinline__ float dot4(const float4_t &x, const float4_t &y) {
 // the caller does not set HAN_FLAG_XCD_ORDER (graphs without locality: 9 % slower in the HBM regime).
 __device__ __forceinline__ int64_t xcd_first_unit(int wave_in_block, int xcd_order) {
     const unsigned b = blockIdx.x, g = gridDim.x;
-    const unsigned vb = ((xcd_order & 1) && g % 8u == 0u) ? (b % 8u) * (g / 8u) + b / 8u : b;
+    const unsigned vb = (xcd_order && g % 8u == 0u) ? (b % 8u) * (g / 8u) + b / 8u : b;
     return (int64_t)vb * 4 + wave_in_block;
 }
 
@@ -583,6 +583,7 @@ struct BwdColsArgs {
     float inv_keep_coef, inv_keep_fts;
     int64_t src_offset, dst_offset;
     int xcd_order;
+    int masked;          // HAN_FLAG_MASKED_EDGES
     int64_t split_deg;
     int64_t n_long, n_chunks;
     const int64_t *long_rows, *long_ptr, *chunk_start, *chunk_end;
@@ -618,7 +619,11 @@ __device__ __forceinline__ SrcRow load_src(const BwdColsArgs &a, const int64_t s
 }
 
 // gather U destinations i of source j and accumulate  acc += alpha~ g_i,  df += dl_ij
-template <int FP, int U, bool BF, bool VAL, bool FAST, bool ALLV>
+// MASKED (HAN_FLAG_MASKED_EDGES): entries of rowidx below 0 are edges whose destination cannot contribute (its g row is
+// identically zero: a destination outside the loss mask of a one-layer model); they keep their POSITION in the
+// row -- so every remaining term is added by the same lane group in the same order as in the full pass and the
+// sums are bit-identical -- but nothing is loaded for them.
+template <int FP, int U, bool BF, bool VAL, bool FAST, bool ALLV, bool MASKED = false>
 __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)[U], const float (&ew)[U],
                                             const bool (&valid)[U], const SrcRow &sr, const int q, const int head, const bool drop_c,
                                             float (&acc)[4], float &dfacc) {
@@ -627,8 +632,17 @@ __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)
     float4_t gv[U], st[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        gv[u] = gs_load_g4<FP, BF>(a.gs, (int64_t)i[u], q);
-        st[u] = gs_load_stats<FP, BF>(a.gs, (int64_t)i[u], head);
+        if (MASKED) {
+            gv[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            st[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            if (valid[u]) {
+                gv[u] = gs_load_g4<FP, BF>(a.gs, (int64_t)i[u], q);
+                st[u] = gs_load_stats<FP, BF>(a.gs, (int64_t)i[u], head);
+            }
+        } else {
+            gv[u] = gs_load_g4<FP, BF>(a.gs, (int64_t)i[u], q);
+            st[u] = gs_load_stats<FP, BF>(a.gs, (int64_t)i[u], head);
+        }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -641,7 +655,7 @@ __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)
         float am = 1.f;
         if (FAST || drop_c) {
             const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF,
-                                            (uint32_t)(((!FAST && a.gid) ? (int64_t)a.gid[i[u]] : (int64_t)i[u]) + a.dst_offset),
+                                            (uint32_t)(((!FAST && a.gid) ? (int64_t)a.gid[(MASKED && !valid[u]) ? 0 : i[u]] : (int64_t)i[u]) + a.dst_offset),
                                             sr.gj * (uint32_t)KQ + (uint32_t)(head >> 2));
             am = rn.field(head & 3) < a.thr_coef ? a.inv_keep_coef : 0.f;
         }
@@ -666,7 +680,7 @@ __device__ __forceinline__ void write_src(const BwdColsArgs &a, const int64_t sr
     if ((4 * q) % FP == 0) a.df2[src * K + head] = dfacc;
 }
 
-template <int FP, int RPW, int U, bool BF, bool VAL, bool FAST>
+template <int FP, int RPW, int U, bool BF, bool VAL, bool FAST, bool MASKED = false>
 __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsArgs a_in) {
     BwdColsArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
@@ -718,11 +732,11 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int idx = (st + u) * 4 + g;
-                        valid[u] = true;
                         i[u] = __shfl(myrow, idx, 64);
+                        valid[u] = MASKED ? i[u] >= 0 : true;
                         ew[u] = VAL ? __shfl(myval, idx, 64) : 1.f;
                     }
-                    bwd_consume<FP, U, BF, VAL, FAST, true>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+                    bwd_consume<FP, U, BF, VAL, FAST, !MASKED, MASKED>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
                 }
                 if (U > 4 && (st + 4) * 4 <= cnt) {             // long unrolls: one half step before the singles
                     int i[4];
@@ -731,19 +745,19 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int idx = (st + u) * 4 + g;
-                        valid[u] = true;
                         i[u] = __shfl(myrow, idx, 64);
+                        valid[u] = MASKED ? i[u] >= 0 : true;
                         ew[u] = VAL ? __shfl(myval, idx, 64) : 1.f;
                     }
-                    bwd_consume<FP, 4, BF, VAL, FAST, true>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+                    bwd_consume<FP, 4, BF, VAL, FAST, !MASKED, MASKED>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
                     st += 4;
                 }
                 for (; st * 4 < cnt; ++st) {                    // tail: single steps of 4 edges
                     const int idx = st * 4 + g;
-                    const bool valid[1] = {idx < cnt};
                     const int i[1] = {__shfl(myrow, idx & 63, 64)};
+                    const bool valid[1] = {idx < cnt && (!MASKED || i[0] >= 0)};
                     const float ew[1] = {VAL ? __shfl(myval, idx & 63, 64) : 1.f};
-                    bwd_consume<FP, 1, BF, VAL, FAST, false>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+                    bwd_consume<FP, 1, BF, VAL, FAST, false, MASKED>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
                 }
             }
         }
@@ -756,9 +770,10 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
                 const int64_t k = it + u;
                 valid[u] = k < len;
                 i[u] = len > 0 ? a.rowidx[valid[u] ? s + k : s] : 0;
+                if (MASKED) valid[u] = valid[u] && i[u] >= 0;
                 ew[u] = (VAL && len > 0) ? a.edge_val[valid[u] ? s + k : s] : 1.f;
             }
-            bwd_consume<FP, U, BF, VAL, FAST, false>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+            bwd_consume<FP, U, BF, VAL, FAST, false, MASKED>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
         }
         if (RPW == 1) {
 #pragma unroll
@@ -799,9 +814,10 @@ __global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsA
                 const int64_t k = (it + u) * 4 + g;
                 valid[u] = k < len;
                 i[u] = a.rowidx[valid[u] ? s + k : s];
+                valid[u] = valid[u] && i[u] >= 0;          // masked edges (HAN_FLAG_MASKED_EDGES) are skipped
                 ew[u] = VAL ? a.edge_val[valid[u] ? s + k : s] : 1.f;
             }
-            bwd_consume<FP, U, BF, VAL, false, false>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+            bwd_consume<FP, U, BF, VAL, false, false, true>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
         }
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
@@ -840,330 +856,6 @@ __global__ __launch_bounds__(256) void node_attn_bwd_finish_kernel(const BwdCols
         dfacc += w[64 + head];
     }
     write_src<FP>(a, src, sr, acc, dfacc, q, head, a14, a24);
-}
-
-// ---------------------------------------------------------------------------------------------
-// bf16 tables, 8 heads x 8 features: ONE LANE PER HEAD (round 3).
-//
-// A bf16 row is 128 B.  With the fp32 lane map (16 lanes x 8 B) two lanes share every head, so each per-edge
-// scalar operation -- score, LeakyReLU, exp, running max, the attention-dropout draw -- is paid by 16 lanes
-// for 128 B of payload; the bf16 forwards were the VALU-bound K2 kernels (issue fraction 0.97 training / 0.81
-// eval at N = 10M, profiles/r02_pmc_k2_keepbits_experiment.json).  Here a wave is 8 groups of 8 lanes, lane h of
-// a group loads the 16 bytes of head h (8 bf16) of its group's neighbour: 8 neighbours per step, the head
-// sums are in-lane (no DPP), and the scalar work per edge is paid by 8 lanes.  Same arithmetic, same
-// summation order within a head's features is NOT required by any test (fp32 sums of 8 terms), results
-// agree with the 16-lane map to rounding.  Long rows (split) keep the chunk kernels above.
-// ---------------------------------------------------------------------------------------------
-struct Row8 {
-    float v[8];
-};
-
-__device__ __forceinline__ Row8 load_bf16_row8(const void *tab, int64_t row_bytes, int64_t row, int h) {
-    const uint4 w = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(tab) + row * row_bytes + 16 * h);
-    Row8 r;
-    r.v[0] = __uint_as_float(w.x << 16); r.v[1] = __uint_as_float(w.x & 0xFFFF0000u);
-    r.v[2] = __uint_as_float(w.y << 16); r.v[3] = __uint_as_float(w.y & 0xFFFF0000u);
-    r.v[4] = __uint_as_float(w.z << 16); r.v[5] = __uint_as_float(w.z & 0xFFFF0000u);
-    r.v[6] = __uint_as_float(w.w << 16); r.v[7] = __uint_as_float(w.w & 0xFFFF0000u);
-    return r;
-}
-
-template <bool TRAIN>
-struct RowState8 {
-    float m, l, tl;
-    float acc[8], accp[8];
-    __device__ __forceinline__ void init() {
-        m = HAN_NEG_BIG; l = 0.f; tl = 0.f;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) { acc[t] = 0.f; accp[t] = 0.f; }
-    }
-    __device__ __forceinline__ void merge(int off) {
-        const float m_o = __shfl_xor(m, off, 64);
-        const float l_o = __shfl_xor(l, off, 64);
-        const float M = fmaxf(m, m_o);
-        const float sa = __expf(m - M), sb = __expf(m_o - M);
-        l = l * sa + l_o * sb;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = acc[t] * sa + __shfl_xor(acc[t], off, 64) * sb;
-        if (TRAIN) {
-            tl = tl * sa + __shfl_xor(tl, off, 64) * sb;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) accp[t] = accp[t] * sa + __shfl_xor(accp[t], off, 64) * sb;
-        }
-        m = M;
-    }
-};
-
-template <bool TRAIN, int U, bool VAL, bool FAST, bool ALLV>
-__device__ __forceinline__ void consume_edges8(const FwdArgs &a, const int (&j)[U], const float (&w)[U],
-                                               const bool (&valid)[U], const float f1h, const uint32_t gi, const int h,
-                                               const float (&a28)[8], const float b2h, const bool drop_c,
-                                               RowState8<TRAIN> &st) {
-    Row8 hv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) hv[u] = load_bf16_row8(a.H, 128, (int64_t)j[u], h);
-    float ev[U], sg[U];
-    float mc = st.m;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        float d = 0.f;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) d += hv[u].v[t] * a28[t];
-        float x = f1h + (d + b2h);                                       // layers.py:24,26
-        if (VAL) x *= w[u];
-        sg[u] = x > 0.f ? 1.f : a.slope;
-        if (VAL) sg[u] *= w[u];
-        ev[u] = (ALLV || valid[u]) ? han_lrelu(x, a.slope) : HAN_NEG_BIG;   // layers.py:27
-        mc = fmaxf(mc, ev[u]);
-    }
-    const float sc = __expf(st.m - mc);
-    st.l *= sc;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) st.acc[t] *= sc;
-    if (TRAIN) {
-        st.tl *= sc;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) st.accp[t] *= sc;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const float p = (ALLV || valid[u]) ? __expf(ev[u] - mc) : 0.f;
-        st.l += p;
-        float pd = p;
-        if (TRAIN) {
-            if (FAST || drop_c) {   // attention dropout, layers.py:29-30: counter (i, 2 j + h / 4), field h % 4
-                const uint32_t gj = (!FAST && a.gid) ? (uint32_t)a.gid[j[u]] : (uint32_t)j[u];
-                const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi, gj * 2u + (uint32_t)(h >> 2));
-                pd = rn.field(h & 3) < a.thr_coef ? p : 0.f;
-            }
-            if (FAST || a.lsb_mask) {   // projected-row dropout, layers.py:31-32: the keep bit is the bf16's lowest bit
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int bits = __float_as_int(hv[u].v[t]);
-                    hv[u].v[t] = __int_as_float(bits & han_bit_mask<16>(bits));
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) st.acc[t] += pd * hv[u].v[t];
-        if (TRAIN) {
-            st.tl += p * sg[u];
-            const float pds = pd * sg[u];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) st.accp[t] += pds * hv[u].v[t];
-        }
-    }
-    st.m = mc;
-}
-
-template <bool TRAIN>
-__device__ __forceinline__ void write_row8(const FwdArgs &a, const int64_t row, const RowState8<TRAIN> &st, const int h,
-                                           const float (&c8)[8], const bool writer) {
-    const float inv = st.l > 0.f ? 1.f / st.l : 0.f;
-    const float scale = TRAIN ? inv * a.inv_keep_coef * (a.lsb_mask ? a.inv_keep_fts : 1.f) : inv;
-    float r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (a.res && writer) {
-        const float4_t r0 = *reinterpret_cast<const float4_t *>(a.res + row * HAN_D + 8 * h);
-        const float4_t r1 = *reinterpret_cast<const float4_t *>(a.res + row * HAN_D + 8 * h + 4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { r8[t] = r0[t]; r8[4 + t] = r1[t]; }
-    }
-    float4_t pv[2], ov[2], ap[2];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const float pre = st.acc[t] * scale + c8[t] + r8[t];
-        pv[t >> 2][t & 3] = pre;
-        ov[t >> 2][t & 3] = a.activation == HAN_ACT_ELU ? han_elu(pre) : pre;
-        if (TRAIN) ap[t >> 2][t & 3] = st.accp[t] * scale;
-    }
-    if (writer) {
-        float *o = a.out + row * a.out_stride + 8 * h;
-        *reinterpret_cast<float4_t *>(o) = ov[0];
-        *reinterpret_cast<float4_t *>(o + 4) = ov[1];
-        if (TRAIN) {
-            *reinterpret_cast<float4_t *>(a.pre + row * HAN_D + 8 * h) = pv[0];
-            *reinterpret_cast<float4_t *>(a.pre + row * HAN_D + 8 * h + 4) = pv[1];
-            *reinterpret_cast<float4_t *>(a.aggp + row * HAN_D + 8 * h) = ap[0];
-            *reinterpret_cast<float4_t *>(a.aggp + row * HAN_D + 8 * h + 4) = ap[1];
-            a.lse[row * 8 + h] = st.l > 0.f ? st.m + __logf(st.l) : HAN_NEG_BIG;
-            a.tsum[row * 8 + h] = st.tl * inv;
-        }
-    }
-}
-
-template <bool TRAIN, int U, bool VAL, bool FAST>
-__global__ __launch_bounds__(256) void node_attn_fwd_h8_kernel(const FwdArgs a_in) {
-    FwdArgs a = a_in;
-    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 3, h = lane & 7;
-    const int64_t wave0 = xcd_first_unit(threadIdx.x >> 6, a.xcd_order);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    float c8[8], a28[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) { c8[t] = a.c[8 * h + t]; a28[t] = a.a2[8 * h + t]; }
-    const float b2h = a.b2[h];
-    const bool drop_c = TRAIN && a.thr_coef < HAN_KEEP_ALL;
-
-    for (int64_t row = wave0; row < a.N; row += nwaves) {
-        const int64_t s = a.rowptr[row];
-        const int64_t e_raw = a.rowptr[row + 1];
-        const bool is_long = e_raw - s > a.split_deg;      // handled by the chunk kernels
-        const int64_t e = is_long ? s : e_raw;
-        const float f1h = a.f1[row * 8 + h];
-        const uint32_t gi = (uint32_t)(row + a.row_offset);
-        RowState8<TRAIN> st;
-        st.init();
-        for (int64_t base = s; base < e; base += 64) {
-            const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
-            const int mycol = a.colidx[base + (lane < cnt ? lane : cnt - 1)];
-            const float myval = VAL ? a.edge_val[base + (lane < cnt ? lane : cnt - 1)] : 1.f;
-            int it = 0;
-            for (; (it + U) * 8 <= cnt; it += U) {       // full steps: every slot is an edge
-                int j[U];
-                float w[U];
-                bool valid[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int idx = (it + u) * 8 + g;
-                    valid[u] = true;
-                    j[u] = __shfl(mycol, idx, 64);
-                    w[u] = VAL ? __shfl(myval, idx, 64) : 1.f;
-                }
-                consume_edges8<TRAIN, U, VAL, FAST, true>(a, j, w, valid, f1h, gi, h, a28, b2h, drop_c, st);
-            }
-            for (; it * 8 < cnt; ++it) {                 // tail: single steps of 8 edges
-                const int idx = it * 8 + g;
-                const int j[1] = {__shfl(mycol, idx & 63, 64)};
-                const float w[1] = {VAL ? __shfl(myval, idx & 63, 64) : 1.f};
-                const bool valid[1] = {idx < cnt};
-                consume_edges8<TRAIN, 1, VAL, FAST, false>(a, j, w, valid, f1h, gi, h, a28, b2h, drop_c, st);
-            }
-        }
-        st.merge(8);
-        st.merge(16);
-        st.merge(32);
-        write_row8<TRAIN>(a, row, st, h, c8, !is_long && g == 0);
-    }
-}
-
-// the transposed-graph pass with the same lane map: lane h gathers the 16 bytes of head h of g_i and the
-// 16-byte (f1, lse, s, 0) record of head h -- two aligned 16-byte loads per lane and destination
-struct SrcRow8 {
-    float hd[8], mk[8];
-    float f2h;
-    uint32_t gj;
-};
-
-template <int U, bool VAL, bool FAST, bool ALLV>
-__device__ __forceinline__ void bwd_consume8(const BwdColsArgs &a, const int (&i)[U], const float (&ew)[U],
-                                             const bool (&valid)[U], const SrcRow8 &sr, const int h, const bool drop_c,
-                                             float (&acc)[8], float &dfacc) {
-    Row8 gv[U];
-    float4_t st[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        gv[u] = load_bf16_row8(a.gs, 256, (int64_t)i[u], h);
-        st[u] = *reinterpret_cast<const float4_t *>(reinterpret_cast<const char *>(a.gs) + (int64_t)i[u] * 256 + 128 + 16 * h);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        float x = st[u][0] + sr.f2h;
-        if (VAL) x *= ew[u];
-        float sg = x > 0.f ? 1.f : a.slope;
-        if (VAL) sg *= ew[u];
-        float alpha = __expf(han_lrelu(x, a.slope) - st[u][1]);
-        alpha = (ALLV || valid[u]) ? alpha : 0.f;
-        float am = 1.f;
-        if (FAST || drop_c) {
-            const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF,
-                                            (uint32_t)(((!FAST && a.gid) ? (int64_t)a.gid[i[u]] : (int64_t)i[u]) + a.dst_offset),
-                                            sr.gj * 2u + (uint32_t)(h >> 2));
-            am = rn.field(h & 3) < a.thr_coef ? a.inv_keep_coef : 0.f;
-        }
-        float dot = 0.f;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) dot += gv[u].v[t] * sr.hd[t];
-        dfacc += alpha * sg * (am * dot - st[u][2]);
-        const float w = alpha * am;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] += w * gv[u].v[t];
-    }
-}
-
-template <int U, bool VAL, bool FAST>
-__global__ __launch_bounds__(256) void node_attn_bwd_cols_h8_kernel(const BwdColsArgs a_in) {
-    BwdColsArgs a = a_in;
-    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 3, h = lane & 7;
-    const int64_t wave0 = xcd_first_unit(threadIdx.x >> 6, a.xcd_order);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const bool drop_c = a.thr_coef < HAN_KEEP_ALL;
-    float a18[8], a28[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) { a18[t] = a.a1[8 * h + t]; a28[t] = a.a2[8 * h + t]; }
-
-    for (int64_t src = wave0; src < a.NS; src += nwaves) {
-        const int64_t s = a.colptr[src];
-        const int64_t e_raw = a.colptr[src + 1];
-        const bool is_long = e_raw - s > a.split_deg;
-        const int64_t e = is_long ? s : e_raw;
-        SrcRow8 sr;
-        sr.gj = (uint32_t)(src + a.src_offset);
-        sr.f2h = a.f2[src * 8 + h];
-        {
-            const Row8 hr = load_bf16_row8(a.H, 128, src, h);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                sr.mk[t] = a.lsb_mask ? (han_keep_bit<true>(hr.v[t]) ? a.inv_keep_fts : 0.f) : 1.f;
-                sr.hd[t] = hr.v[t] * sr.mk[t];
-            }
-        }
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float dfacc = 0.f;
-        for (int64_t base = s; base < e; base += 64) {
-            const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
-            const int myrow = a.rowidx[base + (lane < cnt ? lane : cnt - 1)];
-            const float myval = VAL ? a.edge_val[base + (lane < cnt ? lane : cnt - 1)] : 1.f;
-            int stp = 0;
-            for (; (stp + U) * 8 <= cnt; stp += U) {
-                int i[U];
-                float ew[U];
-                bool valid[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int idx = (stp + u) * 8 + g;
-                    valid[u] = true;
-                    i[u] = __shfl(myrow, idx, 64);
-                    ew[u] = VAL ? __shfl(myval, idx, 64) : 1.f;
-                }
-                bwd_consume8<U, VAL, FAST, true>(a, i, ew, valid, sr, h, drop_c, acc, dfacc);
-            }
-            for (; stp * 8 < cnt; ++stp) {
-                const int idx = stp * 8 + g;
-                const bool valid[1] = {idx < cnt};
-                const int i[1] = {__shfl(myrow, idx & 63, 64)};
-                const float ew[1] = {VAL ? __shfl(myval, idx & 63, 64) : 1.f};
-                bwd_consume8<1, VAL, FAST, false>(a, i, ew, valid, sr, h, drop_c, acc, dfacc);
-            }
-        }
-#pragma unroll
-        for (int off = 8; off <= 32; off <<= 1) {
-            dfacc += __shfl_xor(dfacc, off, 64);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) acc[t] += __shfl_xor(acc[t], off, 64);
-        }
-        if (!is_long && g == 0) {
-            const float d1 = a.df1[src * 8 + h];
-            float4_t o[2];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) o[t >> 2][t & 3] = acc[t] * sr.mk[t] + d1 * a18[t] + dfacc * a28[t];
-            *reinterpret_cast<float4_t *>(a.dH + src * HAN_D + 8 * h) = o[0];
-            *reinterpret_cast<float4_t *>(a.dH + src * HAN_D + 8 * h + 4) = o[1];
-            a.df2[src * 8 + h] = dfacc;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1338,12 +1030,6 @@ static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split,
         const int grid = attn_grid((a.N + 3) / 4);
         if (train) node_attn_fwd_kernel<FPC, true, 4, 2, BF, VAL, false, false><<<grid, 256, 0, st>>>(a);
         else node_attn_fwd_kernel<FPC, false, 4, 2, BF, VAL, false, false><<<grid, 256, 0, st>>>(a);
-    } else if (BF && FPC == 8 && !(a.xcd_order & 2)) {
-        // bf16, 8 heads x 8: one lane per head, 8 neighbours per step (node_attn_fwd_h8_kernel)
-        const int grid = attn_grid(a.N);
-        if (train && fast) node_attn_fwd_h8_kernel<true, 4, VAL, true><<<grid, 256, 0, st>>>(a);
-        else if (train) node_attn_fwd_h8_kernel<true, 4, VAL, false><<<grid, 256, 0, st>>>(a);
-        else node_attn_fwd_h8_kernel<false, 4, VAL, false><<<grid, 256, 0, st>>>(a);
     } else {
         const int grid = attn_grid(a.N);
         // bf16 rows are 128 B: the eval forward (and the backward gather) keep 8 steps in flight
@@ -1370,11 +1056,11 @@ static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split,
 template <int FPC, bool BF, bool VAL>
 static void launch_bwd_cols_v(const BwdColsArgs &a, bool low, bool has_split, hipStream_t st) {
     const bool fast = a.thr_coef < HAN_KEEP_ALL && !a.gid;
-    if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF, VAL, false><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
-    else if (BF && FPC == 8 && !(a.xcd_order & 2)) {
-        if (fast) node_attn_bwd_cols_h8_kernel<4, VAL, true><<<attn_grid(a.NS), 256, 0, st>>>(a);
-        else node_attn_bwd_cols_h8_kernel<4, VAL, false><<<attn_grid(a.NS), 256, 0, st>>>(a);
-    } else if (fast) node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL, true><<<attn_grid(a.NS), 256, 0, st>>>(a);
+    if (a.masked) {      // opt-in masked backward: the general instantiations, dead entries skipped in place
+        if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF, VAL, false, true><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
+        else node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL, false, true><<<attn_grid(a.NS), 256, 0, st>>>(a);
+    } else if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF, VAL, false><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
+    else if (fast) node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL, true><<<attn_grid(a.NS), 256, 0, st>>>(a);
     else node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL, false><<<attn_grid(a.NS), 256, 0, st>>>(a);
     if (has_split) {
         node_attn_bwd_chunk_kernel<FPC, 4, BF, VAL><<<attn_grid(a.n_chunks), 256, 0, st>>>(a);
@@ -1425,8 +1111,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
     a.inv_keep_fts = 1.f / (1.f - fts_drop);
-    a.row_offset = row_offset; a.activation = activation;
-    a.xcd_order = ((flags & HAN_FLAG_XCD_ORDER) ? 1 : 0) | ((flags & HAN_FLAG_K2_LANES16) ? 2 : 0);
+    a.row_offset = row_offset; a.activation = activation; a.xcd_order = (flags & HAN_FLAG_XCD_ORDER) ? 1 : 0;
     const bool has_split = split && split->n_long > 0;
     a.split_deg = has_split ? split->split_deg : INT64_MAX;
     a.n_long = has_split ? split->n_long : 0;
@@ -1512,8 +1197,8 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
     a.inv_keep_fts = 1.f / (1.f - fts_drop);
-    a.src_offset = src_offset; a.dst_offset = dst_offset;
-    a.xcd_order = ((flags & HAN_FLAG_XCD_ORDER) ? 1 : 0) | ((flags & HAN_FLAG_K2_LANES16) ? 2 : 0);
+    a.src_offset = src_offset; a.dst_offset = dst_offset; a.xcd_order = (flags & HAN_FLAG_XCD_ORDER) ? 1 : 0;
+    a.masked = (flags & HAN_FLAG_MASKED_EDGES) ? 1 : 0;
     const bool has_split = split && split->n_long > 0;
     a.split_deg = has_split ? split->split_deg : INT64_MAX;
     a.n_long = has_split ? split->n_long : 0;

@@ -758,14 +758,22 @@ __global__ __launch_bounds__(512) void project_fwd_b6_multi_kernel(const ProjMul
 }
 
 // split-F epilogue: H[row] = sum over the f-chunks (fixed order), then the same keep-bit
-// stamping / bf16 rounding as the unsplit kernel's epilogue.
-template <bool BF>
-__global__ __launch_bounds__(256) void project_finish_kernel(const ProjFwdArgs a_in, int nsplit) {
+// stamping / bf16 rounding as the unsplit kernel's epilogue -- and the attention scores f1 / f2
+// (layers.py:23-24) from the row exactly as stored, in the same pass (round 3: one launch per
+// projection less on the short inputs, whose epochs are launch-bound).
+template <int FP, bool BF>
+__global__ __launch_bounds__(256) void project_finish_kernel(const ProjFwdArgs a_in, int nsplit, float *f1, float *f2) {
     ProjFwdArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
+    constexpr int K = HAN_D / FP;
     const int q = threadIdx.x & 15;
+    const int head = (4 * q) / FP;
     const int64_t grp0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int64_t ngrp = (int64_t)gridDim.x * 16;
+    const float4_t a14 = *reinterpret_cast<const float4_t *>(a.a1 + 4 * q);
+    const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
+    const float b1 = a.b1[head], b2 = a.b2[head];
+    // all 16 lanes of a group run the same trip count -> the in-head shuffles are safe
     for (int64_t row = grp0; row < a.N; row += ngrp) {
         float4_t v = {0.f, 0.f, 0.f, 0.f};
         for (int sidx = 0; sidx < nsplit; ++sidx) {
@@ -773,21 +781,39 @@ __global__ __launch_bounds__(256) void project_finish_kernel(const ProjFwdArgs a
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += pv[e];
         }
-        if (a.thr_fts < HAN_KEEP_ALL) {   // layers.py:31-32, d = 4q + e -> counter d/4 = q, field e
-            const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_FTS, (uint32_t)(row + a.row_offset),
-                                            (uint32_t)q);
+        HanRand64 rn = {0u, 0u};
+        if (a.thr_fts < HAN_KEEP_ALL)      // layers.py:31-32, d = 4q + e -> counter d/4 = q, field e
+            rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_FTS, (uint32_t)(row + a.row_offset), (uint32_t)q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t keepbit = rn.field(e) < a.thr_fts ? 1u : 0u;
-                if (BF) {
-                    const uint32_t b = (han_f32_to_bf16_bits(v[e]) & ~1u) | keepbit;
-                    v[e] = __uint_as_float(b << 16);
-                } else {
-                    v[e] = __uint_as_float((__float_as_uint(v[e]) & ~1u) | keepbit);
-                }
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t keepbit = rn.field(e) < a.thr_fts ? 1u : 0u;
+            if (BF) {
+                uint32_t b = han_f32_to_bf16_bits(v[e]);
+                if (a.thr_fts < HAN_KEEP_ALL) b = (b & ~1u) | keepbit;
+                v[e] = __uint_as_float(b << 16);          // the value as stored (what the scores see)
+            } else if (a.thr_fts < HAN_KEEP_ALL) {
+                v[e] = __uint_as_float((__float_as_uint(v[e]) & ~1u) | keepbit);
             }
         }
-        han_store_row4<BF>(a.H, row, q, v);
+        if (BF) {      // already rounded: pack the high halves
+            uint2 w;
+            w.x = (__float_as_uint(v[0]) >> 16) | (__float_as_uint(v[1]) & 0xFFFF0000u);
+            w.y = (__float_as_uint(v[2]) >> 16) | (__float_as_uint(v[3]) & 0xFFFF0000u);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.H) + row * 64 + 4 * q) = w;
+        } else {
+            *reinterpret_cast<float4_t *>(reinterpret_cast<float *>(a.H) + row * 64 + 4 * q) = v;
+        }
+        float s1 = v[0] * a14[0] + v[1] * a14[1] + v[2] * a14[2] + v[3] * a14[3];
+        float s2 = v[0] * a24[0] + v[1] * a24[1] + v[2] * a24[2] + v[3] * a24[3];
+#pragma unroll
+        for (int o = 1; o < FP / 4; o <<= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+        }
+        if ((4 * q) % FP == 0) {
+            f1[row * K + head] = s1 + b1;
+            f2[row * K + head] = s2 + b2;
+        }
     }
 }
 
@@ -1403,11 +1429,13 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
     if (b6) { /* done above */ } else if (mt == 2) { HAN_LAUNCH_FWD(2) } else { HAN_LAUNCH_FWD(1) }
 #undef HAN_LAUNCH_FWD
     HAN_CHECK_LAUNCH();
-    if (nsplit > 1) {
+    if (nsplit > 1) {      // sums the partial tiles, stamps / rounds, and takes the scores from the stored row
         const int fgrid = han_grid_for(N, 16, 256 * 8);
-        if (a.h_bf16) project_finish_kernel<true><<<fgrid, 256, 0, st>>>(a, nsplit);
-        else project_finish_kernel<false><<<fgrid, 256, 0, st>>>(a, nsplit);
+        a.a1 = a1; a.a2 = a2; a.b1 = b1; a.b2 = b2;
+        if (a.h_bf16) { HAN_DISPATCH_FP(FP, { project_finish_kernel<FPC, true><<<fgrid, 256, 0, st>>>(a, nsplit, f1, f2); }) }
+        else { HAN_DISPATCH_FP(FP, { project_finish_kernel<FPC, false><<<fgrid, 256, 0, st>>>(a, nsplit, f1, f2); }) }
         HAN_CHECK_LAUNCH();
+        return 0;
     }
     if (a.f1 && !(b6 && in_drop == 0.f)) return 0;      // f1 / f2 were written by the epilogue
     ScoreArgs s;

@@ -156,22 +156,24 @@ class NodePartition:
         (padding of the last shard) hold zeros and are never indexed."""
         return self.all_gather_rows_async(local).wait()
 
-    def all_gather_rows_async(self, local: torch.Tensor, tag=None) -> "GatheredTable":
+    def all_gather_rows_async(self, local: torch.Tensor, tag=None, rows_per_rank: int | None = None) -> "GatheredTable":
         """Start the all-gather and return a handle; `.wait()` yields the table.
         Under RCCL the collective runs on the communicator's stream (after the
         producer kernels already queued on the current stream) and overlaps with
         whatever is launched before `.wait()`; under gloo it completes here.
-        tag: reuse the persistent table of that name instead of allocating one per step."""
+        tag: reuse the persistent table of that name instead of allocating one per step.
+        rows_per_rank: block height every rank contributes (default: the shard); `local` is zero-padded to it."""
         if not self.active:
             return GatheredTable(local, None)
+        per = self.shard if rows_per_rank is None else int(rows_per_rank)
         tail = tuple(local.shape[1:])
-        if local.shape[0] != self.shard:
-            padded = self.buffer(None if tag is None else (tag, "pad"), (self.shard,) + tail, local.dtype, local.device)
+        if local.shape[0] != per:
+            padded = self.buffer(None if tag is None else (tag, "pad"), (per,) + tail, local.dtype, local.device)
             padded[:local.shape[0]] = local
             padded[local.shape[0]:] = 0
         else:
             padded = local.contiguous()
-        table = self.buffer(tag, (self.n_table,) + tail, local.dtype, local.device)
+        table = self.buffer(tag, (per * self.world,) + tail, local.dtype, local.device)
         if self._backend() == "nccl":
             work = dist.all_gather_into_tensor(table, padded, group=self.group, async_op=True)
             return GatheredTable(table, work, keep=padded)
@@ -239,6 +241,52 @@ class NodePartition:
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             flat.copy_(host)
         return flat
+
+
+class MaskedBackwardPlan:
+    """Opt-in masked backward (HANTrainer(masked_backward=True)) of ONE meta-path: with a single node-attention
+    layer the g row of every destination outside the loss mask is identically zero, so those destinations add
+    exactly 0 to dH_j and df2_j of their sources.  The transposed graph keeps their entries as -1 IN PLACE (the
+    kernel skips them and sums the rest in the order of the full pass: bit-identical results); under a node
+    partition only the LIVE rows of the backward table [g | stats] travel -- every rank contributes its live rows
+    (padded to the largest count) to one all-gather, 384 B x |mask| instead of 384 B x N per meta-path.
+
+    graph_t   masked transposed shard (rows = local sources; entries = rows of `table`, or -1)
+    live_idx  local rows (int64) that are live, or None on one GPU (the local table is used as it is)
+    gid       (world * per_rank,) int32 global id of each row of the gathered table (dropout RNG keys), or None
+    """
+
+    def __init__(self, part: "NodePartition | None", graph_t: CSRGraph, live_local: torch.Tensor,
+                 live_global: torch.Tensor | None = None):
+        dev = graph_t.device
+        self.part = part if (part is not None and part.active) else None
+        if self.part is None:
+            self.graph_t = graph_t.with_masked_columns(live_local.bool())
+            self.live_idx, self.gid, self.per_rank = None, None, int(live_local.numel())
+            self.rows_on_wire = 0
+            return
+        pt = self.part
+        lg = live_global.bool()                                    # (n_table,) in global numbering
+        counts = lg.view(pt.world, pt.shard).sum(1)
+        self.per_rank = max(int(counts.max()), 1)
+        # position of every live node among its owner's live rows -> its row in the gathered compact table
+        pos = torch.cumsum(lg.view(pt.world, pt.shard).long(), 1) - 1
+        remap = (pos + torch.arange(pt.world, device=dev)[:, None] * self.per_rank).view(-1)
+        self.graph_t = graph_t.with_masked_columns(lg, remap, n_cols=pt.world * self.per_rank)
+        self.live_idx = torch.nonzero(live_local.bool()).flatten()
+        gid = torch.full((pt.world * self.per_rank,), 0, dtype=torch.int32, device=dev)
+        ids = torch.nonzero(lg).flatten()
+        gid[remap[ids]] = ids.to(torch.int32)
+        self.gid = gid
+        self.rows_on_wire = (pt.world - 1) * self.per_rank        # rows this rank receives per meta-path and step
+
+    def table_async(self, gs_local: torch.Tensor, tag):
+        """The table the masked transposed graph indexes: the local table itself on one GPU, else the all-gather of
+        every rank's live rows (started asynchronously; `.wait()` yields it)."""
+        if self.part is None:
+            return GatheredTable(gs_local, None)
+        packed = gs_local.index_select(0, self.live_idx)
+        return self.part.all_gather_rows_async(packed, tag, rows_per_rank=self.per_rank)
 
 
 class HaloPlan:

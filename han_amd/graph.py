@@ -54,6 +54,7 @@ class CSRGraph:
         self._t = None
         self._split = {}
         self._locality = None
+        self.masked = False         # True: colidx holds -1 for skipped entries (with_masked_columns)
         if validate:
             self.validate()
 
@@ -90,6 +91,19 @@ class CSRGraph:
                 dist = (self.colidx[pos].long() - (rows + self.row_base)).abs().double().mean()
                 self._locality = bool(float(dist) < 0.05 * max(self.n_cols, 1))
         return self._locality
+
+    def with_masked_columns(self, live: torch.Tensor, remap: torch.Tensor | None = None,
+                            n_cols: int | None = None) -> "CSRGraph":
+        """The same rows with every entry whose column is not `live` replaced by -1 IN PLACE (positions kept),
+        the others optionally renumbered through `remap` (HAN_FLAG_MASKED_EDGES form of a transposed graph:
+        han_node_attn_bwd_cols skips the negative entries and sums the rest in the order of the full graph)."""
+        c = self.colidx.long()
+        new = torch.where(live[c], c if remap is None else remap[c], torch.full_like(c, -1)).to(torch.int32)
+        g = CSRGraph(self.rowptr, new.contiguous(), self.n_cols if n_cols is None else n_cols, validate=False,
+                     values=self.values, row_base=self.row_base)
+        g._locality = False         # its column ids are no longer row ids
+        g.masked = True
+        return g
 
     def has_empty_rows(self) -> bool:
         return self.n_rows > 0 and bool((self.degrees() == 0).any())

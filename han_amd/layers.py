@@ -222,6 +222,7 @@ class NodeLevelAttention(torch.autograd.Function):
         multi = part is not None and part.active
         seed_dev = cfg.get("seed_dev")
         plans_b = cfg.get("plans_b") if multi else None
+        masked = cfg.get("masked_bwd")        # per meta-path MaskedBackwardPlan, or None (the full pass)
         rows = []
         dres_in = []
         for p in range(P):      # row-local halves first; their tables go out while we continue
@@ -239,7 +240,10 @@ class NodeLevelAttention(torch.autograd.Function):
                     dres_in.append(ops.project_bwd_input(g32, Wr[p], K, FP, in_drop=ctx.in_drop,
                                                          seed=seed_p, row_offset=row_offset,
                                                          seed_dev=seed_dev))
-            if multi:
+            mb = masked[p] if masked is not None else None
+            if mb is not None:        # opt-in masked backward: only the live rows of [g | stats] are read / travel
+                rows.append((mb.table_async(gs, ("bm", cfg.get("layer", 0), cfg.get("group", 0), p)), df1))
+            elif multi:
                 plan = plans_b[p] if plans_b is not None else None
                 ex = plan.exchange_async if plan is not None else part.all_gather_rows_async
                 rows.append((ex(gs, ("b", cfg.get("layer", 0), cfg.get("group", 0), p)), df1))   # ONE fused [g | stats] table on the wire
@@ -249,13 +253,14 @@ class NodeLevelAttention(torch.autograd.Function):
             H, f1, f2, pre, lse, aggp, tsum, R, keep = ctx.saved_per_p[p]
             seed = int(cfg["seeds"][p])
             gs_h, df1 = rows[p]
-            gs_tab = gs_h.wait() if multi else gs_h
-            plan = plans_b[p] if plans_b is not None else None
-            dH, df2 = ops.node_attn_bwd_cols(plan.graph if plan is not None else graphs_t[p], gs_tab,
-                                             H, f2, df1, a1[p], a2[p],
+            mb = masked[p] if masked is not None else None
+            gs_tab = gs_h.wait() if (multi or mb is not None) else gs_h
+            plan = plans_b[p] if (plans_b is not None and mb is None) else None
+            gt = mb.graph_t if mb is not None else (plan.graph if plan is not None else graphs_t[p])
+            dH, df2 = ops.node_attn_bwd_cols(gt, gs_tab, H, f2, df1, a1[p], a2[p],
                                              coef_drop=ctx.coef_drop, fts_drop=ctx.in_drop, seed=seed,
                                              src_offset=row_offset, dst_offset=0,
-                                             table_gid=plan.gid if plan is not None else None,
+                                             table_gid=mb.gid if mb is not None else (plan.gid if plan is not None else None),
                                              seed_dev=seed_dev)
             rows[p] = None
             ops.score_param_bwd(H, df1, df2, K=K, FP=FP, out=(da1[p], da2[p], db1[p], db2[p]))

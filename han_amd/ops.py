@@ -16,6 +16,7 @@ from .graph import CSRGraph
 ACT_IDENTITY = 0
 ACT_ELU = 1
 FLAG_XCD_ORDER = 1         # HAN_FLAG_XCD_ORDER: XCD-aware work order for graphs with locality
+FLAG_MASKED_EDGES = 64     # HAN_FLAG_MASKED_EDGES: negative entries of the transposed graph are skipped in place
 FLAG_K1_EXACT_PIPE = 2     # HAN_FLAG_K1_EXACT_PIPE / _MATRIX_PIPE: force one of the two K1 forward kernels (tests, measurements)
 FLAG_K1_MATRIX_PIPE = 4
 FLAG_K1_4WAVE = 16         # HAN_FLAG_K1_4WAVE (measurements: the two-waves-per-SIMD form of the bf16 x 6 kernel)
@@ -27,9 +28,6 @@ STATS_ROW_BYTES = 128      # per destination row: the (f1, lse, s, 0) records of
 
 _workspaces: dict = {}
 _retired_workspaces: list = []      # superseded buffers stay alive: a captured hipGraph may have baked their pointers in
-
-FLAG_K2_LANES16 = 64       # HAN_FLAG_K2_LANES16: bf16 8 x 8 tables through the 16-lane map (tests / measurements)
-K2_EXTRA_FLAGS = 0         # or-ed into the flags of node_attn_fwd / node_attn_bwd_cols (tests / tools set FLAG_K2_LANES16)
 
 # Optional timing hook (bench.py): a list to which node_attn_fwd / node_attn_bwd_cols
 # append (tag, start_event, end_event, N, E) recorded on the launch stream.
@@ -358,7 +356,7 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         a2.data_ptr(), b2.data_ptr(), c.data_ptr(), res.data_ptr() if res is not None else None,
         out.data_ptr(), out.stride(0) if N > 1 else D,
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
-        int(seed), _dev_word(seed_dev), int(row_offset), int(activation), (FLAG_XCD_ORDER if graph.has_locality() else 0) | K2_EXTRA_FLAGS,
+        int(seed), _dev_word(seed_dev), int(row_offset), int(activation), FLAG_XCD_ORDER if graph.has_locality() else 0,
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_fwd")
     if timing is not None:
         ev1.record()
@@ -477,7 +475,8 @@ def node_attn_bwd_cols(graph_t: CSRGraph, gs_tab, H, f2, df1, a1, a2, coef_drop=
         table_gid.data_ptr() if table_gid is not None else None, H.data_ptr(),
         tcode, f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
         NS, graph_t.nnz, K, FP, LEAKY_SLOPE, _check_drop(coef_drop, "coef_drop"), fts_drop,
-        int(seed), _dev_word(seed_dev), int(src_offset), int(dst_offset), (FLAG_XCD_ORDER if graph_t.has_locality() else 0) | K2_EXTRA_FLAGS,
+        int(seed), _dev_word(seed_dev), int(src_offset), int(dst_offset),
+        (FLAG_XCD_ORDER if graph_t.has_locality() else 0) | (FLAG_MASKED_EDGES if graph_t.masked else 0),
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_bwd_cols")
     if timing is not None:
         ev1.record()

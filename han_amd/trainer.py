@@ -26,7 +26,7 @@ class HANTrainer:
     def __init__(self, model: HeteGAT_multi, xs, graphs, labels, train_mask, val_mask=None,
                  lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
                  part: NodePartition | None = None, patience=100, max_halo_fraction=0.6,
-                 use_graph=False, graphs_local=False, xs_full=None, replicate="auto"):
+                 use_graph=False, graphs_local=False, xs_full=None, replicate="auto", masked_backward=False):
         """xs: list of P (N_local,F) feature tensors (this rank's rows);
         graphs: list of P CSRGraph (or dense masks / CSR tuples).  Under a partition (`part`) either
         the GLOBAL graphs (graphs_local=False: each rank keeps its row block; small data sets) or --
@@ -42,7 +42,12 @@ class HANTrainer:
         xs_full: under a partition, optionally the features of ALL rows (P tensors (N,F), the same on
         every rank): the forward passes named by `replicate` ("auto" = dist.replication_policy,
         "all", "eval", "none") then project the whole table on every rank instead of exchanging it;
-        `xs` may then be None (the local rows are views of xs_full)."""
+        `xs` may then be None (the local rows are views of xs_full).
+        masked_backward: OPT-IN (never the default, never the headline measurement): with a single node-attention
+        layer the backward row g_i of every destination outside `train_mask` is identically zero, so the
+        transposed-graph pass skips those destinations in place (bit-identical results, dist.MaskedBackwardPlan)
+        and, under a partition, only the live rows of the backward table travel.  The reference evaluates every
+        row in every step (sess.run, ex_acm3025.py:190); this mode computes the same numbers with less work."""
         if not model._built:
             raise RuntimeError("build the model first (model.build(...))")
         self.model = model
@@ -88,6 +93,8 @@ class HANTrainer:
             self._calibrate_replication(ffd_drop)
         self.labels = labels.to(device=dev, dtype=torch.int32).contiguous()
         self.train_mask = train_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        self._masked_plans = None
+        self.set_masked_backward(masked_backward)
         self.val_mask = (val_mask if val_mask is not None else train_mask).to(
             device=dev, dtype=torch.uint8).contiguous()
         # mean(loss * mask / mean(mask)) == sum(mask * loss) / count(mask): the
@@ -113,6 +120,24 @@ class HANTrainer:
             self._step_inc = torch.tensor([-0x61C8864680B583EB, 1], dtype=torch.int64, device=dev)  # 0x9E37...15
             model.step_seed_dev = self.step_state[0:1]
             self.opt.step_dev = self.step_state[1:2]
+
+    def set_masked_backward(self, flag: bool):
+        """Switch the opt-in masked backward on or off (plans are built on first use; collective under a partition)."""
+        self.masked_backward = bool(flag)
+        if not self.masked_backward:
+            self.model.masked_bwd = None
+            return
+        if getattr(self, "use_graph", False) and self._graph is not None:
+            raise RuntimeError("the epoch is already captured; choose masked_backward before the first epoch")
+        if self.model.extra:
+            raise NotImplementedError("masked_backward needs a single node-attention layer: with more, the rows "
+                                      "outside the mask feed the rows inside it")
+        if self._masked_plans is None:
+            from .dist import MaskedBackwardPlan
+            live_global = self.part.all_gather_rows(self.train_mask) if self.part is not None else None
+            self._masked_plans = [MaskedBackwardPlan(self.part, gt, self.train_mask, live_global)
+                                  for gt in self.graphs_t]
+        self.model.masked_bwd = self._masked_plans
 
     def _calibrate_replication(self, ffd_drop, reps=3):
         """replicate="auto" over RCCL: MEASURE, on this machine and this shape, what a forward table costs to

@@ -43,8 +43,10 @@ extern "C" {
                                   different source windows.  Speed only; off for graphs without structure, where it
                                   measured 9 % slower in the HBM regime (eight separate index / output streams). */
 
-#define HAN_FLAG_K2_LANES16 64  /* measurements / tests: bf16 8 x 8 tables through the 16-lane map of the fp32 kernels
-                                  instead of one lane per head (round 3)                                             */
+#define HAN_FLAG_MASKED_EDGES 64 /* han_node_attn_bwd_cols: entries of rowidx below 0 are skipped IN PLACE (their destination's
+                                  g row is identically zero -- a destination outside the loss mask of a one-layer model);
+                                  the remaining terms are summed in the positions and order of the full pass, so the
+                                  results are bit-identical to it.  Opt-in (HANTrainer(masked_backward=True)).          */
 /* `flags` of han_project_fwd: which matrix pipe runs the projection (default 0: the library chooses --
  * the bf16 x 6 kernel for training forwards and bf16 features, the exact-fp32 kernel otherwise).
  * Both have fp32-class accuracy; the switches exist for measurements and tests.                     */

@@ -209,6 +209,11 @@ def node_attn_bwd_cols(graph_t, gs_tab, H, f2, df1, a1, a2, coef_drop=0.0, fts_d
     dst = graph_t.colidx.long()                   # destination i (table index)
     st = _f64(stats_tab)
     w = _f64(graph_t.values)[:, None] if graph_t.values is not None else torch.ones((1, 1), dtype=torch.float64)
+    if getattr(graph_t, "masked", False):         # HAN_FLAG_MASKED_EDGES: negative entries are skipped
+        live = dst >= 0
+        src, dst = src[live], dst[live]
+        if graph_t.values is not None:
+            w = w[live]
     u = w * (st[dst, :, 0] + _f64(f2)[src])
     sg = torch.where(u > 0, torch.ones_like(u), torch.full_like(u, SLOPE)) * w
     alpha = torch.exp(torch.maximum(u, SLOPE * u) - st[dst, :, 1])

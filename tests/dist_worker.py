@@ -81,7 +81,8 @@ def run(rank, world, device, epochs, drop, out_path, port, use_cpu_backend):
     tr = HANTrainer(model, [loc(x)] * p, graphs, loc(labels), loc(tm), loc(vm), attn_drop=drop,
                     ffd_drop=drop, part=part, graphs_local=local,
                     xs_full=[x] * p if (rep and part is not None) else None, replicate=rep or "auto",
-                    max_halo_fraction=-1.0 if os.environ.get("HAN_TEST_ALLGATHER") == "1" else 0.6)
+                    max_halo_fraction=-1.0 if os.environ.get("HAN_TEST_ALLGATHER") == "1" else 0.6,
+                    masked_backward=os.environ.get("HAN_TEST_MASKED_BWD") == "1")
     hist = []
     for _ in range(epochs):
         hist.append(tr.reduce_metrics(*tr.epoch()))

@@ -106,3 +106,25 @@ def test_replicated_projection_two_ranks_real_kernels(dev, tmp_path, mode, bf16)
     tol = 2e-5 if bf16 == "0" else 5e-4
     assert np.abs(a["flat"] - b["flat"]).max() < tol
     assert np.abs(a["hist"] - b["hist"]).max() < tol
+
+
+@pytest.mark.parametrize("bf16", ["0", "1"])
+def test_masked_backward_real_kernels_bit_identical(dev, tmp_path, bf16):
+    """Opt-in masked backward on the real kernels (HAN_FLAG_MASKED_EDGES: dead entries of the transposed graph skipped
+    in place): one process and two ranks sharing the GPU (compact all-gather of the live [g | stats] rows with
+    a global-id table for the dropout keys), with dropout, fp32 and bf16 tables.  Parameters after 3 epochs
+    within the usual tolerance of the single-process full pass (whose backward runs the FAST instantiation;
+    bit-equality inside one instantiation is pinned by test_masked_edges_backward_is_bit_identical and, for the
+    host logic at world 8, by tests/test_dist_gloo.py)."""
+    env = {"HAN_TEST_ALLGATHER": "1", "HAN_TEST_LOCAL": "1", "HAN_TEST_BF16": bf16}
+    outs = {}
+    for tag, world, masked, port in (("full1", 1, "0", 29661), ("mask1", 1, "1", 29663),
+                                     ("full2", 2, "0", 29665), ("mask2", 2, "1", 29667)):
+        out = str(tmp_path / f"{tag}.npz")
+        _launch(world, 3, 0.6, out, port, dict(env, HAN_TEST_MASKED_BWD=masked))
+        outs[tag] = np.load(out)
+    tol = 2e-5 if bf16 == "0" else 5e-4
+    assert np.isfinite(outs["mask1"]["flat"]).all()
+    assert np.abs(outs["full1"]["flat"] - outs["mask1"]["flat"]).max() < tol
+    assert np.abs(outs["full1"]["flat"] - outs["mask2"]["flat"]).max() < tol
+    assert np.abs(outs["full1"]["hist"] - outs["mask2"]["hist"]).max() < tol

@@ -1355,45 +1355,41 @@ def test_bf16_mode_forward_backward(dev, drop, P):
         assert rel_err(got, gref[k]) < (0.2 if k in ("a1", "b1", "b2") else 6e-2), k
 
 
-@pytest.mark.parametrize("deg", [13, 40, 64, 150, 700])
-@pytest.mark.parametrize("cd,fd", [(0.0, 0.0), (0.6, 0.6), (0.6, 0.0), (0.0, 0.6)])
-def test_bf16_one_lane_per_head_map_matches_the_16_lane_map(dev, deg, cd, fd):
-    """Round 3: bf16 8 x 8 tables run K2 with ONE LANE PER HEAD (8 groups of 8 lanes, 16-byte loads, 8 neighbours
-    per step; node_attn_fwd_h8_kernel / node_attn_bwd_cols_h8_kernel).  Same tables, same draws, same arithmetic
-    as the 16-lane map (HAN_FLAG_K2_LANES16) up to the order of fp32 sums: eval forward, training forward with
-    its saved statistics, and the transposed-graph backward, on degrees with full steps, tails and several
-    64-edge batches (and a weighted adjacency)."""
+@pytest.mark.parametrize("deg", [5, 40, 300])
+@pytest.mark.parametrize("tdt", [torch.float32, torch.bfloat16])
+def test_masked_edges_backward_is_bit_identical(dev, deg, tdt):
+    """HAN_FLAG_MASKED_EDGES: destinations whose g row is identically zero (outside the loss mask of a one-layer
+    model) are replaced by -1 IN PLACE in the transposed graph; the kernel loads nothing for them and adds the
+    remaining terms in the positions and order of the full pass.  dH and df2 must be BIT-EQUAL to the full
+    graph run through the same (general, non-FAST: table_gid given) instantiation, low- and high-degree rows,
+    weighted adjacency, fp32 and bf16 tables; and equal the FAST full pass to rounding."""
     from han_amd import ops, synth
     from han_amd.graph import CSRGraph
-    n = 1500
-    g = synth.random_regular_graph(n, deg, 5, dev)
+    n = 900
+    g = synth.random_regular_graph(n, deg, 11, dev)
     rng = np.random.default_rng(deg)
     gens = lambda *sh: _t(rng.standard_normal(sh), dev)
-    x = gens(n, 64)
     a1, a2, b1, b2, c = gens(8, 8) * 0.3, gens(8, 8) * 0.3, gens(8) * 0.1, gens(8) * 0.1, gens(64) * 0.1
-    H, f1, f2 = ops.project_fwd(x, torch.eye(64, device=dev), a1, a2, b1, b2, in_drop=0.0, fts_drop=fd, seed=9,
-                                table_dtype=torch.bfloat16)
-    dOut = gens(n, 64)
-    res = {}
+    H, f1, f2 = ops.project_fwd(gens(n, 64), torch.eye(64, device=dev), a1, a2, b1, b2, fts_drop=0.6, seed=9,
+                                table_dtype=tdt)
+    live = _t((rng.random(n) < 0.15).astype(np.float32), dev) > 0
+    dOut = gens(n, 64) * live[:, None]                                   # g == 0 outside the mask
     for vals in (None, _t(rng.uniform(0.5, 1.5, g.nnz), dev)):
         gg = CSRGraph(g.rowptr, g.colidx, n, validate=False, values=vals)
         gt = gg.transpose()
-        for flag in (0, ops.FLAG_K2_LANES16):
-            ops.K2_EXTRA_FLAGS = flag
-            try:
-                out_e, _ = ops.node_attn_fwd(gg, H, f1, a2, b2, c) if fd == 0 else (None, None)
-                out_t, sv = ops.node_attn_fwd(gg, H, f1, a2, b2, c, train=True, coef_drop=cd, fts_drop=fd, seed=77)
-                pre, lse, aggp, tsum = sv
-                gs, df1, _ = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, table_dtype=torch.bfloat16)
-                dH, df2 = ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, coef_drop=cd, fts_drop=fd, seed=77)
-            finally:
-                ops.K2_EXTRA_FLAGS = 0
-            res[flag] = (out_e, out_t, pre, lse, aggp, tsum, dH, df2)
-        for a_, b_, nm in zip(res[0], res[ops.FLAG_K2_LANES16], ("eval", "train", "pre", "lse", "aggp", "tsum", "dH", "df2")):
-            if a_ is None:
-                continue
-            d = float((a_ - b_).abs().max())
-            assert d < 2e-5 * max(1.0, float(b_.abs().max())), (nm, d, vals is not None)
+        _, sv = ops.node_attn_fwd(gg, H, f1, a2, b2, c, train=True, coef_drop=0.6, fts_drop=0.6, seed=77)
+        pre, lse, aggp, tsum = sv
+        gs, df1, _ = ops.node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, table_dtype=tdt)
+        ident = torch.arange(n, dtype=torch.int32, device=dev)             # table_gid = identity: the general instantiation
+        kw = dict(coef_drop=0.6, fts_drop=0.6, seed=77)
+        dH_f, df2_f = ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, table_gid=ident, **kw)
+        gm = gt.with_masked_columns(live)
+        assert int((gm.colidx < 0).sum()) > 0.5 * gm.nnz
+        dH_m, df2_m = ops.node_attn_bwd_cols(gm, gs, H, f2, df1, a1, a2, table_gid=ident, **kw)
+        assert torch.equal(dH_f, dH_m) and torch.equal(df2_f, df2_m), vals is not None
+        dH_q, df2_q = ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, **kw)   # FAST full pass
+        assert float((dH_q - dH_m).abs().max()) < 1e-5 * max(1.0, float(dH_q.abs().max()))
+        assert float((df2_q - df2_m).abs().max()) < 1e-5 * max(1.0, float(df2_q.abs().max()))
 
 
 @pytest.mark.parametrize("K,FP", [(4, 16), (16, 4), (2, 32), (1, 64), (5, 12), (12, 8)])

@@ -15,8 +15,6 @@ from han_amd import ops, synth  # noqa: E402
 
 
 def train_variants(dev, sizes=(1_000_000, 4_000_000, 10_000_000)):
-    if os.environ.get("LANES16"):      # bf16 8 x 8 tables through the 16-lane map of round 2 (comparison runs)
-        ops.K2_EXTRA_FLAGS = ops.FLAG_K2_LANES16
     if os.environ.get("N_ONLY"):
         sizes = (int(os.environ["N_ONLY"]),)
     """Training kernels (forward with both dropouts, transposed-graph backward) in the
@@ -53,7 +51,7 @@ def train_variants(dev, sizes=(1_000_000, 4_000_000, 10_000_000)):
             # the (f1, lse, s) records; DESIGN.md section 3 (K2): time ~ lines per edge, not bytes
             lf, lb = (2, 3) if tdt == torch.float32 else (1, 2)
             e = g.nnz
-            print(json.dumps({"N": n, "tables": tag, "bf16_lane_map": "16 lanes x 8 B" if ops.K2_EXTRA_FLAGS else "8 lanes x 16 B", "fwd_eval_ms": round(te, 3), "fwd_train_ms": round(tt, 3),
+            print(json.dumps({"N": n, "tables": tag,  "fwd_eval_ms": round(te, 3), "fwd_train_ms": round(tt, 3),
                               "bwd_cols_ms": round(tb, 3), "lines_per_edge": {"fwd": lf, "bwd": lb},
                               "ns_per_1000_lines": {"fwd_eval": round(te * 1e6 / (e * lf) * 1e3, 2),
                                                     "fwd_train": round(tt * 1e6 / (e * lf) * 1e3, 2),
