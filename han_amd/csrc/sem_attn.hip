@@ -1545,12 +1545,21 @@ extern "C" int han_sem_attn_fwd(const float *M, const float *w_omega, const floa
                                 int flags, void *stream) {
     if (N == 0) return 0;   // nothing to do; row pointers of empty tensors may be null
     if (!M || !w_omega || !b_omega || !u_omega || !Z || !beta || N < 0 || P <= 0) return HAN_E_BADARG;
-    if ((D != 64 && D != 128) || P > 64 || (A != 64 && A != 128)) return HAN_E_UNSUPPORTED;
+    if ((D != 64 && D != 128) || P > 64 || A < 64 || A > 256 || A % 64 != 0) return HAN_E_UNSUPPORTED;
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (D == 128) {
-        if (A == 64) return launch_fwd_gen<1, 8>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
-        return launch_fwd_gen<2, 8>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
+    // attention spaces of 192 / 256 columns (round 3) and 128-wide embeddings: the width-templated block-level kernels
+    if (D == 128 || A > 128) {
+        if (D == 128) {
+            switch (A / 64) {
+                case 1: return launch_fwd_gen<1, 8>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
+                case 2: return launch_fwd_gen<2, 8>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
+                case 3: return launch_fwd_gen<3, 8>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
+                default: return launch_fwd_gen<4, 8>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
+            }
+        }
+        if (A == 192) return launch_fwd_gen<3, 4>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
+        return launch_fwd_gen<4, 4>(M, w_omega, b_omega, u_omega, Z, beta, N, P, st);
     }
     if (A == 64) return launch_fwd<1>(M, w_omega, b_omega, u_omega, Z, beta, N, P, flags, st);
     return launch_fwd<2>(M, w_omega, b_omega, u_omega, Z, beta, N, P, flags, st);
@@ -1568,13 +1577,14 @@ extern "C" int han_sem_attn_bwd(const float *M, const float *w_omega, const floa
     if (!M || !w_omega || !b_omega || !u_omega || !beta || !dZ || !dM || !dw_omega || !db_omega || !du_omega ||
         !workspace || N < 0 || P <= 0)
         return HAN_E_BADARG;
-    if ((D != 64 && D != 128) || P > 64 || (A != 64 && A != 128)) return HAN_E_UNSUPPORTED;
+    if ((D != 64 && D != 128) || P > 64 || A < 64 || A > 256 || A % 64 != 0) return HAN_E_UNSUPPORTED;
     if (workspace_bytes < han_sem_attn_bwd_workspace(N, P, D, A)) return HAN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *slab = (float *)workspace;
     int grid = 0;
     int rc;
     if (D == 128) rc = launch_bwd_gen<8>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, A, &grid, st);
+    else if (A > 128) rc = launch_bwd_gen<4>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, A, &grid, st);
     else rc = (A == 64)
                  ? launch_bwd<1>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, &grid, flags, st)
                  : launch_bwd<2>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, &grid, flags, st);

@@ -54,6 +54,42 @@ def _same_tensor(ts) -> bool:
                and t.dtype == t0.dtype for t in ts[1:])
 
 
+class _on_path:
+    """Run the enclosed launches of meta-path p on its own stream (cfg["streams"], single GPU): the per-meta-path
+    chains K1 -> K2 (forward) and rows -> cols -> score gradients -> dW (backward) are independent of each other,
+    and at the size of the reference's data sets every kernel is a few microseconds on a few CUs -- side by side
+    in a captured epoch they overlap instead of queueing (HANTrainer(use_graph=True)).  Scratch buffers are per path."""
+
+    def __init__(self, streams, p):
+        self.s = streams[p] if streams is not None else None
+        self.p = p
+
+    def __enter__(self):
+        if self.s is not None:
+            self.ctx = torch.cuda.stream(self.s)
+            self.ctx.__enter__()
+            self.prev, ops.WS_SUFFIX = ops.WS_SUFFIX, f"@p{self.p}"
+
+    def __exit__(self, *exc):
+        if self.s is not None:
+            ops.WS_SUFFIX = self.prev
+            self.ctx.__exit__(*exc)
+
+
+def _fork(streams):
+    if streams is not None:
+        cur = torch.cuda.current_stream()
+        for st in streams:
+            st.wait_stream(cur)
+
+
+def _join(streams):
+    if streams is not None:
+        cur = torch.cuda.current_stream()
+        for st in streams:
+            cur.wait_stream(st)
+
+
 class _Ready:
     """A table that needs no exchange (same interface as the async exchange handles)."""
 
@@ -118,14 +154,17 @@ class NodeLevelAttention(torch.autograd.Function):
         replicated = [xs_full is not None and (plans_f is None or plans_f[p] is None) for p in range(P)]
         pj = [None] * P
         src = xs_full if all(replicated) else (xs if not any(replicated) else None)
-        if P > 1 and src is not None and _same_tensor(src) and W.is_contiguous() and src[0].stride(-1) == 1:
+        streams = cfg.get("streams") if (not multi and cfg.get("streams") is not None and len(cfg["streams"]) >= P) else None
+        _fork(streams)
+        if streams is None and P > 1 and src is not None and _same_tensor(src) and W.is_contiguous() and src[0].stride(-1) == 1:
             full = all(replicated)
             Hs, f1s, f2s, keeps = ops.project_fwd_multi(src[0], W, a1, a2, b1, b2, in_drop=in_drop, fts_drop=in_drop,
                                                         seeds=[int(v) for v in cfg["seeds"]],
                                                         row_offset=0 if full else row_offset, table_dtype=tdt,
                                                         seed_dev=seed_dev, want_keep=True)
             pj = [(Hs[p], f1s[p], f2s[p], keeps[p]) for p in range(P)]
-        for p in range(P):
+
+        def project_path(p):
             seed = int(cfg["seeds"][p])
             plan = plans_f[p] if plans_f is not None else None
             handle = keep = None
@@ -166,7 +205,8 @@ class NodeLevelAttention(torch.autograd.Function):
                 R = R + br[p]
             proj.append((H, f1, f2, handle, R))
             proj_keep.append(keep)
-        for p in range(P):
+
+        def attend_path(p):
             H, f1, f2, handle, R = proj[p]
             H_tab = handle.wait() if multi else H
             plan = plans_f[p] if plans_f is not None else None
@@ -178,6 +218,14 @@ class NodeLevelAttention(torch.autograd.Function):
                                       seed_dev=seed_dev)
             if train:
                 saved.append((H, f1, f2) + sv + (R, proj_keep[p]))
+
+        for p in range(P):
+            with _on_path(streams, p):
+                project_path(p)
+        for p in range(P):
+            with _on_path(streams, p):
+                attend_path(p)
+        _join(streams)
         del proj
         ctx.cfg, ctx.xs, ctx.graphs = cfg, xs, graphs
         ctx.xin_shape = tuple(Xin.shape) if Xin is not None else None
@@ -223,9 +271,12 @@ class NodeLevelAttention(torch.autograd.Function):
         seed_dev = cfg.get("seed_dev")
         plans_b = cfg.get("plans_b") if multi else None
         masked = cfg.get("masked_bwd")        # per meta-path MaskedBackwardPlan, or None (the full pass)
-        rows = []
+        rows = [None] * P
         dres_in = []
-        for p in range(P):      # row-local halves first; their tables go out while we continue
+        streams = cfg.get("streams") if (not multi and cfg.get("streams") is not None and len(cfg["streams"]) >= P) else None
+        _fork(streams)
+
+        def rows_path(p):      # row-local halves first; their tables go out while we continue
             H, f1, f2, pre, lse, aggp, tsum, R, _keep = ctx.saved_per_p[p]
             gs, df1, dcp = ops.node_attn_bwd_rows(dM[:, p, :], pre, aggp, tsum, f1, lse, c[p],
                                                   activation=cfg["act"], K=K, FP=FP,
@@ -242,14 +293,15 @@ class NodeLevelAttention(torch.autograd.Function):
                                                          seed_dev=seed_dev))
             mb = masked[p] if masked is not None else None
             if mb is not None:        # opt-in masked backward: only the live rows of [g | stats] are read / travel
-                rows.append((mb.table_async(gs, ("bm", cfg.get("layer", 0), cfg.get("group", 0), p)), df1))
+                rows[p] = (mb.table_async(gs, ("bm", cfg.get("layer", 0), cfg.get("group", 0), p)), df1)
             elif multi:
                 plan = plans_b[p] if plans_b is not None else None
                 ex = plan.exchange_async if plan is not None else part.all_gather_rows_async
-                rows.append((ex(gs, ("b", cfg.get("layer", 0), cfg.get("group", 0), p)), df1))   # ONE fused [g | stats] table on the wire
+                rows[p] = (ex(gs, ("b", cfg.get("layer", 0), cfg.get("group", 0), p)), df1)   # ONE fused [g | stats] table on the wire
             else:
-                rows.append((gs, df1))
-        for p in range(P):
+                rows[p] = (gs, df1)
+
+        def cols_path(p):
             H, f1, f2, pre, lse, aggp, tsum, R, keep = ctx.saved_per_p[p]
             seed = int(cfg["seeds"][p])
             gs_h, df1 = rows[p]
@@ -271,6 +323,14 @@ class NodeLevelAttention(torch.autograd.Function):
                                       seed=seed, row_offset=row_offset, seed_dev=seed_dev)
                 if dres_in:
                     dXin[:, p, :] += dres_in[p]
+
+        for p in range(P):
+            with _on_path(streams, p):
+                rows_path(p)
+        for p in range(P):
+            with _on_path(streams, p):
+                cols_path(p)
+        _join(streams)
         ctx.saved_per_p = None
         if direct is not None:
             return (dXin,) + (None,) * 11
@@ -284,6 +344,7 @@ class SemanticAttention(torch.autograd.Function):
     def forward(ctx, M, w_omega, b_omega, u_omega):
         M = M.contiguous()
         Z, beta = ops.sem_attn_fwd(M, w_omega, b_omega, u_omega)
+        ctx.set_materialize_grads(False)      # no zero-filled gradient for beta (a fill launch per step)
         plist = (w_omega, b_omega, u_omega)
         ctx.direct = tuple(p.grad for p in plist) if all(_direct(p) for p in plist) else None
         ctx.save_for_backward(M, w_omega, b_omega, u_omega, beta)
@@ -293,6 +354,8 @@ class SemanticAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dZ, _dbeta):
         M, w, b, u, beta = ctx.saved_tensors
+        if dZ is None:
+            dZ = torch.zeros((M.shape[0], M.shape[2]), dtype=M.dtype, device=M.device)
         dM, dw, db, du = ops.sem_attn_bwd(M, w, b, u, beta, dZ.contiguous(), out=ctx.direct)
         if ctx.direct is not None:
             return dM, None, None, None
@@ -306,7 +369,9 @@ class ClassifierLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, Z, Wc, bc, labels, mask, row_weight):
-        need = Z.requires_grad or Wc.requires_grad or bc.requires_grad
+        # (an eval forward under torch.no_grad() must not pay for the gradient half of the kernel)
+        need = any(ctx.needs_input_grad[:3])      # all False under torch.no_grad()
+        ctx.set_materialize_grads(False)      # no zero-filled gradients for the accuracy / logits outputs
         # direct-gradient mode additionally assumes the loss is the root of backward()
         # (d loss = 1), which is how HANTrainer calls it
         ctx.direct = need and _direct(Wc) and _direct(bc)
@@ -327,6 +392,8 @@ class ClassifierLoss(torch.autograd.Function):
         ctx.grads = None
         if ctx.direct:
             return dZ, None, None, None, None, None
+        if dloss is None:
+            return None, None, None, None, None, None
         return dZ * dloss, dWc * dloss, dbc * dloss, None, None, None
 
 
@@ -358,7 +425,8 @@ def classifier(Z, Wc, bc):
     return _ClassifierForward.apply(Z, Wc, bc)
 
 
-K3_WIDTHS = (64, 128)      # embedding widths (and attention sizes) the K3 / classifier kernels are built for
+K3_WIDTHS = (64, 128)      # embedding widths the K3 / classifier kernels are built for
+K3_MAX_ATT = 256           # attention sizes: multiples of 64 up to 256 (round 3; above 128 through the width-templated kernels)
 MAX_CLASSES = 64           # classes the classifier kernels take
 
 
@@ -373,7 +441,7 @@ def semantic_attention(M, w_omega, b_omega, u_omega):
     which is exact.  D > 128 (a last layer wider than the kernels, e.g. 8 heads x 32) or A > 128: the
     same arithmetic through torch on the GPU (library GEMM + elementwise, autograd); off the tuned path."""
     d, a = M.shape[2], w_omega.shape[1]
-    if d > K3_WIDTHS[-1] or a > K3_WIDTHS[-1]:
+    if d > K3_WIDTHS[-1] or a > K3_MAX_ATT:
         ops.require_gpu(M, "inputs")
         v = torch.tanh(torch.matmul(M, w_omega) + b_omega)
         att = torch.softmax(torch.matmul(v, u_omega), dim=1)

@@ -55,13 +55,17 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+WS_SUFFIX = ""             # set by layers._on_path: kernels of different meta-paths that run concurrently (one side stream per
+                           # meta-path inside a captured epoch) must not share a scratch buffer
+
+
 def _ws(nbytes: int, device, tag: str = "") -> torch.Tensor:
     """Grow-only scratch buffer per (device, tag).  A buffer that has to grow is REPLACED, and the old
     one is kept alive for the life of the process (never returned to the caching allocator): an epoch
     captured into a hipGraph (HANTrainer(use_graph=True)) replays with the raw pointers it saw, and a
     later, larger request for the same tag must not free memory such a graph still reads and writes.
     Growth is geometric, so the retired buffers of a tag add up to less than its current one."""
-    key = (str(device), tag)
+    key = (str(device), tag + WS_SUFFIX)
     t = _workspaces.get(key)
     if t is None or t.numel() < nbytes:
         if t is not None:

@@ -120,6 +120,11 @@ class HANTrainer:
             self._step_inc = torch.tensor([-0x61C8864680B583EB, 1], dtype=torch.int64, device=dev)  # 0x9E37...15
             model.step_seed_dev = self.step_state[0:1]
             self.opt.step_dev = self.step_state[1:2]
+            # one stream per meta-path: inside the captured epoch the per-meta-path chains (K1 -> K2, and the four
+            # backward kernels) become parallel branches of the graph -- at these sizes every kernel is a few
+            # microseconds on a few CUs (layers._on_path); HAN_PATH_STREAMS=0 keeps the single chain
+            if dev.type == "cuda" and os.environ.get("HAN_PATH_STREAMS", "1") != "0" and len(self.graphs) > 1:
+                model.path_streams = [torch.cuda.Stream(device=dev) for _ in self.graphs]
 
     def set_masked_backward(self, flag: bool):
         """Switch the opt-in masked backward on or off (plans are built on first use; collective under a partition)."""

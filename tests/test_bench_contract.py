@@ -14,9 +14,9 @@ CONTRACT_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
                  "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
 
 
-def _lines():
+def _lines(rnd="r02"):
     out = []
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{rnd}_bench_*.json"))):
         txt = [l for l in open(f).read().splitlines() if l.startswith("{")]
         assert len(txt) == 1, f"{f}: expected exactly one JSON line"
         out.append((os.path.basename(f), json.loads(txt[0])))
@@ -88,3 +88,43 @@ def test_host_cores_reports_usable_cores():
     cores, affinity, quota = bench.host_cores()
     assert 1 <= cores <= affinity <= (os.cpu_count() or 1)
     assert quota is None or cores <= quota
+
+
+def test_round3_headline_line_is_complete_and_self_consistent():
+    """the default line carries the power-law variant beside the headline, a cache-path
+    K2 rate is never labelled an HBM fraction (bound 'fabric / infinity cache' + the HBM-regime fraction of the same
+    kernel in hbm_frac), the PMC traffic belongs to the headline workload only, and the CPU baseline says what the
+    cores really bought (one thread and all cores on the SAME sample)."""
+    lines = dict(_lines("r03"))
+    d = lines["r03_bench_syn1m_f32_1gpu.json"]
+    assert CONTRACT_KEYS <= set(d) and d["unit"] == "epochs/s" and d["vs_baseline"] is None
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-3
+    r = d["roofline"]
+    assert r["bound"] == "fabric / infinity cache" and 0.5 <= r["hbm_frac"] <= 1.0       # BASELINE: >= 50 % of the HBM roofline
+    assert abs(r["hbm_frac"] - d["roofline_hbm_regime"][[k for k, v in d["roofline_k2_all"].items()
+                                                         if v["kernel"] == r["kernel"]][0]]["frac"]) < 1e-9
+    assert abs(r["traffic"] / r["moved_bytes_per_launch"] - 1.0) < 0.03
+    for v in d["roofline_k2_all"].values():
+        assert v["bound"] != "hbm" and v["hbm_frac"] >= 0.5
+    sk = d["skew"]
+    assert sk["unit"] == "epochs/s" and "power-law" in sk["workload"] and set(sk["k2"]) == {"eval", "train", "bwd_cols"}
+    assert abs(sk["value"] * sk["ms_per_step"] / 1e3 - 1.0) < 1e-3
+    assert all(v["bound"] != "hbm" for v in sk["k2"].values())
+    c = d["cpu_baseline"]
+    assert c["all_cores"]["sample_n"] == c["one_thread"]["sample_n"] >= 10_000
+    assert c["all_cores"]["threads"] == c["cores"] and c["one_thread"]["threads"] == 1
+    assert abs(c["cores_effective"] - c["one_thread"]["epoch_s"] / c["all_cores"]["epoch_s"]) < 0.02
+    assert d["value"] >= 26.3                         # not slower than round 2's line
+    for name, dd in lines.items():                    # every committed round-3 line follows the contract
+        assert CONTRACT_KEYS <= set(dd) | {"roofline"}, name
+        assert dd["unit"] == "epochs/s" and dd["data"] == "synthetic" and "workload" in dd["config"]
+
+
+def test_cpu_baseline_leg_runs_on_one_sample(monkeypatch):
+    """bench.cpu_baseline on a tiny sample: both thread counts on the same N, cores_effective = their ratio."""
+    monkeypatch.setattr(bench, "host_cores", lambda: (2, 2, None))
+    monkeypatch.setattr(bench, "_tune_host_malloc", lambda: False)      # do not retune the test process's allocator
+    c = bench.cpu_baseline("tiny", 512, 512)
+    assert c["all_cores"]["sample_n"] == c["one_thread"]["sample_n"] == 512
+    assert c["cores"] == 2 and c["one_thread"]["threads"] == 1 and c["cores_effective"] > 0
+    assert c["kind"] == "port" and c["value"] > 0

@@ -541,9 +541,10 @@ def test_dropout_statistics(dev):
                                     (5, 12, 128), (3, 20, 64), (2, 3, 32), (1, 50, 100), (10, 10, 128),
                                     # a last layer wider than the K3 / classifier kernels (256, 192 columns)
                                     (8, 32, 128), (3, 64, 40),
-                                    (8, 8, 200)])                                                    # mp_att_size above the K3 kernels
+                                    (8, 8, 200), (8, 16, 256),                                       # mp_att_size 129 .. 256: K3 kernels (round 3)
+                                    (8, 8, 300)])                                                    # mp_att_size above the K3 kernels
 @pytest.mark.parametrize("drop", [0.0, 0.6])
-def test_other_head_shapes_match_oracle(dev, K, FP, A, drop):
+def test_other_head_shapes_match_oracle(dev, K, FP, A, drop, monkeypatch):
     """hid_units=[F'], n_heads=[K,1] other than 8x8 and mp_att_size other than 128 (models/gat.py:37,42-57
     leave them free).  K*F' = 64: every kernel template (K1 per-head dropout tiles, K2 lane->head maps,
     score-parameter reductions).  Other widths: the heads run through K1/K2 in 64-column groups (short
@@ -554,11 +555,22 @@ def test_other_head_shapes_match_oracle(dev, K, FP, A, drop):
     n, f, p = 90, 14, 2
     prob = make_problem(500 + K, n, f, p, 3, [0.06, 0.4], hid_units=[FP], n_heads=(K, 1), mp_att_size=A)
     model, bp = build_model(prob, dev)
+    import contextlib
+
+    @contextlib.contextmanager
+    def hip_only():      # shapes on the HIP kernels end to end: no library GEMM / torch elementwise in the product path
+        with monkeypatch.context() as mp:
+            if K * FP <= 128 and A <= 256:
+                def _no_torch(*a, **k):
+                    raise AssertionError("torch.matmul / torch.tanh in a path the HIP kernels cover")
+                mp.setattr(torch, "matmul", _no_torch)
+                mp.setattr(torch, "tanh", _no_torch)
+            yield
     assert (model.K, model.FP, model.A) == (K, FP, A) and tuple(model.w_omega.shape) == (K * FP, A)
     lg, fe, att = ho.hetegat_multi_inference([prob["x"]] * p, 3, n, False, 0.0, 0.0, prob["biases"],
                                              [FP], [K, 1], prob["params"], mp_att_size=A)
     x, graphs = gpu_inputs(prob, dev)
-    with torch.no_grad():
+    with torch.no_grad(), hip_only():
         logits, final_embed, att_val = model.inference([x] * p, 3, n, False, 0.0, 0.0, graphs, [FP], [K, 1],
                                                        mp_att_size=A)
     assert tuple(final_embed.shape) == (n, K * FP)
@@ -573,7 +585,8 @@ def test_other_head_shapes_match_oracle(dev, K, FP, A, drop):
         keep = rng_ref.keep_prob32(drop)
         masks = [group_masks(seeds[q], n, f, K, FP, *ho.bias_to_csr(prob["biases"][q]), drop) for q in range(p)]
     loss_ref, gref, lg_ref = _oracle_grads(prob, bp, masks=masks, keep=keep, dense=False)
-    loss, grads, lgg, _ = _gpu_loss_and_grads(model, prob, dev, attn_drop=drop, ffd_drop=drop)
+    with hip_only():
+        loss, grads, lgg, _ = _gpu_loss_and_grads(model, prob, dev, attn_drop=drop, ffd_drop=drop)
     assert np.abs(lgg - lg_ref).max() < 5 * TOL
     assert abs(loss - loss_ref) < 5e-4
     for k in ht.PARAM_ORDER:
@@ -589,7 +602,11 @@ def test_other_head_shapes_match_oracle(dev, K, FP, A, drop):
                                      (77, 5, 128, 128), (129, 64, 64, 128), (5000, 3, 128, 128),
                                      # >= 65536 rows: the forward contraction runs on the bf16 matrix pipe (exact split)
                                      (20000, 4, 128, 64), (70000, 1, 64, 64), (9000, 8, 128, 64), (5000, 16, 64, 64),
-                                     (40000, 2, 128, 64)])
+                                     (40000, 2, 128, 64),
+                                     # round 3: attention spaces of 192 / 256 columns (mp_att_size up to 256) on the
+                                     # width-templated kernels, 64- and 128-wide embeddings
+                                     (333, 2, 256, 64), (1000, 4, 192, 64), (77, 5, 256, 128), (2000, 8, 192, 128),
+                                     (70000, 4, 256, 64), (1, 1, 256, 128)])
 def test_semantic_attention_fwd_bwd(dev, n, p, a, d):
     from han_amd import ops
     rng = np.random.default_rng(n + p)
