@@ -121,6 +121,35 @@ __device__ __forceinline__ float4_t load_x4(const void *X, int bf, int64_t idx) 
     return *reinterpret_cast<const float4_t *>(reinterpret_cast<const float *>(X) + idx);
 }
 
+// Four consecutive elements starting at element `idx`, of which the first `nvalid` (1..4) exist: one 16-byte (fp32) /
+// 8-byte (bf16) load that needs no more than element alignment when all four exist (global memory is in unaligned
+// access mode; F = 1870 of the ACM data set makes every other row start 8 bytes off a 16-byte boundary), element
+// loads for a row's last, partial quad.  (Round 3: inputs whose width is not a multiple of 4 used to fall back to
+// one 4-byte load per element in the fp32 kernels.)
+typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned int uint2_u __attribute__((ext_vector_type(2), aligned(2)));
+__device__ __forceinline__ float4_t load_x4_tail(const void *X, int bf, int64_t idx, int nvalid) {
+    float4_t v = {0.f, 0.f, 0.f, 0.f};
+    if (nvalid >= 4) {
+        if (bf) {
+            const uint2_u w = *reinterpret_cast<const uint2_u *>(reinterpret_cast<const uint16_t *>(X) + idx);
+            v[0] = __uint_as_float(w[0] << 16);
+            v[1] = __uint_as_float(w[0] & 0xFFFF0000u);
+            v[2] = __uint_as_float(w[1] << 16);
+            v[3] = __uint_as_float(w[1] & 0xFFFF0000u);
+        } else {
+            const float4_u w = *reinterpret_cast<const float4_u *>(reinterpret_cast<const float *>(X) + idx);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = w[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            if (e < nvalid) v[e] = load_x1(X, bf, idx + e);
+    }
+    return v;
+}
+
 // heads covered by one 16-column MFMA tile
 template <int FP>
 struct HeadsPerTile { static constexpr int value = FP >= 16 ? 1 : 16 / FP; };
@@ -165,7 +194,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a_in
                 const int r = idx >> 3, c4 = (idx & 7) * 4;
                 const int64_t row = row0 + r;
                 float4_t v = {0.f, 0.f, 0.f, 0.f};
-                if (row < a.N && k0 + c4 < k_end) v = load_x4(a.X, a.x_bf16, row * a.ldx + k0 + c4);
+                if (row < a.N && k0 + c4 < k_end) v = load_x4_tail(a.X, a.x_bf16, row * a.ldx + k0 + c4, k_end - (k0 + c4));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xr[4 * i + e] = v[e];
             }
@@ -916,7 +945,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const ProjBwdArgs a_in
                 const int r = idx / (BFR / 4), c4 = (idx % (BFR / 4)) * 4;
                 const int64_t row = n0 + r;
                 float4_t v = {0.f, 0.f, 0.f, 0.f};
-                if (row < n_end && f0 + c4 < a.F) v = load_x4(a.X, a.x_bf16, row * a.ldx + f0 + c4);
+                if (row < n_end && f0 + c4 < a.F) v = load_x4_tail(a.X, a.x_bf16, row * a.ldx + f0 + c4, a.F - (f0 + c4));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xr[4 * i + e] = v[e];
             }
@@ -1158,7 +1187,7 @@ __global__ __launch_bounds__(256, 4) void project_bwd_blk_kernel(const ProjBwdBl
         DROP ? (int)((nrows - 1) * a.F + (a.F - f0 < DW_FB ? a.F - f0 : DW_FB)) : 0, 0x00020000);
     const int xc4 = (tid & 31) * 4;
     const uint32_t vx = f0 + xc4 < a.F ? (uint32_t)(((tid >> 5) * a.ldx + xc4) * XE) : OOB;      // + 8 i rows
-    const uint32_t vg = (uint32_t)((tid >> 4) * (HAN_D * 4) + (tid & 15) * 16);               // + 16 i rows
+    const uint32_t vg = (uint32_t)((tid >> 3) * (HAN_D * 4) + (tid & 7) * 32);                // (row, head): 8 columns = 2 x 16 B
     const uint32_t vk = f0 + 16 * (tid & 7) < a.F ? (uint32_t)((tid >> 3) * a.F + 16 * (tid & 7)) : OOB;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -1184,8 +1213,8 @@ __global__ __launch_bounds__(256, 4) void project_bwd_blk_kernel(const ProjBwdBl
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            gr[i] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_g, vg + (step + 16 * i) * (HAN_D * 4), 0, 0));
+        for (int i = 0; i < 2; ++i)      // the 8 columns of this thread's (row, head): parity 0 and parity 1 quads
+            gr[i] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_g, vg + step * (HAN_D * 4) + 16 * i, 0, 0));
         if (DROP) {      // features beyond F meet X == 0, so their (arbitrary) keep bits do not matter
             const uint32_t vo = vk == OOB ? OOB : vk + step * (uint32_t)a.F;
             kr[0] = __builtin_amdgcn_raw_buffer_load_b64(rs_k, vo, 0, 0);
@@ -1193,7 +1222,9 @@ __global__ __launch_bounds__(256, 4) void project_bwd_blk_kernel(const ProjBwdBl
         }
     };
     // dword offsets of this lane's operands inside a row of the three LDS images
-    const int a_off = 32 * w + 16 * q + 4 * i4;
+    // (the wave's 32 dwords of a row are rotated by 4 w: with it the staging stores of the four waves' features fall
+    //  on 32 different banks -- without, 4-way conflicts on every store made LDS co-critical with the matrix pipe)
+    const int a_off = 32 * w + ((16 * q + 4 * i4 + 4 * w) & 31);
     const int b_off = 8 * bq + 2 * i4;
     const int k_off = 8 * w + 4 * q;
     const uint32_t my_bit = (uint32_t)(lane & 31);
@@ -1205,18 +1236,17 @@ __global__ __launch_bounds__(256, 4) void project_bwd_blk_kernel(const ProjBwdBl
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
             const int r = idx >> 5, k = idx & 31;      // features 4k .. 4k+3: wave k/8, octet (k%8)/2, half k%2, i = e
-            float *dst = Xs + r * DW_FB + 32 * (k >> 3) + 16 * (k & 1) + ((k & 7) >> 1);
+            const int wv = k >> 3;
+            float *dst = Xs + r * DW_FB + 32 * wv + ((k & 7) >> 1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[4 * e] = xr[i][e];
+            for (int e = 0; e < 4; ++e) dst[(16 * (k & 1) + 4 * e + 4 * wv) & 31] = xr[i][e];
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            const int cq = idx & 15, hd = cq >> 1;                     // column quad -> (head, parity); j = e
+        {      // dH: this thread's (row, head) as [j][parity] pairs -- 32 contiguous bytes, two 16-B stores
+            const int hd = tid & 7;
             const int rank = (hd & 1) * 4 + (hd >> 1);                 // b' of that head
-            float *dst = Gs + (idx >> 4) * HAN_D + 8 * rank + (cq & 1);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dst[2 * e] = gr[i][e];
+            float *dst = Gs + (tid >> 3) * HAN_D + 8 * rank;
+            *reinterpret_cast<float4_t *>(dst) = (float4_t){gr[0][0], gr[1][0], gr[0][1], gr[1][1]};
+            *reinterpret_cast<float4_t *>(dst + 4) = (float4_t){gr[0][2], gr[1][2], gr[0][3], gr[1][3]};
         }
         if (DROP) {
             const int seg = tid & 7;                                   // octets 2 seg, 2 seg + 1 of the tile's 16
@@ -1372,6 +1402,7 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
     a.row_offset = row_offset;
     a.keep = in_drop > 0.f ? keep : nullptr;
     const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & (a.x_bf16 ? 7 : 15)) == 0);
+    const bool vec32 = true;      // the exact-fp32 kernels: quad loads at element alignment, element loads for a partial last quad
     int mt, nsplit;
     fwd_geometry(N, F, &mt, &nsplit, &a.f_chunk);
     a.partial = nullptr;
@@ -1419,10 +1450,10 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
 #define HAN_LAUNCH_FWD(MTC)                                                                  \
     HAN_DISPATCH_FP(FP, {                                                                    \
         if (in_drop > 0.f) {                                                                 \
-            if (vec) project_fwd_kernel<FPC, true, MTC, true><<<grid, 256, 0, st>>>(a);      \
+            if (vec32) project_fwd_kernel<FPC, true, MTC, true><<<grid, 256, 0, st>>>(a);    \
             else project_fwd_kernel<FPC, true, MTC, false><<<grid, 256, 0, st>>>(a);         \
         } else {                                                                             \
-            if (vec) project_fwd_kernel<FPC, false, MTC, true><<<grid, 256, 0, st>>>(a);     \
+            if (vec32) project_fwd_kernel<FPC, false, MTC, true><<<grid, 256, 0, st>>>(a);   \
             else project_fwd_kernel<FPC, false, MTC, false><<<grid, 256, 0, st>>>(a);        \
         }                                                                                    \
     })
@@ -1580,12 +1611,13 @@ extern "C" int han_project_bwd(const void *X, int x_dtype, int64_t ldx, const fl
     // (dW on the bf16 x 6 matrix pipe was built and measured in round 2 -- coalesced loads + on-chip transpose:
     // 0.55 ms without / 0.83 ms with dropout against 0.41 / 0.84 ms for this exact-fp32 kernel at SYN-1M --
     // and not kept: the transposition of both operands through LDS costs what the shorter matrix time saves.)
+    const bool vec32 = true;      // quad loads at element alignment (load_x4_tail)
     HAN_DISPATCH_FP(FP, {
         if (in_drop > 0.f) {
-            if (vec) project_bwd_kernel<FPC, true, kBwdMT, true><<<grid, 256, 0, st>>>(a);
+            if (vec32) project_bwd_kernel<FPC, true, kBwdMT, true><<<grid, 256, 0, st>>>(a);
             else project_bwd_kernel<FPC, true, kBwdMT, false><<<grid, 256, 0, st>>>(a);
         } else {
-            if (vec) project_bwd_kernel<FPC, false, kBwdMT, true><<<grid, 256, 0, st>>>(a);
+            if (vec32) project_bwd_kernel<FPC, false, kBwdMT, true><<<grid, 256, 0, st>>>(a);
             else project_bwd_kernel<FPC, false, kBwdMT, false><<<grid, 256, 0, st>>>(a);
         }
     })
