@@ -62,6 +62,8 @@ SIGNATURES = {
     "han_classifier_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
     "han_classifier_loss": (c_int, [P, P, P, P, P, c_float, P, P, P, P, P, P, c_size_t, I64,
                                     c_int, c_int, c_int, P]),
+    "han_classifier_bwd_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
+    "han_classifier_bwd": (c_int, [P, P, P, P, P, P, P, P, c_size_t, I64, c_int, c_int, c_int, P]),
     "han_adam_step": (c_int, [P, P, P, P, I64, c_float, c_float, c_float, c_float, c_float, P, P]),
     "han_l2_half_sumsq": (c_int, [P, I64, P, P, c_size_t, P]),
     "han_bias_row_counts": (c_int, [P, I64, I64, P, P]),

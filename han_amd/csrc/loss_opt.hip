@@ -361,10 +361,204 @@ __global__ __launch_bounds__(256) void bias_fill_kernel(const float *bias, int64
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Any embedding width (D a multiple of 64: a last layer of 8 heads x 32, hid_units = [128] ...) and any
+// class count (round 3; models/gat.py:61-72 leaves both free).  Three small kernels instead of one:
+//   cls_mean_kernel   WmT[c][d] = mean_h Wc[h][d][c], bm[c] = mean_h bc[h][c]   (the head average, once)
+//   cls_gen_kernel    one wave per row, lane = feature: logit_c = wave_sum(z . WmT[c]) + bm[c] class by class
+//                     (online max / sum / first argmax), loss + accuracy; backward: dl_c, dZ = sum_c dl_c WmT[c]
+//                     in registers, dl rows to a scratch table.  Rows outside the loss mask have dl == 0
+//                     exactly: their dZ row is written as zeros and the class loop is skipped.
+//   cls_dw_kernel     dWm = Z^T dL over the MASKED rows only (the others add exactly 0), one block per
+//                     (row split, 64-feature tile, 16-class tile), lane = feature; db from the feature-tile-0 blocks
+// NV = registers holding the row (64*NV >= D), or 0: any width, the row is re-read from L1 per class.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cls_mean_kernel(const float *Wc, const float *bc, float *WmT, float *bm,
+                                                       int D, int C, int HC) {
+    const float invh = 1.f / (float)HC;
+    const int64_t n = (int64_t)D * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i / D), d = (int)(i % D);
+        float s = 0.f;
+        for (int h = 0; h < HC; ++h) s += Wc[(int64_t)h * n + (int64_t)d * C + c];
+        WmT[i] = s * invh;
+    }
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float s = 0.f;
+            for (int h = 0; h < HC; ++h) s += bc[h * C + c];
+            bm[c] = s * invh;
+        }
+}
+
+struct ClsGenArgs {
+    const float *Z, *WmT, *bm;
+    const int32_t *labels;
+    const uint8_t *mask;
+    float row_weight;
+    float *logits, *dZ, *dL, *slab;    // slab: [gridDim.x][2] loss | acc
+    int64_t N;
+    int D, C;
+};
+
+template <bool BWD, int NV>
+__global__ __launch_bounds__(256) void cls_gen_kernel(const ClsGenArgs a) {
+    constexpr int NR = NV > 0 ? NV : 1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int D = a.D, C = a.C, nv = D / 64;
+    float loss_acc = 0.f, acc_acc = 0.f;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave0; row < a.N; row += nwaves) {
+        const float *zrow = a.Z + row * D + lane;
+        float z[NR];
+        if (NV > 0) {
+#pragma unroll
+            for (int v = 0; v < NR; ++v) z[v] = v < nv ? zrow[64 * v] : 0.f;
+        }
+        float mx = HAN_NEG_BIG, se = 0.f, llab = 0.f;
+        int am = 0;
+        const int lab = a.labels[row];
+        const float wgt = a.mask[row] ? a.row_weight : 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float *wr = a.WmT + (int64_t)c * D + lane;
+            float part = 0.f;
+            if (NV > 0) {
+#pragma unroll
+                for (int v = 0; v < NR; ++v) part += v < nv ? z[v] * wr[64 * v] : 0.f;
+            } else {
+                for (int v = 0; v < nv; ++v) part += zrow[64 * v] * wr[64 * v];
+            }
+            const float lg = han_wave_sum(part) + a.bm[c];
+            if (lane == 0) a.logits[row * C + c] = lg;
+            if (lg > mx) {       // first maximum, as argmax
+                se = se * __expf(mx - lg) + 1.f;
+                mx = lg;
+                am = c;
+            } else {
+                se += __expf(lg - mx);
+            }
+            llab = (c == lab) ? lg : llab;
+        }
+        if (lane == 0) {
+            loss_acc += wgt * (mx + __logf(se) - llab);
+            acc_acc += wgt * (am == lab ? 1.f : 0.f);
+        }
+        if (BWD) {
+            float dz[NR];
+#pragma unroll
+            for (int v = 0; v < NR; ++v) dz[v] = 0.f;
+            if (wgt != 0.f) {        // wave-uniform: rows outside the mask have dl == 0 exactly
+                const float inv = 1.f / se;
+                if (NV == 0)
+                    for (int v = 0; v < nv; ++v) a.dZ[row * D + 64 * v + lane] = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    // lane 0 wrote the logit; it reads it back (same thread) and hands it to the wave
+                    const float lg = __int_as_float(__builtin_amdgcn_readfirstlane(
+                        __float_as_int(lane == 0 ? a.logits[row * C + c] : 0.f)));
+                    const float dl = wgt * (__expf(lg - mx) * inv - (c == lab ? 1.f : 0.f));
+                    if (lane == 0) a.dL[row * C + c] = dl;
+                    const float *wr = a.WmT + (int64_t)c * D + lane;
+                    if (NV > 0) {
+#pragma unroll
+                        for (int v = 0; v < NR; ++v) dz[v] += v < nv ? dl * wr[64 * v] : 0.f;
+                    } else {
+                        for (int v = 0; v < nv; ++v) a.dZ[row * D + 64 * v + lane] += dl * wr[64 * v];
+                    }
+                }
+            }
+            if (NV > 0 || wgt == 0.f) {
+                if (NV > 0) {
+#pragma unroll
+                    for (int v = 0; v < NR; ++v)
+                        if (v < nv) a.dZ[row * D + 64 * v + lane] = dz[v];
+                } else {
+                    for (int v = 0; v < nv; ++v) a.dZ[row * D + 64 * v + lane] = 0.f;
+                }
+            }
+        }
+    }
+    __shared__ float red[4][2];
+    if (lane == 0) { red[w][0] = loss_acc; red[w][1] = acc_acc; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        a.slab[(int64_t)blockIdx.x * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// slab row per row split: [D*C] dWm | [C] dbm.  grid = (splits, D/64 feature tiles, ceil(C/16) class tiles)
+__global__ __launch_bounds__(256) void cls_dw_kernel(const float *Z, const float *dL, const uint8_t *mask, float *slab,
+                                                     int64_t N, int D, int C) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int d0 = 64 * blockIdx.y, c0 = 16 * blockIdx.z;
+    const int nc = C - c0 < 16 ? C - c0 : 16;
+    const int64_t per = (N + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = per * blockIdx.x, r1 = (r0 + per < N) ? r0 + per : N;
+    float acc[16], dbacc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { acc[j] = 0.f; dbacc[j] = 0.f; }
+    for (int64_t row = r0 + w; row < r1; row += 4) {
+        if (mask && !mask[row]) continue;               // wave-uniform; dl of such a row is exactly 0
+        const float z = Z[row * D + d0 + lane];
+        const float *dl = dL + row * C + c0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float v = j < nc ? dl[j] : 0.f;
+            acc[j] += z * v;
+            dbacc[j] += v;
+        }
+    }
+    __shared__ float red[4][16][65];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) red[w][j][lane] = acc[j];
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[w][j][64] = dbacc[j];
+    }
+    __syncthreads();
+    float *out = slab + (int64_t)blockIdx.x * ((int64_t)D * C + C);
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+        const int j = i & 15, d = i >> 4;
+        if (j < nc) out[(int64_t)(d0 + d) * C + c0 + j] = red[0][j][d] + red[1][j][d] + red[2][j][d] + red[3][j][d];
+    }
+    if (blockIdx.y == 0 && threadIdx.x < nc)
+        out[(int64_t)D * C + c0 + threadIdx.x] = red[0][threadIdx.x][64] + red[1][threadIdx.x][64] + red[2][threadIdx.x][64] + red[3][threadIdx.x][64];
+}
+
+// dZ = dL . Wm^T for a given dL (the backward of the logits alone, HeteGAT_multi.inference without the fused loss)
+__global__ __launch_bounds__(256) void cls_dz_kernel(const float *dL, const float *WmT, float *dZ, int64_t N, int D, int C) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave0; row < N; row += nwaves) {
+        const float *dl = dL + row * C;
+        for (int f = lane; f < D; f += 64) {
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s += dl[c] * WmT[(int64_t)c * D + f];
+            dZ[row * D + f] = s;
+        }
+    }
+}
+
+constexpr int kClsGenBlocks = 2048;
+
+static int cls_dw_splits(int D, int C) {
+    const int tiles = (D / 64) * ((C + 15) / 16);
+    int s = 1024 / tiles;
+    return s < 1 ? 1 : (s > 256 ? 256 : s);
+}
+
+// workspace of the general path, in floats: WmT | bm | loss/acc slabs | dL | dW slabs
+static size_t cls_gen_workspace_floats(int64_t N, int D, int C) {
+    return (size_t)D * C + (size_t)C + (size_t)kClsGenBlocks * 2 + (size_t)N * C +
+           (size_t)cls_dw_splits(D, C) * ((size_t)D * C + C);
+}
+
+static bool cls_tuned(int D, int C) { return (D == 64 || D == 128) && C >= 1 && C <= 64; }
+
 }  // namespace
 
 extern "C" size_t han_classifier_workspace(int64_t N, int D, int C, int HC) {
-    (void)N; (void)HC;
+    (void)HC;
+    if (D >= 64 && D % 64 == 0 && C >= 1 && !cls_tuned(D, C)) return cls_gen_workspace_floats(N, D, C) * sizeof(float);
     return (size_t)kClsBlocks * (size_t)(D * C + C + 2) * sizeof(float);
 }
 
@@ -374,11 +568,46 @@ extern "C" int han_classifier_loss(const float *Z, const float *Wc, const float 
                                    int64_t N, int D, int C, int HC, void *stream) {
     if (!Z || !Wc || !bc || !labels || !mask || !logits || !loss_acc || !workspace || N < 0 || HC <= 0)
         return HAN_E_BADARG;
-    if ((D != 64 && D != 128) || C < 1 || C > 64) return HAN_E_UNSUPPORTED;
+    if (D < 64 || D % 64 != 0 || C < 1) return HAN_E_UNSUPPORTED;
     const bool bwd = dZ != nullptr;
     if (bwd && (!dWc || !dbc)) return HAN_E_BADARG;
     if (workspace_bytes < han_classifier_workspace(N, D, C, HC)) return HAN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (!cls_tuned(D, C)) {       // any embedding width / class count: the three-kernel path
+        float *ws = (float *)workspace;
+        ClsGenArgs g;
+        float *WmT = ws, *bm = WmT + (size_t)D * C, *la = bm + C, *dL = la + (size_t)kClsGenBlocks * 2,
+              *dws = dL + (size_t)N * C;
+        g.Z = Z; g.WmT = WmT; g.bm = bm; g.labels = labels; g.mask = mask; g.row_weight = row_weight;
+        g.logits = logits; g.dZ = dZ; g.dL = dL; g.slab = la; g.N = N; g.D = D; g.C = C;
+        cls_mean_kernel<<<han_grid_for((int64_t)D * C, 256, 256), 256, 0, st>>>(Wc, bc, WmT, bm, D, C, HC);
+        HAN_CHECK_LAUNCH();
+        const int grid = han_grid_for(N > 0 ? N : 1, 4, kClsGenBlocks);
+#define HAN_CLS_GEN(NVV)                                                   \
+    if (bwd) cls_gen_kernel<true, NVV><<<grid, 256, 0, st>>>(g);           \
+    else cls_gen_kernel<false, NVV><<<grid, 256, 0, st>>>(g);
+        if (D <= 256) { HAN_CLS_GEN(4) } else if (D <= 512) { HAN_CLS_GEN(8) } else if (D <= 1024) { HAN_CLS_GEN(16) } else { HAN_CLS_GEN(0) }
+#undef HAN_CLS_GEN
+        HAN_CHECK_LAUNCH();
+        hipError_t e = han_reduce_slabs(la, grid, 2, 2, han_reduce_to(loss_acc, 2), st);
+        if (e != hipSuccess) return (int)e;
+        if (bwd) {
+            const int S = cls_dw_splits(D, C);
+            cls_dw_kernel<<<dim3(S, D / 64, (C + 15) / 16), 256, 0, st>>>(Z, dL, mask, dws, N, D, C);
+            HAN_CHECK_LAUNCH();
+            const int width = D * C + C;
+            HanReduceOut o = han_reduce_to(dWc, width);
+            o.nseg = 2;
+            o.ptr[1] = dbc;
+            o.seg_end[0] = D * C; o.seg_end[1] = width;
+            o.scale[0] = o.scale[1] = 1.f / (float)HC;
+            o.rep[0] = o.rep[1] = HC;
+            o.rep_stride[0] = (int64_t)D * C; o.rep_stride[1] = C;
+            e = han_reduce_slabs(dws, S, width, width, o, st);
+            if (e != hipSuccess) return (int)e;
+        }
+        return 0;
+    }
     ClsArgs a;
     a.Z = Z; a.Wc = Wc; a.bc = bc; a.labels = labels; a.mask = mask; a.row_weight = row_weight;
     a.logits = logits; a.dZ = dZ; a.slab = (float *)workspace; a.N = N; a.C = C; a.HC = HC;
@@ -413,6 +642,40 @@ extern "C" int han_classifier_loss(const float *Z, const float *Wc, const float 
         hipError_t e = han_reduce_slabs(slab + D * C + C, grid, width, 2, han_reduce_to(loss_acc, 2), st);
         if (e != hipSuccess) return (int)e;
     }
+    return 0;
+}
+
+extern "C" size_t han_classifier_bwd_workspace(int64_t N, int D, int C, int HC) {
+    (void)N; (void)HC;
+    if (D < 64 || D % 64 != 0 || C < 1) return 0;
+    return ((size_t)D * C + (size_t)C + (size_t)cls_dw_splits(D, C) * ((size_t)D * C + C)) * sizeof(float);
+}
+
+extern "C" int han_classifier_bwd(const float *Z, const float *Wc, const float *bc, const float *dlogits, float *dZ,
+                                  float *dWc, float *dbc, void *workspace, size_t workspace_bytes, int64_t N, int D,
+                                  int C, int HC, void *stream) {
+    if (!Z || !Wc || !bc || !dlogits || !dZ || !dWc || !dbc || !workspace || N < 0 || HC <= 0) return HAN_E_BADARG;
+    if (D < 64 || D % 64 != 0 || C < 1) return HAN_E_UNSUPPORTED;
+    if (workspace_bytes < han_classifier_bwd_workspace(N, D, C, HC)) return HAN_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float *WmT = (float *)workspace, *bm = WmT + (size_t)D * C, *dws = bm + C;
+    cls_mean_kernel<<<han_grid_for((int64_t)D * C, 256, 256), 256, 0, st>>>(Wc, bc, WmT, bm, D, C, HC);
+    HAN_CHECK_LAUNCH();
+    cls_dz_kernel<<<han_grid_for(N > 0 ? N : 1, 4, kClsGenBlocks), 256, 0, st>>>(dlogits, WmT, dZ, N, D, C);
+    HAN_CHECK_LAUNCH();
+    const int S = cls_dw_splits(D, C);
+    cls_dw_kernel<<<dim3(S, D / 64, (C + 15) / 16), 256, 0, st>>>(Z, dlogits, nullptr, dws, N, D, C);
+    HAN_CHECK_LAUNCH();
+    const int width = D * C + C;
+    HanReduceOut o = han_reduce_to(dWc, width);
+    o.nseg = 2;
+    o.ptr[1] = dbc;
+    o.seg_end[0] = D * C; o.seg_end[1] = width;
+    o.scale[0] = o.scale[1] = 1.f / (float)HC;
+    o.rep[0] = o.rep[1] = HC;
+    o.rep_stride[0] = (int64_t)D * C; o.rep_stride[1] = C;
+    hipError_t e = han_reduce_slabs(dws, S, width, width, o, st);
+    if (e != hipSuccess) return (int)e;
     return 0;
 }
 
@@ -462,7 +725,7 @@ extern "C" const char *han_error_string(int code) {
     switch (code) {
         case 0: return "ok";
         case HAN_E_BADARG: return "han: bad argument (null pointer, negative size or inconsistent shape)";
-        case HAN_E_UNSUPPORTED: return "han: shape not supported by this build (needs K*FP == 64, FP in {4,8,16,32,64}, A in {64,128}, C <= 16)";
+        case HAN_E_UNSUPPORTED: return "han: shape not supported by this build (K*FP == 64 with FP in {4,8,16,32,64}; D and A multiples of 64)";
         case HAN_E_WORKSPACE: return "han: workspace too small";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "han: unknown error";
     }

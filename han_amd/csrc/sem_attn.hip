@@ -1389,6 +1389,264 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_gen_kernel(const float *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Any embedding width and any attention size (round 3): D and A are run-time multiples of 64 -- a last
+// layer of 8 heads x 32 (D = 256), hid_units = [128] with 8 heads (D = 1024), mp_att_size = 512 ...
+// (models/gat.py:42-61 leaves all of them free).  Womega (D x A, at most a few hundred KB) no longer fits
+// the LDS next to the tiles, so the B fragments of the contraction come straight from global memory: every
+// wave of the chip reads the same matrix, which lives in the L1s / L2s.  The forward runs the attention
+// space in slices of 64*CA columns -- the score s = sum_a u_a tanh(pre_a) is additive over slices -- and
+// the backward in slices of 64 columns x chunks of 128 embedding columns for dWomega (one launch per
+// (slice, chunk); the launches of a slice after the first recompute pre and only add their dW chunk).
+// Off the tuned path: ~L1-bandwidth-bound (5 fragment loads per 4 MFMAs), measured in DESIGN.md sec. 3.
+// ---------------------------------------------------------------------------------------------
+template <int CA>
+__global__ __launch_bounds__(256) void sem_attn_fwd_wide_kernel(const float *__restrict__ M, const float *__restrict__ Wg,
+                                                                const float *bw, const float *uw, float *Z,
+                                                                float *beta, int64_t N, int P, int D, int A) {
+    constexpr int AS = 64 * CA;
+    constexpr int TA = AS / 16;
+    __shared__ float sc[2 * ROWS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int NB = ROWS / P;
+    const int64_t nchunks = (N + NB - 1) / NB;
+    int buf = 0;
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x, buf ^= 1) {
+        const int64_t node0 = ch * NB;
+        const int nodes = (int)((N - node0) < NB ? (N - node0) : NB);
+        const int rows = nodes * P;
+        const int64_t row0 = node0 * P;
+        {
+            const int lr = 16 * w + l15;
+            const float *mrow = M + (row0 + (lr < rows ? lr : rows - 1)) * D + l4;
+            float spart[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int a_off = 0; a_off < A; a_off += AS) {
+                f32x4 acc[TA];
+#pragma unroll
+                for (int t = 0; t < TA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float *wcol = Wg + (int64_t)l4 * A + a_off + l15;
+#pragma unroll 4
+                for (int ks = 0; ks < D / 4; ++ks) {
+                    const float a = mrow[4 * ks];
+                    const float *wr = wcol + (int64_t)(4 * ks) * A;
+#pragma unroll
+                    for (int t = 0; t < TA; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wr[16 * t], acc[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < TA; ++t) {
+                    const float bc = bw[a_off + 16 * t + l15], uc = uw[a_off + 16 * t + l15];
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) spart[reg] += fast_tanh(acc[t][reg] + bc) * uc;
+                }
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float s = han_row16_sum(spart[reg]);
+                if (l15 == 0) sc[buf * ROWS + 16 * w + 4 * l4 + reg] = s;
+            }
+        }
+        __syncthreads();
+        for (int nd = w; nd < nodes; nd += 4) {
+            const int64_t n = node0 + nd;
+            const float *srow = sc + buf * ROWS + nd * P;
+            float mrun = HAN_NEG_BIG;
+            for (int p = 0; p < P; ++p) mrun = fmaxf(mrun, srow[p]);
+            float lrun = 0.f;
+            for (int p = 0; p < P; ++p) lrun += __expf(srow[p] - mrun);
+            const float inv = 1.f / lrun;
+            for (int f = lane; f < D; f += 64) {
+                float z = 0.f;
+                for (int p = 0; p < P; ++p) z += __expf(srow[p] - mrun) * M[(n * P + p) * D + f];
+                Z[n * D + f] = z * inv;
+            }
+            if (lane < P) beta[n * P + lane] = __expf(srow[lane] - mrun) * inv;
+        }
+    }
+}
+
+constexpr int kWideDChunk = 128;     // embedding columns of dWomega per backward launch (DTC = 8 tiles)
+
+// slab row per block: [D*A] dW | [A] db | [A] du; this launch owns the attention columns [a_off, a_off + 64) and the
+// dW rows [d_off, d_off + 128); the launch with d_off == 0 also owns db / du of its slice and adds the slice's dM term
+__global__ __launch_bounds__(256) void sem_attn_bwd_wide_kernel(const float *__restrict__ M, const float *__restrict__ Wg,
+                                                                const float *bw, const float *uw,
+                                                                const float *beta, const float *dZ, float *dM,
+                                                                float *slab, int64_t N, int P, int D, int A,
+                                                                int a_off, int d_off) {
+    constexpr int AS = 64;
+    constexpr int TA = AS / 16;
+    constexpr int DTC = kWideDChunk / 16;
+    constexpr int WLD2 = AS + 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *dp = smem;                         // [4 waves][16][WLD2]
+    float *dsb = dp + 4 * 16 * WLD2;          // [2][ROWS]
+    float *btb = dsb + 2 * ROWS;              // [2][ROWS]
+    const bool first = d_off == 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ntile = (D - d_off) / 16 < DTC ? (D - d_off) / 16 : DTC;   // dW tiles of this chunk that exist
+    float bcol[TA], ucol[TA], du[TA], db[TA];
+    f32x4 dW[DTC][TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        bcol[t] = bw[a_off + 16 * t + l15];
+        ucol[t] = uw[a_off + 16 * t + l15];
+        du[t] = 0.f;
+        db[t] = 0.f;
+#pragma unroll
+        for (int ft = 0; ft < DTC; ++ft) dW[ft][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float *mydp = dp + w * 16 * WLD2;
+    const int NB = ROWS / P;
+    const int64_t nchunks = (N + NB - 1) / NB;
+    int buf = 0;
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x, buf ^= 1) {
+        const int64_t node0 = ch * NB;
+        const int nodes = (int)((N - node0) < NB ? (N - node0) : NB);
+        const int rows = nodes * P;
+        const int64_t row0 = node0 * P;
+        float *dsr = dsb + buf * ROWS, *btr = btb + buf * ROWS;
+        if (threadIdx.x < ROWS && threadIdx.x >= rows) {
+            dsr[threadIdx.x] = 0.f;
+            btr[threadIdx.x] = 0.f;
+        }
+        for (int nd = w; nd < nodes; nd += 4) {
+            const int64_t n = node0 + nd;
+            const float breg = lane < P ? beta[n * P + lane] : 0.f;
+            float dbreg = 0.f;
+            for (int p = 0; p < P; ++p) {
+                float part = 0.f;
+                for (int f = lane; f < D; f += 64) part += dZ[n * D + f] * M[(n * P + p) * D + f];
+                const float d = han_wave_sum(part);
+                if (lane == p) dbreg = d;
+            }
+            const float S = han_wave_sum(breg * dbreg);
+            if (lane < P) {
+                dsr[nd * P + lane] = breg * (dbreg - S);
+                btr[nd * P + lane] = breg;
+            }
+        }
+        __syncthreads();
+        f32x4 acc[TA];
+#pragma unroll
+        for (int t = 0; t < TA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            const int lr = 16 * w + l15;
+            const float *mrow = M + (row0 + (lr < rows ? lr : rows - 1)) * D + l4;
+            const float *wcol = Wg + (int64_t)l4 * A + a_off + l15;
+#pragma unroll 4
+            for (int ks = 0; ks < D / 4; ++ks) {
+                const float a = mrow[4 * ks];
+                const float *wr = wcol + (int64_t)(4 * ks) * A;
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wr[16 * t], acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float ds = dsr[16 * w + 4 * l4 + reg];
+#pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                const float v = fast_tanh(acc[t][reg] + bcol[t]);
+                const float d = ds * ucol[t] * (1.f - v * v);
+                du[t] += ds * v;
+                db[t] += d;
+                acc[t][reg] = d;
+                if (first) mydp[(4 * l4 + reg) * WLD2 + 16 * t + l15] = d;
+            }
+        }
+        // G3: dW[d_off + 16 ft + .][a_off + 16 t + .] += M^T . dpre over this tile's rows
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int lr = 16 * w + 4 * l4 + reg;
+            const float *mrow = M + (row0 + (lr < rows ? lr : rows - 1)) * D + d_off + l15;
+#pragma unroll
+            for (int ft = 0; ft < DTC; ++ft) {
+                if (ft < ntile) {
+                    const float a = mrow[16 * ft];
+#pragma unroll
+                    for (int t = 0; t < TA; ++t)
+                        dW[ft][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, acc[t][reg], dW[ft][t], 0, 0, 0);
+                }
+            }
+        }
+        // G2 (first launch of the slice): dM[r][d] (+)= sum_a dpre[r][a] Womega[d][a], four 16-column tiles at a time
+        if (first) {
+            for (int dt0 = 0; dt0 < D / 16; dt0 += 4) {
+                f32x4 acc2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float *wrow = Wg + (int64_t)(16 * dt0 + l15) * A + a_off + l4;
+#pragma unroll 4
+                for (int ks = 0; ks < AS / 4; ++ks) {
+                    const float a = mydp[l15 * WLD2 + 4 * ks + l4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[(int64_t)(16 * j) * A + 4 * ks], acc2[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int lr = 16 * w + 4 * l4 + reg;
+                    if (lr < rows) {
+                        const int64_t n = node0 + lr / P;
+                        const float bt = btr[lr];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int f = 16 * (dt0 + j) + l15;
+                            float *dst = dM + (row0 + lr) * D + f;
+                            if (a_off == 0) *dst = acc2[j][reg] + bt * dZ[n * D + f];
+                            else *dst += acc2[j][reg];
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            du[t] += __shfl_xor(du[t], o, 64);
+            db[t] += __shfl_xor(db[t], o, 64);
+        }
+    }
+    __syncthreads();
+    float *red = smem;   // [128*AS] dW | [AS] db | [AS] du
+    for (int ww = 0; ww < 4; ++ww) {
+        if (w == ww) {
+#pragma unroll
+            for (int ft = 0; ft < DTC; ++ft)
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int idx = (16 * ft + 4 * l4 + reg) * AS + 16 * t + l15;
+                        red[idx] = (ww == 0 ? 0.f : red[idx]) + dW[ft][t][reg];
+                    }
+            if (l4 == 0) {
+#pragma unroll
+                for (int t = 0; t < TA; ++t) {
+                    const int idx = kWideDChunk * AS + 16 * t + l15;
+                    red[idx] = (ww == 0 ? 0.f : red[idx]) + db[t];
+                    red[idx + AS] = (ww == 0 ? 0.f : red[idx + AS]) + du[t];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *out = slab + (int64_t)blockIdx.x * ((int64_t)D * A + 2 * A);
+    for (int i = threadIdx.x; i < 16 * ntile * AS; i += 256)
+        out[(int64_t)(d_off + i / AS) * A + a_off + (i % AS)] = red[i];
+    if (first)
+        for (int i = threadIdx.x; i < AS; i += 256) {
+            out[(int64_t)D * A + a_off + i] = red[kWideDChunk * AS + i];
+            out[(int64_t)D * A + A + a_off + i] = red[kWideDChunk * AS + AS + i];
+        }
+}
+
 constexpr int kSemBwdBlocks = 256;   // one 4-wave block per CU (104 KB of LDS at A = 128)
 
 template <int CA>
@@ -1538,6 +1796,33 @@ int launch_bwd_gen(const float *M, const float *w, const float *b, const float *
     return 0;
 }
 
+template <int CA>
+int launch_fwd_wide(const float *M, const float *w, const float *b, const float *u, float *Z, float *beta,
+                    int64_t N, int P, int D, int A, hipStream_t st) {
+    const int grid = han_grid_for(N, ROWS / P, 256 * 4);
+    sem_attn_fwd_wide_kernel<CA><<<grid, 256, 0, st>>>(M, w, b, u, Z, beta, N, P, D, A);
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_bwd_wide(const float *M, const float *w, const float *b, const float *u, const float *beta,
+                    const float *dZ, float *dM, float *slab, int64_t N, int P, int D, int A, int *grid_out,
+                    hipStream_t st) {
+    const size_t lds = (size_t)(kWideDChunk * 64 + 2 * 64) * sizeof(float);
+    const int grid = han_grid_for(N > 0 ? N : 1, ROWS / P, kSemBwdBlocks);
+    *grid_out = grid;
+    for (int a_off = 0; a_off < A; a_off += 64)          // same grid every pass: a block's slab row fills up piece by piece
+        for (int d_off = 0; d_off < D; d_off += kWideDChunk) {
+            sem_attn_bwd_wide_kernel<<<grid, 256, lds, st>>>(M, w, b, u, beta, dZ, dM, slab, N, P, D, A, a_off, d_off);
+            HAN_CHECK_LAUNCH();
+        }
+    return 0;
+}
+
+// shapes of the tuned kernels; everything else (multiples of 64) goes to the run-time-width kernels
+bool k3_tuned(int D, int A) { return (D == 64 || D == 128) && A >= 64 && A <= 256; }
+bool k3_shape_ok(int P, int D, int A) { return P >= 1 && P <= 64 && D >= 64 && D % 64 == 0 && A >= 64 && A % 64 == 0; }
+
 }  // namespace
 
 extern "C" int han_sem_attn_fwd(const float *M, const float *w_omega, const float *b_omega,
@@ -1545,9 +1830,14 @@ extern "C" int han_sem_attn_fwd(const float *M, const float *w_omega, const floa
                                 int flags, void *stream) {
     if (N == 0) return 0;   // nothing to do; row pointers of empty tensors may be null
     if (!M || !w_omega || !b_omega || !u_omega || !Z || !beta || N < 0 || P <= 0) return HAN_E_BADARG;
-    if ((D != 64 && D != 128) || P > 64 || A < 64 || A > 256 || A % 64 != 0) return HAN_E_UNSUPPORTED;
-    if (N == 0) return 0;
+    if (!k3_shape_ok(P, D, A)) return HAN_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    if (!k3_tuned(D, A)) {      // any wider embedding / attention space
+        if (A % 256 == 0) return launch_fwd_wide<4>(M, w_omega, b_omega, u_omega, Z, beta, N, P, D, A, st);
+        if (A % 192 == 0) return launch_fwd_wide<3>(M, w_omega, b_omega, u_omega, Z, beta, N, P, D, A, st);
+        if (A % 128 == 0) return launch_fwd_wide<2>(M, w_omega, b_omega, u_omega, Z, beta, N, P, D, A, st);
+        return launch_fwd_wide<1>(M, w_omega, b_omega, u_omega, Z, beta, N, P, D, A, st);
+    }
     // attention spaces of 192 / 256 columns (round 3) and 128-wide embeddings: the width-templated block-level kernels
     if (D == 128 || A > 128) {
         if (D == 128) {
@@ -1577,13 +1867,14 @@ extern "C" int han_sem_attn_bwd(const float *M, const float *w_omega, const floa
     if (!M || !w_omega || !b_omega || !u_omega || !beta || !dZ || !dM || !dw_omega || !db_omega || !du_omega ||
         !workspace || N < 0 || P <= 0)
         return HAN_E_BADARG;
-    if ((D != 64 && D != 128) || P > 64 || A < 64 || A > 256 || A % 64 != 0) return HAN_E_UNSUPPORTED;
+    if (!k3_shape_ok(P, D, A)) return HAN_E_UNSUPPORTED;
     if (workspace_bytes < han_sem_attn_bwd_workspace(N, P, D, A)) return HAN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *slab = (float *)workspace;
     int grid = 0;
     int rc;
-    if (D == 128) rc = launch_bwd_gen<8>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, A, &grid, st);
+    if (!k3_tuned(D, A)) rc = launch_bwd_wide(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, D, A, &grid, st);
+    else if (D == 128) rc = launch_bwd_gen<8>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, A, &grid, st);
     else if (A > 128) rc = launch_bwd_gen<4>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, A, &grid, st);
     else rc = (A == 64)
                  ? launch_bwd<1>(M, w_omega, b_omega, u_omega, beta, dZ, dM, slab, N, P, &grid, flags, st)

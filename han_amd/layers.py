@@ -398,36 +398,32 @@ class ClassifierLoss(torch.autograd.Function):
 
 
 class _ClassifierForward(torch.autograd.Function):
-    """logits = (1/HC) sum_h (Z Wc[h] + bc[h]) (models/gat.py:65-72) by the HIP
-    kernel; the (tiny, N x C) backward uses torch matmuls."""
+    """logits = (1/HC) sum_h (Z Wc[h] + bc[h]) (models/gat.py:65-72) by the HIP kernels, forward and backward
+    (han_classifier_loss with an empty mask; han_classifier_bwd for a caller-supplied dlogits)."""
 
     @staticmethod
     def forward(ctx, Z, Wc, bc):
         N = Z.shape[0]
         labels = torch.zeros(N, dtype=torch.int32, device=Z.device)
         mask = torch.zeros(N, dtype=torch.uint8, device=Z.device)
-        logits, _, _ = ops.classifier_loss(Z.contiguous(), Wc, bc, labels, mask, 0.0, backward=False)
-        ctx.save_for_backward(Z, Wc)
+        Z = Z.contiguous()
+        logits, _, _ = ops.classifier_loss(Z, Wc, bc, labels, mask, 0.0, backward=False)
+        ctx.save_for_backward(Z, Wc, bc)
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
-        Z, Wc = ctx.saved_tensors
-        HC = Wc.shape[0]
-        Wm = Wc.mean(0)
-        dZ = dlogits @ Wm.t()
-        dWc = (Z.t() @ dlogits / HC).unsqueeze(0).expand(HC, -1, -1).contiguous()
-        dbc = (dlogits.sum(0) / HC).unsqueeze(0).expand(HC, -1).contiguous()
-        return dZ, dWc, dbc
+        Z, Wc, bc = ctx.saved_tensors
+        return ops.classifier_bwd(Z, Wc, bc, dlogits.contiguous())
 
 
 def classifier(Z, Wc, bc):
     return _ClassifierForward.apply(Z, Wc, bc)
 
 
-K3_WIDTHS = (64, 128)      # embedding widths the K3 / classifier kernels are built for
-K3_MAX_ATT = 256           # attention sizes: multiples of 64 up to 256 (round 3; above 128 through the width-templated kernels)
-MAX_CLASSES = 64           # classes the classifier kernels take
+K3_WIDTHS = (64, 128)      # embedding widths the TUNED K3 / classifier kernels are built for
+K3_MAX_ATT = 256           # attention sizes of the tuned K3 kernels: multiples of 64 up to 256
+MAX_CLASSES = 64           # classes of the fused single-launch classifier kernels (more: the three-kernel path)
 
 
 def _pad_to(n: int) -> int:
@@ -435,17 +431,12 @@ def _pad_to(n: int) -> int:
 
 
 def semantic_attention(M, w_omega, b_omega, u_omega):
-    """utils/layers.py:152-159 for any embedding width D and attention size A <= 128.
-    D, A in {64, 128}: the K3 kernels as they are.  Narrower: zero-padded -- padded columns of
-    w_omega / u_omega contribute tanh(.) * 0 = 0 to the scores and padded embedding columns are 0 --
-    which is exact.  D > 128 (a last layer wider than the kernels, e.g. 8 heads x 32) or A > 128: the
-    same arithmetic through torch on the GPU (library GEMM + elementwise, autograd); off the tuned path."""
+    """utils/layers.py:152-159 for any embedding width D and attention size A, always on the K3 kernels.
+    Widths that are not multiples of 64 are zero-padded -- padded columns of w_omega / u_omega contribute
+    tanh(.) * 0 = 0 to the scores and padded embedding columns are 0 -- which is exact.  D in {64, 128} with
+    A <= 256 run the tuned kernels; anything wider (a last layer of 8 heads x 32, hid_units = [128],
+    mp_att_size = 512, ...) the run-time-width kernels of sem_attn.hip (round 3: no torch branch is left)."""
     d, a = M.shape[2], w_omega.shape[1]
-    if d > K3_WIDTHS[-1] or a > K3_MAX_ATT:
-        ops.require_gpu(M, "inputs")
-        v = torch.tanh(torch.matmul(M, w_omega) + b_omega)
-        att = torch.softmax(torch.matmul(v, u_omega), dim=1)
-        return (M * att.unsqueeze(-1)).sum(1), att
     dm, am = _pad_to(d), _pad_to(a)
     if dm == d and am == a:
         return SemanticAttention.apply(M.contiguous(), w_omega, b_omega, u_omega)
@@ -455,17 +446,10 @@ def semantic_attention(M, w_omega, b_omega, u_omega):
     return Z[:, :d], att
 
 
-def _wide_logits(Z, Wc, bc):
-    ops.require_gpu(Z, "Z")
-    return torch.matmul(Z, Wc.mean(0)) + bc.mean(0)          # (1/HC) sum_h (Z Wc[h] + bc[h]), models/gat.py:65-72
-
-
 def classifier_any(Z, Wc, bc):
-    """models/gat.py:65-72 for any embedding width: the kernel (zero-padded to 64 / 128 columns) or,
-    above 128, torch on the GPU."""
+    """models/gat.py:65-72 for any embedding width and class count: always the HIP kernels (widths that are not
+    multiples of 64 are zero-padded, which is exact)."""
     d = Z.shape[1]
-    if d > K3_WIDTHS[-1] or Wc.shape[2] > MAX_CLASSES:
-        return _wide_logits(Z, Wc, bc)
     dm = _pad_to(d)
     if dm != d:
         Z, Wc = torch.nn.functional.pad(Z, (0, dm - d)), torch.nn.functional.pad(Wc, (0, 0, 0, dm - d))
@@ -474,15 +458,8 @@ def classifier_any(Z, Wc, bc):
 
 def classifier_loss_any(Z, Wc, bc, labels, mask, weight):
     """Classifier + masked softmax cross-entropy + accuracy (models/base_gattn.py:41-48,61-69) for any
-    embedding width; returns (loss, accuracy, logits)."""
+    embedding width / class count; returns (loss, accuracy, logits)."""
     d = Z.shape[1]
-    if d > K3_WIDTHS[-1] or Wc.shape[2] > MAX_CLASSES:
-        logits = _wide_logits(Z, Wc, bc)
-        m = mask.to(logits.dtype)
-        ce = torch.nn.functional.cross_entropy(logits, labels.long(), reduction="none")
-        loss = (ce * m).sum() * weight
-        acc = ((logits.argmax(1) == labels.long()).to(logits.dtype) * m).sum() * weight
-        return loss, acc.detach(), logits.detach()
     dm = _pad_to(d)
     if dm != d:
         Z, Wc = torch.nn.functional.pad(Z, (0, dm - d)), torch.nn.functional.pad(Wc, (0, 0, 0, dm - d))

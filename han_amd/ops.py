@@ -516,8 +516,8 @@ def sem_attn_fwd(M, w_omega, b_omega, u_omega, flags=0):
     """utils/layers.py:152-159.  M (N,P,D) -> Z (N,D), beta (N,P)."""
     lib = _lib.load()
     _chk(M, "M")
-    if M.dim() != 3 or M.shape[2] not in (64, 128):
-        raise ValueError(f"M: expected (N,P,64) or (N,P,128), got {tuple(M.shape)}")
+    if M.dim() != 3 or M.shape[2] % 64 != 0 or M.shape[2] == 0:
+        raise ValueError(f"M: expected (N,P,D) with D a multiple of 64, got {tuple(M.shape)}")
     N, P, Dm = M.shape
     A = w_omega.shape[1]
     dev = M.device
@@ -565,8 +565,8 @@ def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False, grad_ou
     N = Z.shape[0]
     dev = Z.device
     HC, Dm, C = Wc.shape
-    if Dm not in (64, 128):
-        raise ValueError(f"Wc: the embedding width must be 64 or 128 (zero-pad it), got {Dm}")
+    if Dm % 64 != 0 or Dm == 0:
+        raise ValueError(f"Wc: the embedding width must be a multiple of 64 (zero-pad it), got {Dm}")
     _chk(Z, "Z", (N, Dm))
     _chk(Wc, "Wc", (HC, Dm, C), device=dev)
     _chk(bc, "bc", (HC, C), device=dev)
@@ -589,6 +589,28 @@ def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False, grad_ou
         float(row_weight), logits.data_ptr(), loss_acc.data_ptr(), ptrs[0], ptrs[1], ptrs[2],
         ws.data_ptr(), ws.numel(), N, Dm, C, HC, _stream()), "han_classifier_loss")
     return logits, loss_acc, grads
+
+
+def classifier_bwd(Z, Wc, bc, dlogits):
+    """Backward of logits = (1/HC) sum_h (Z Wc[h] + bc[h]) (models/gat.py:65-72) for a given dlogits (N,C):
+    returns (dZ, dWc, dbc)."""
+    lib = _lib.load()
+    _chk(Z, "Z")
+    N, dev = Z.shape[0], Z.device
+    HC, Dm, C = Wc.shape
+    if Dm % 64 != 0 or Dm == 0:
+        raise ValueError(f"Wc: the embedding width must be a multiple of 64 (zero-pad it), got {Dm}")
+    _chk(Z, "Z", (N, Dm))
+    _chk(Wc, "Wc", (HC, Dm, C), device=dev)
+    _chk(bc, "bc", (HC, C), device=dev)
+    _chk(dlogits, "dlogits", (N, C), device=dev)
+    dZ = torch.empty((N, Dm), dtype=torch.float32, device=dev)
+    dWc, dbc = torch.empty_like(Wc), torch.empty_like(bc)
+    ws = _ws(lib.han_classifier_bwd_workspace(N, Dm, C, HC), dev, "clsb")
+    _lib.check(lib.han_classifier_bwd(Z.data_ptr(), Wc.data_ptr(), bc.data_ptr(), dlogits.data_ptr(), dZ.data_ptr(),
+                                      dWc.data_ptr(), dbc.data_ptr(), ws.data_ptr(), ws.numel(), N, Dm, C, HC,
+                                      _stream()), "han_classifier_bwd")
+    return dZ, dWc, dbc
 
 
 # ------------------------------------------------------------------- optimiser

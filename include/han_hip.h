@@ -246,7 +246,10 @@ int han_score_param_bwd(const void *H, int table_dtype, const float *df1, const 
 /* ---- K3: semantic-level (meta-path) attention ------------------------------
  * utils/layers.py:152-159: v = tanh(M Womega + bomega); s = v . uomega;
  * beta = softmax over P PER NODE; Z = sum_p beta_p M_p.
- * M (N,P,D); Womega (D,A); bomega,uomega (A); Z (N,D); beta (N,P).          */
+ * M (N,P,D); Womega (D,A); bomega,uomega (A); Z (N,D); beta (N,P).
+ * D and A: any multiples of 64 (zero-pad narrower ones: exact).  D in {64,128} with
+ * A <= 256 run the tuned kernels, anything wider the run-time-width kernels
+ * (models/gat.py:42-61 leaves the last layer's width and mp_att_size free).   */
 int han_sem_attn_fwd(const float *M, const float *w_omega, const float *b_omega,
                      const float *u_omega, float *Z, float *beta, int64_t N, int P,
                      int D, int A, int flags, void *stream);
@@ -266,13 +269,24 @@ int han_sem_attn_bwd(const float *M, const float *w_omega, const float *b_omega,
  *   loss_acc[0] = sum_i w_i CE_i,  loss_acc[1] = sum_i w_i [argmax == label]
  * labels are class ids (int32, argmax of the one-hot rows); mask uint8.
  * If dZ != NULL also writes dlogits (N,C) = w_i (softmax - onehot) and
- * dZ = dlogits @ mean_h(Wc[h])^T, dWc (HC,D,C), dbc (HC,C).                 */
+ * dZ = dlogits @ mean_h(Wc[h])^T, dWc (HC,D,C), dbc (HC,C).
+ * D: any multiple of 64; C: any class count (D in {64,128} with C <= 64: the fused
+ * single-launch kernels; otherwise head average -> row kernel -> Z^T dlogits over
+ * the masked rows).                                                          */
 size_t han_classifier_workspace(int64_t N, int D, int C, int HC);
 int han_classifier_loss(const float *Z, const float *Wc, const float *bc,
                         const int32_t *labels, const uint8_t *mask, float row_weight,
                         float *logits, float *loss_acc, float *dZ, float *dWc, float *dbc,
                         void *workspace, size_t workspace_bytes, int64_t N, int D, int C,
                         int HC, void *stream);
+
+/* The backward of the logits alone (HeteGAT_multi.inference returns logits; a caller
+ * that forms its own loss hands back dlogits (N,C)):  dZ = dlogits @ mean_h(Wc[h])^T,
+ * dWc[h] = Z^T dlogits / HC, dbc[h] = sum_n dlogits / HC.  Same shape rules.      */
+size_t han_classifier_bwd_workspace(int64_t N, int D, int C, int HC);
+int han_classifier_bwd(const float *Z, const float *Wc, const float *bc, const float *dlogits,
+                       float *dZ, float *dWc, float *dbc, void *workspace,
+                       size_t workspace_bytes, int64_t N, int D, int C, int HC, void *stream);
 
 /* ---- optimiser --------------------------------------------------------------
  * models/base_gattn.py:12-24: L2 on every trainable + tf.train.AdamOptimizer:

@@ -286,6 +286,15 @@ def classifier_loss(Z, Wc, bc, labels, mask, row_weight, backward=False, grad_ou
     return logits.detach().to(torch.float32), la, grads
 
 
+def classifier_bwd(Z, Wc, bc, dlogits):
+    z, w, dl = _f64(Z), _f64(Wc), _f64(dlogits)
+    hc = w.shape[0]
+    dZ = dl @ w.mean(0).t()
+    dWc = (z.t() @ dl / hc)[None].expand(hc, -1, -1).contiguous()
+    dbc = (dl.sum(0) / hc)[None].expand(hc, -1).contiguous()
+    return dZ.to(torch.float32), dWc.to(torch.float32), dbc.to(torch.float32)
+
+
 def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, l2_coef=0.0, step_dev=None):
     if step_dev is not None:
         t = int(step_dev.item())
@@ -306,7 +315,7 @@ def require_gpu(t, name):
 
 _NAMES = ("require_gpu", "project_fwd", "project_fwd_multi", "keep_bytes", "project_bwd", "project_bwd_input", "node_attn_fwd", "node_attn_bwd_rows", "node_attn_bwd_cols",
           "gs_row_bytes", "gs_views",
-          "score_param_bwd", "sem_attn_fwd", "sem_attn_bwd", "classifier_loss", "adam_step",
+          "score_param_bwd", "sem_attn_fwd", "sem_attn_bwd", "classifier_loss", "classifier_bwd", "adam_step",
           "l2_half_sumsq")
 
 

@@ -606,7 +606,12 @@ def test_other_head_shapes_match_oracle(dev, K, FP, A, drop, monkeypatch):
                                      # round 3: attention spaces of 192 / 256 columns (mp_att_size up to 256) on the
                                      # width-templated kernels, 64- and 128-wide embeddings
                                      (333, 2, 256, 64), (1000, 4, 192, 64), (77, 5, 256, 128), (2000, 8, 192, 128),
-                                     (70000, 4, 256, 64), (1, 1, 256, 128)])
+                                     (70000, 4, 256, 64), (1, 1, 256, 128),
+                                     # round 3: ANY embedding width / attention size (multiples of 64) on the
+                                     # run-time-width kernels: 8 x 32 last layers (D = 256), hid_units = [128] x 8 heads
+                                     # (D = 1024), mp_att_size = 320 / 512; dW chunks of 128 columns incl. a short one
+                                     (300, 3, 128, 256), (257, 4, 320, 192), (100, 2, 512, 1024), (70, 5, 64, 320),
+                                     (1, 1, 128, 256), (3000, 4, 256, 256), (129, 64, 64, 192), (50, 2, 320, 64)])
 def test_semantic_attention_fwd_bwd(dev, n, p, a, d):
     from han_amd import ops
     rng = np.random.default_rng(n + p)
@@ -654,7 +659,12 @@ def test_empty_inputs_are_noops(dev):
                                       (5, 3, 1, 128), (257, 4, 2, 128), (300, 8, 1, 128), (64, 16, 1, 128),
                                       # more than 16 classes: the class-per-lane kernel
                                       (5, 17, 1, 64), (300, 40, 1, 64), (1000, 64, 2, 64), (257, 64, 2, 128),
-                                      (130, 33, 1, 128)])
+                                      (130, 33, 1, 128),
+                                      # round 3: any embedding width / class count (head average -> row kernel ->
+                                      # Z^T dlogits over the masked rows): 8 x 32 last layers, hid_units = [128],
+                                      # widths beyond the register-held row (D = 2048), > 64 classes
+                                      (300, 3, 1, 256), (257, 7, 2, 192), (100, 100, 1, 64), (130, 65, 2, 128),
+                                      (70, 5, 1, 1024), (40, 3, 1, 2048), (1, 1, 1, 256), (1500, 200, 1, 320)])
 def test_classifier_loss_matches_oracle(dev, n, c, hc, d):
     from han_amd import ops
     rng = np.random.default_rng(n + c)
@@ -680,6 +690,18 @@ def test_classifier_loss_matches_oracle(dev, n, c, hc, d):
     assert abs(float(la[0]) - float(loss_t)) < 1e-4
     assert abs(float(la[1]) - float(acc_t)) < 1e-5
     dZ, dWc, dbc = grads
+    assert rel_err(dZ.cpu().numpy(), tZ.grad.numpy()) < GTOL
+    assert rel_err(dWc.cpu().numpy(), tW.grad.numpy()) < GTOL
+    assert rel_err(dbc.cpu().numpy(), tb.grad.numpy()) < GTOL
+    # the forward-only launch and the backward of the logits alone (han_classifier_bwd) for a caller-supplied dlogits
+    logits2, la2, none = ops.classifier_loss(_t(Z, dev), _t(Wc, dev), _t(bc, dev), _t(labels, dev, torch.int32),
+                                             _t(mask.astype(np.uint8), dev, torch.uint8), 1.0 / mask.sum())
+    assert none is None and torch.equal(logits2, logits) and abs(float(la2[0]) - float(la[0])) < 1e-6
+    dl = rng.standard_normal((n, c))
+    tZ.grad = tW.grad = tb.grad = None
+    logits_u = sum(tZ @ tW[i] + tb[i] for i in range(hc)) / hc
+    (logits_u * torch.tensor(dl)).sum().backward()
+    dZ, dWc, dbc = ops.classifier_bwd(_t(Z, dev), _t(Wc, dev), _t(bc, dev), _t(dl, dev))
     assert rel_err(dZ.cpu().numpy(), tZ.grad.numpy()) < GTOL
     assert rel_err(dWc.cpu().numpy(), tW.grad.numpy()) < GTOL
     assert rel_err(dbc.cpu().numpy(), tb.grad.numpy()) < GTOL
