@@ -69,6 +69,7 @@ struct FwdArgs {
     const int32_t *gid;   // global id of each table row (halo tables), or null: the index is the id
     int lsb_mask;   // training with fts dropout: the lowest mantissa bit of every H element is its keep bit
     const float *f1;
+    const float *f2g;   // F' = 64 only: gathered neighbour scores (slices of a wide head), or null: recomputed from the row
     const float *a2;
     const float *b2;
     const float *c;
@@ -181,7 +182,9 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         // layers.py:24,26; sp_attn_head: adj_ij*f1_i + adj_ij*f2_j (:95-96), w == 1 when binary
-        float x = f1h + (head_sum<FP>(dot4(hv[u], a24)) + b2h);
+        float x;
+        if (FP == HAN_D && !FAST && a.f2g) x = f1h + a.f2g[j[u]];      // one head of 64 columns: K = 1, index = row
+        else x = f1h + (head_sum<FP>(dot4(hv[u], a24)) + b2h);
         if (VAL) x *= w[u];
         sg[u] = x > 0.f ? 1.f : a.slope;
         if (VAL) sg[u] *= w[u];
@@ -1025,7 +1028,7 @@ template <int FPC, bool BF, bool VAL>
 static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split, hipStream_t st) {
     // FAST: the training configuration every shipped script uses (both dropouts on, table
     // index == global id) gets an edge loop without uniform branches
-    const bool fast = train && a.thr_coef < HAN_KEEP_ALL && a.lsb_mask && !a.gid;
+    const bool fast = train && a.thr_coef < HAN_KEEP_ALL && a.lsb_mask && !a.gid && !a.f2g;
     if (low) {
         const int grid = attn_grid((a.N + 3) / 4);
         if (train) node_attn_fwd_kernel<FPC, true, 4, 2, BF, VAL, false, false><<<grid, 256, 0, st>>>(a);
@@ -1086,7 +1089,8 @@ static bool dtype_ok(int dt, int FP) {
 
 extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float *edge_val,
                                  const void *H, int table_dtype,
-                                 const int32_t *table_gid, const float *f1, const float *a2, const float *b2,
+                                 const int32_t *table_gid, const float *f1, const float *f2_src, const float *a2,
+                                 const float *b2,
                                  const float *c, const float *res, float *out, int64_t out_stride, float *pre,
                                  float *lse,
                                  float *aggp, float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
@@ -1098,13 +1102,14 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
         return HAN_E_BADARG;
     if (!split_ok(split)) return HAN_E_BADARG;
     if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
+    if (f2_src && FP != HAN_D) return HAN_E_UNSUPPORTED;
     const bool train = pre || lse || aggp || tsum;
     if (train && !(pre && lse && aggp && tsum)) return HAN_E_BADARG;
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
     if ((coef_drop > 0.f || fts_drop > 0.f) && !train) return HAN_E_BADARG;
     if (N == 0) return 0;
     FwdArgs a;
-    a.rowptr = rowptr; a.colidx = colidx; a.edge_val = edge_val; a.H = H; a.gid = table_gid; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.a2 = a2; a.b2 = b2; a.c = c; a.res = res;
+    a.rowptr = rowptr; a.colidx = colidx; a.edge_val = edge_val; a.H = H; a.gid = table_gid; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.f2g = f2_src; a.a2 = a2; a.b2 = b2; a.c = c; a.res = res;
     a.out = out; a.out_stride = out_stride; a.pre = pre; a.lse = lse; a.aggp = aggp; a.tsum = tsum;
     a.N = N; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;

@@ -32,6 +32,7 @@ struct ProjFwdArgs {
     int64_t N;
     int F;
     uint32_t seed_lo, seed_hi, thr_in, thr_fts;   // thr_fts < 2^16: stamp keep bits into H
+    uint32_t fts_stream;                          // HAN_STREAM_FTS + 4 * slice (HAN_FLAG_FTS_SLICE: slices of a wide head)
     const uint64_t *seed_dev;
     float inv_keep_in;
     int64_t row_offset;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const ProjFwdArgs a_in
                     // projected-row dropout (layers.py:31-32): the keep bit rides in the lowest
                     // mantissa bit of the STORED element (fp32 bit 0 / bf16 bit 0)
                     const int d = 16 * t + l15;
-                    const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_FTS,
+                    const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, a.fts_stream,
                                                     (uint32_t)(row + a.row_offset), (uint32_t)(d >> 2));
                     keepbit = rn.field(d & 3) < a.thr_fts ? 1u : 0u;
                     stamp = 1;
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
                 uint32_t keepbit = 0, stamp = 0;
                 if (a.thr_fts < HAN_KEEP_ALL) {
                     const int d = 16 * t + l15;
-                    const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_FTS,
+                    const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, a.fts_stream,
                                                     (uint32_t)(row + a.row_offset), (uint32_t)(d >> 2));
                     keepbit = rn.field(d & 3) < a.thr_fts ? 1u : 0u;
                     stamp = 1;
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(256) void project_finish_kernel(const ProjFwdArgs a
         }
         HanRand64 rn = {0u, 0u};
         if (a.thr_fts < HAN_KEEP_ALL)      // layers.py:31-32, d = 4q + e -> counter d/4 = q, field e
-            rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_FTS, (uint32_t)(row + a.row_offset), (uint32_t)q);
+            rn = han_rand64(a.seed_lo, a.seed_hi, a.fts_stream, (uint32_t)(row + a.row_offset), (uint32_t)q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t keepbit = rn.field(e) < a.thr_fts ? 1u : 0u;
@@ -1398,6 +1399,7 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_in = in_drop > 0.f ? han_keep_threshold(1.f - in_drop) : HAN_KEEP_ALL;
     a.thr_fts = fts_drop > 0.f ? han_keep_threshold(1.f - fts_drop) : HAN_KEEP_ALL;
+    a.fts_stream = HAN_STREAM_FTS + 4u * (uint32_t)HAN_FLAG_FTS_SLICE_OF(flags);
     a.inv_keep_in = 1.f / (1.f - in_drop);
     a.row_offset = row_offset;
     a.keep = in_drop > 0.f ? keep : nullptr;

@@ -45,11 +45,12 @@ FP_SIZES = (4, 8, 16, 32, 64)
 
 def _kernel_head_width(FP: int) -> int:
     """The lane-mapped head width the K1/K2 kernels run a head of width FP at: the next of 4, 8, 16, 32, 64
-    (the extra columns carry zero weights: their scores terms and outputs are exactly 0 and are cut off)."""
+    (the extra columns carry zero weights: their scores terms and outputs are exactly 0 and are cut off).
+    Heads wider than 64 columns run as column slices of 64 (layers.WideHeadAttention)."""
     for w in FP_SIZES:
         if FP <= w:
             return w
-    raise NotImplementedError(f"hid_units entries above {FP_SIZES[-1]} (got {FP})")
+    return GROUP
 
 
 def _head_groups(K: int, FP: int):
@@ -126,8 +127,9 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
             # any number of heads; head widths are the lane-mapped sizes of the K2 kernels; a layer's
             # concatenated width K*F' is served in 64-column head groups (K1/K2) and, for the last
             # layer, zero-padded to 64 or 128 columns for K3 / the classifier
-            if not (1 <= FPi <= FP_SIZES[-1]) or Ki < 1:
-                raise NotImplementedError(f"hid_units entries must be in [1, {FP_SIZES[-1]}] (got {FPi}) with n_heads >= 1")
+            # -- or, for a head wider than 64 columns, in 64-column slices of one head (layers.WideHeadAttention)
+            if FPi < 1 or Ki < 1:
+                raise ValueError(f"hid_units entries and n_heads must be positive (got {FPi}, {Ki})")
         if mp_att_size < 1 or nb_classes < 1:
             raise ValueError("mp_att_size and nb_classes must be positive")
         dev = torch.device(device) if device is not None else (self._device or torch.device("cuda:0"))
@@ -287,6 +289,25 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
             g = lambda n: getattr(self, n + sfx, None)
             W, a1, b1, a2, b2, c, Wr, br = (g(n) for n in ("W", "a1", "b1", "a2", "b2", "c", "Wr", "br"))
             sd = seeds(layer)
+            if FP > GROUP:       # heads wider than a K1 / K2 row: one head at a time, S = ceil(F'/64) column slices
+                S = -(-FP // GROUP)
+                outs, coef_acc = [], None
+                for k in range(K):
+                    cols = slice(k * FP, (k + 1) * FP)
+                    pw = lambda t: F_torch.pad(t[..., cols], (0, S * GROUP - FP)).contiguous()
+                    pa = lambda t: F_torch.pad(t[:, k], (0, S * GROUP - FP)).contiguous()
+                    gsink = [] if sink is not None else None
+                    Mk = layers.WideHeadAttention.apply(
+                        Xin, pw(W), pa(a1), b1[:, k].contiguous(), pa(a2), b2[:, k].contiguous(), pw(c),
+                        pw(Wr) if Wr is not None else None, pw(br) if br is not None else None, xs_, tuple(graphs),
+                        cfg(layer, tuple((s_ + k) & ((1 << 64) - 1) for s_ in sd), coef_sink=gsink, coef_mean=True,
+                            group=k))
+                    outs.append(Mk[:, :, :FP])
+                    if sink is not None:      # (E,) per meta-path and head
+                        coef_acc = gsink if coef_acc is None else [x + y for x, y in zip(coef_acc, gsink)]
+                if sink is not None:
+                    sink.extend(v / K for v in coef_acc)
+                return torch.cat(outs, dim=2) if len(outs) > 1 else outs[0].contiguous()
             groups = _head_groups(K, FP)
             if len(groups) == 1 and K * FP == GROUP:      # the reference shapes: no slicing, direct gradients
                 return layers.NodeLevelAttention.apply(Xin, W, a1, b1, a2, b2, c, Wr, br, xs_, tuple(graphs),

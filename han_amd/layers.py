@@ -337,6 +337,150 @@ class NodeLevelAttention(torch.autograd.Function):
         return dXin, dW, da1, db1, da2, db2, dc, dWr, dbr, None, None, None
 
 
+class WideHeadAttention(torch.autograd.Function):
+    """K1 + K2 for ONE head wider than the 64 columns of a K1 / K2 row (hid_units > 64; models/gat.py:42-57 leaves
+    the width free), every meta-path: the head runs as S = ceil(F'/64) column slices, each a K = 1, F' = 64 launch.
+
+    What the slices of a head share is what makes them one head: the scores f1 / f2 (each slice's K1 epilogue gives
+    its partial dot product, b1 / b2 ride in slice 0, the partials are added and K2 GATHERS f2 -- han_node_attn_fwd
+    f2_src -- instead of recomputing it from its 64 columns), hence the coefficients, and the dropout draws keyed by
+    the head: the per-head input dropout and the attention dropout (same seed, head index 0 in every slice).  The
+    projected-row dropout is per column: slice s draws from its own stream (HAN_FLAG_FTS_SLICE).  The backward is the
+    backward of the slices -- the softmax backward is linear in d alpha, so the slices' df1 / df2 add up -- with the
+    totals in the places that need them (df1 into the transposed-graph pass, df2 into dH and the score gradients).
+
+    forward(Xin, W (P,F,S*64), a1 (P,S*64), b1 (P,), a2 (P,S*64), b2 (P,), c (P,S*64), Wr, br, xs, graphs, cfg) -> M (N,P,S*64);
+    columns beyond F' carry zero weights (their outputs are exactly act(0 + 0) and are cut off by the caller).
+    cfg as for NodeLevelAttention; single GPU (a node partition would also have to exchange f2)."""
+
+    @staticmethod
+    def forward(ctx, Xin, W, a1, b1, a2, b2, c, Wr, br, xs, graphs, cfg):
+        P = len(graphs)
+        if Xin is not None:
+            Xin = Xin.contiguous()
+            xs = tuple(Xin[:, p, :] for p in range(P))
+        part = cfg.get("part")
+        if part is not None and part.active:
+            raise NotImplementedError("heads wider than 64 columns under a node partition (the slices' f2 totals would "
+                                      "have to be exchanged as well)")
+        S = W.shape[2] // D
+        train = bool(cfg["train"])
+        in_drop = float(cfg.get("in_drop", 0.0)) if train else 0.0
+        coef_drop = float(cfg.get("coef_drop", 0.0)) if train else 0.0
+        N, dev = xs[0].shape[0], W.device
+        M = torch.empty((N, P, S * D), dtype=torch.float32, device=dev)
+        seed_dev = cfg.get("seed_dev")
+        tdt = cfg.get("table_dtype", torch.float32)
+        zero1 = torch.zeros(1, dtype=torch.float32, device=dev)
+        saved = []
+        for p in range(P):
+            seed = int(cfg["seeds"][p])
+            Ws = W[p].view(-1, S, D).permute(1, 0, 2).contiguous()          # (S,F,64)
+            a1s, a2s, cs = a1[p].view(S, 1, D), a2[p].view(S, 1, D), c[p].view(S, D)
+            Hs, f1, f2, Rs = [], None, None, []
+            for s_ in range(S):
+                fl = ops.flag_fts_slice(s_)
+                H, f1s, f2s = ops.project_fwd(xs[p], Ws[s_], a1s[s_], a2s[s_], b1[p:p + 1] if s_ == 0 else zero1,
+                                              b2[p:p + 1] if s_ == 0 else zero1, in_drop=in_drop, fts_drop=in_drop,
+                                              seed=seed, table_dtype=tdt, seed_dev=seed_dev, flags=fl)
+                Hs.append(H)
+                f1 = f1s if f1 is None else f1 + f1s
+                f2 = f2s if f2 is None else f2 + f2s
+                R = None
+                if Wr is not None:      # residual conv1d(seq, F', 1) of the DROPPED input (layers.py:38-40): same draws
+                    Wrs = Wr[p].view(-1, S, D)[:, s_, :].contiguous()
+                    R, _, _ = ops.project_fwd(xs[p], Wrs, a1s[s_], a2s[s_], zero1, zero1, in_drop=in_drop, fts_drop=0.0,
+                                              seed=seed, seed_dev=seed_dev)
+                    R = R + br[p].view(S, D)[s_]
+                Rs.append(R)
+            if cfg.get("coef_sink") is not None:
+                cfg["coef_sink"].append(ops.node_attn_coefs(graphs[p], f1, f2, coef_drop=coef_drop, seed=seed,
+                                                            mean_heads=bool(cfg.get("coef_mean", False)),
+                                                            seed_dev=seed_dev))
+            per_s = []
+            for s_ in range(S):
+                _, sv = ops.node_attn_fwd(graphs[p], Hs[s_], f1, a2s[s_], b2[p:p + 1], cs[s_],
+                                          out=M[:, p, s_ * D:(s_ + 1) * D], train=train, coef_drop=coef_drop,
+                                          fts_drop=in_drop, seed=seed, activation=cfg["act"], res=Rs[s_],
+                                          seed_dev=seed_dev, f2_src=f2)
+                if train:
+                    per_s.append((Hs[s_],) + sv + (Rs[s_],))
+            if train:
+                saved.append((f1, f2, per_s))
+        ctx.cfg, ctx.xs, ctx.graphs, ctx.S = cfg, xs, graphs, S
+        ctx.xin_shape = tuple(Xin.shape) if Xin is not None else None
+        ctx.saved_per_p = saved
+        ctx.in_drop, ctx.coef_drop = in_drop, coef_drop
+        ctx.has_res = Wr is not None
+        ctx.save_for_backward(W, a1, a2, c, *((Wr,) if Wr is not None else ()))
+        return M
+
+    @staticmethod
+    def backward(ctx, dM):
+        W, a1, a2, c = ctx.saved_tensors[:4]
+        Wr = ctx.saved_tensors[4] if ctx.has_res else None
+        cfg, xs, graphs, S = ctx.cfg, ctx.xs, ctx.graphs, ctx.S
+        if not cfg["train"]:
+            raise RuntimeError("WideHeadAttention was run with train=False; no backward state")
+        P, dev = len(graphs), W.device
+        Fw = W.shape[1]
+        dM = dM.contiguous()
+        graphs_t = cfg.get("graphs_t") or tuple(g.transpose() for g in graphs)
+        seed_dev = cfg.get("seed_dev")
+        dW = torch.empty((P, S, Fw, D), dtype=torch.float32, device=dev)
+        da1, da2, dc = torch.empty_like(a1), torch.empty_like(a2), torch.empty_like(c)
+        db1 = torch.empty((P,), dtype=torch.float32, device=dev)
+        db2 = torch.empty((P,), dtype=torch.float32, device=dev)
+        dWr = torch.empty((P, S, Fw, D), dtype=torch.float32, device=dev) if Wr is not None else None
+        dXin = None
+        if ctx.xin_shape is not None and ctx.needs_input_grad[0]:
+            dXin = torch.zeros(ctx.xin_shape, dtype=torch.float32, device=dev)
+        for p in range(P):
+            f1, f2, per_s = ctx.saved_per_p[p]
+            seed = int(cfg["seeds"][p])
+            a1s, a2s, cs = a1[p].view(S, 1, D), a2[p].view(S, 1, D), c[p].view(S, D)
+            rows, df1 = [], None
+            for s_ in range(S):       # row-local halves: g, the slice's share of df1
+                H, pre, lse, aggp, tsum, R = per_s[s_]
+                gs, df1s, _ = ops.node_attn_bwd_rows(dM[:, p, s_ * D:(s_ + 1) * D], pre, aggp, tsum, f1, lse, cs[s_],
+                                                     activation=cfg["act"], K=1, FP=D, table_dtype=H.dtype, res=R,
+                                                     dc_out=dc[p, s_ * D:(s_ + 1) * D])
+                rows.append(gs)
+                df1 = df1s if df1 is None else df1 + df1s
+                if Wr is not None:
+                    g32 = ops.gs_views(gs, 1, D, H.dtype)[0].to(torch.float32).contiguous()
+                    ops.project_bwd(xs[p], g32, 1, D, in_drop=ctx.in_drop, seed=seed, seed_dev=seed_dev, out=dWr[p, s_])
+                    if dXin is not None:
+                        Wrs = Wr[p].view(-1, S, D)[:, s_, :].contiguous()
+                        dXin[:, p, :] += ops.project_bwd_input(g32, Wrs, 1, D, in_drop=ctx.in_drop, seed=seed,
+                                                               seed_dev=seed_dev)
+            cols, df2 = [], None
+            for s_ in range(S):       # transposed-graph halves with the head's df1; each returns its share of df2
+                H = per_s[s_][0]
+                dH, df2s = ops.node_attn_bwd_cols(graphs_t[p], rows[s_], H, f2, df1, a1s[s_], a2s[s_],
+                                                  coef_drop=ctx.coef_drop, fts_drop=ctx.in_drop, seed=seed,
+                                                  seed_dev=seed_dev)
+                cols.append((dH, df2s))
+                df2 = df2s if df2 is None else df2 + df2s
+            for s_ in range(S):
+                H = per_s[s_][0]
+                dH, df2s = cols[s_]
+                if S > 1:             # the kernel added its own df2 share times a2; the head's total belongs there
+                    dH.addcmul_(df2 - df2s, a2s[s_])
+                o1 = torch.empty((1,), dtype=torch.float32, device=dev) if s_ else db1[p:p + 1]
+                o2 = torch.empty((1,), dtype=torch.float32, device=dev) if s_ else db2[p:p + 1]
+                ops.score_param_bwd(H, df1, df2, K=1, FP=D, out=(da1[p].view(S, 1, D)[s_], da2[p].view(S, 1, D)[s_], o1, o2))
+                ops.project_bwd(xs[p], dH, 1, D, in_drop=ctx.in_drop, seed=seed, seed_dev=seed_dev, out=dW[p, s_])
+                if dXin is not None:
+                    Ws = W[p].view(-1, S, D)[:, s_, :].contiguous()
+                    dXin[:, p, :] += ops.project_bwd_input(dH, Ws, 1, D, in_drop=ctx.in_drop, seed=seed,
+                                                           seed_dev=seed_dev)
+        ctx.saved_per_p = None
+        fold = lambda t: t.permute(0, 2, 1, 3).reshape(P, Fw, S * D)
+        return (dXin, fold(dW), da1, db1, da2, db2, dc, fold(dWr) if dWr is not None else None,
+                dc.clone() if Wr is not None else None, None, None, None)
+
+
 class SemanticAttention(torch.autograd.Function):
     """K3: M (N,P,D) -> (Z (N,D), beta (N,P)); utils/layers.py:152-159."""
 
@@ -486,8 +630,11 @@ def _single_head(seq, out_sz, graph, activation, in_drop, coef_drop, residual, p
     slots of the lane-mapped width F'k = next of 4, 8, 16, 32, 64 >= out_sz; the columns beyond out_sz
     and the other slots have zero weights."""
     x = _squeeze_batch(seq)
-    if not (1 <= out_sz <= D):
-        raise NotImplementedError(f"out_sz must be in [1, {D}] in this build")
+    if out_sz < 1:
+        raise ValueError("out_sz must be positive")
+    if out_sz > D:
+        return _single_wide_head(x, out_sz, graph, activation, in_drop, coef_drop, residual, params, training, seed,
+                                 return_coef)
     fpk = next(w for w in (4, 8, 16, 32, 64) if out_sz <= w)
     K = D // fpk
     dev = x.device
@@ -526,6 +673,42 @@ def _single_head(seq, out_sz, graph, activation, in_drop, coef_drop, residual, p
                                         cfg["coef_sink"][0][:, 0].contiguous(), (graph.n_rows, graph.n_cols))
         return ret[None], coefs
     return ret[None]     # (1,N,out_sz)
+
+
+def _single_wide_head(x, out_sz, graph, activation, in_drop, coef_drop, residual, params, training, seed,
+                      return_coef):
+    """One head wider than 64 columns: ceil(out_sz / 64) column slices that share the head's scores, coefficients
+    and per-head dropout draws (WideHeadAttention); columns beyond out_sz carry zero weights."""
+    S = -(-out_sz // D)
+    Fin = x.shape[1]
+
+    def pad_last(t):
+        out = t.new_zeros(t.shape[:-1] + (S * D,))
+        out[..., :t.shape[-1]] = t
+        return out
+
+    W = pad_last(params["W"])[None]
+    if W.shape[1] != Fin:
+        raise ValueError(f"W has {W.shape[1]} input features, seq has {Fin}")
+    a1, a2, c = (pad_last(params[k])[None] for k in ("a1", "a2", "c"))
+    b1, b2 = params["b1"].reshape(1), params["b2"].reshape(1)
+    code, post = _act_code(activation)
+    train = bool(training) or in_drop > 0 or coef_drop > 0 or W.requires_grad
+    cfg = {"train": train, "in_drop": in_drop, "coef_drop": coef_drop,
+           "seeds": (rng.next_seed() if seed is None else seed,), "act": code, "part": None,
+           "coef_sink": [] if return_coef else None, "coef_mean": True}
+    Wr = br = None
+    if residual and Fin != out_sz:
+        Wr, br = pad_last(params["res_W"])[None], pad_last(params["res_b"])[None]
+    M = WideHeadAttention.apply(None, W, a1, b1, a2, b2, c, Wr, br, (x,), (graph,), cfg)
+    ret = M[:, 0, :out_sz]
+    if post is not None:
+        ret = post(ret)
+    if return_coef:
+        coefs = torch.sparse_csr_tensor(graph.rowptr, graph.colidx.long(), cfg["coef_sink"][0].contiguous(),
+                                        (graph.n_rows, graph.n_cols))
+        return ret[None], coefs
+    return ret[None]
 
 
 def attn_head(seq, out_sz, bias_mat, activation, in_drop=0.0, coef_drop=0.0, residual=False,

@@ -22,6 +22,16 @@ FLAG_K1_MATRIX_PIPE = 4
 FLAG_K1_4WAVE = 16         # HAN_FLAG_K1_4WAVE (measurements: the two-waves-per-SIMD form of the bf16 x 6 kernel)
 FLAG_K1_PAIRS = 32         # HAN_FLAG_K1_PAIRS (measurements: project_fwd_multi fuses 2 meta-paths per block, not 4)
 FLAG_K3_EXACT_PIPE = 8     # HAN_FLAG_K3_EXACT_PIPE: fp32 MFMA K3 kernels also for large inputs
+
+
+def flag_fts_slice(s: int) -> int:
+    """HAN_FLAG_FTS_SLICE(s): column slice s of a head wider than 64 columns (project_fwd: the projected-row
+    dropout of slice s draws from stream 2 + 4 s; everything else is keyed as for slice 0)."""
+    if not 0 <= s < 256:
+        raise ValueError("at most 256 slices of 64 columns per head")
+    return (int(s) & 0xFF) << 8
+
+
 LEAKY_SLOPE = 0.2          # tf.nn.leaky_relu default (utils/layers.py:27)
 D = 64                     # K * F' of this build
 STATS_ROW_BYTES = 128      # per destination row: the (f1, lse, s, 0) records of the K = 8 heads inside the fused gs row (bench.py byte model)
@@ -303,15 +313,16 @@ def project_bwd_input(dH, W, K, FP, out=None, in_drop=0.0, seed=0, row_offset=0,
 # --------------------------------------------------------------------------- K2
 def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=0.0,
                   fts_drop=0.0, seed=0, row_offset=0, activation=ACT_ELU, table_gid=None, res=None,
-                  seed_dev=None):
+                  seed_dev=None, f2_src=None):
     """utils/layers.py:26-35,46.  H_tab (NT,D): gather table of UNDROPPED projected
     rows indexed by graph.colidx (f2_j is recomputed from the gathered row with
     a2 (K,F'), b2 (K,)); with fts_drop > 0 bit 0 of each element is its keep bit
     (as project_fwd stamped it); f1 (N,K) local rows; c (D,).  table_gid (NT,)
     int32: global id of each table row when H_tab is a [local | halo] table.
     res (N,D) fp32: residual term added before the activation (layers.py:38-40).  `out`: optional (N,D) view with unit inner
-    stride (e.g. M[:,p,:]).  Returns out, saved where
-    saved = (pre, lse, aggp, tsum) if train else None."""
+    stride (e.g. M[:,p,:]).  f2_src (NT,1): one head of 64 columns only -- the neighbour scores are gathered from
+    this table instead of being recomputed (slices of a head wider than 64 columns: f1 / f2_src hold the head's
+    totals).  Returns out, saved where saved = (pre, lse, aggp, tsum) if train else None."""
     lib = _lib.load()
     K, FP = a2.shape
     _check_heads(K, FP)
@@ -327,6 +338,10 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         _chk(table_gid, "table_gid", (graph.n_cols,), dtype=torch.int32, device=dev)
     if res is not None:
         _chk(res, "res", (N, D), device=dev)
+    if f2_src is not None:
+        if FP != D:
+            raise ValueError("f2_src: only for one head of 64 columns (K = 1, F' = 64)")
+        _chk(f2_src, "f2_src", (graph.n_cols, 1), device=dev)
     if graph.device != dev:
         raise ValueError("graph and tables must be on the same device")
     if out is None:
@@ -357,6 +372,7 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         graph.rowptr.data_ptr(), graph.colidx.data_ptr(),
         graph.values.data_ptr() if graph.values is not None else None, H_tab.data_ptr(), tcode,
         table_gid.data_ptr() if table_gid is not None else None, f1.data_ptr(),
+        f2_src.data_ptr() if f2_src is not None else None,
         a2.data_ptr(), b2.data_ptr(), c.data_ptr(), res.data_ptr() if res is not None else None,
         out.data_ptr(), out.stride(0) if N > 1 else D,
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,

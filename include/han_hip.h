@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HAN_ABI_VERSION 4
+#define HAN_ABI_VERSION 5
 
 #define HAN_E_BADARG   (-1)   /* null pointer, negative size, inconsistent shape.  The forward
                               * entry points return 0 at once for N == 0 (empty tensors may
@@ -55,6 +55,13 @@ extern "C" {
 #define HAN_FLAG_K1_PAIRS      32   /* measurements only: han_project_fwd_multi fuses 2 meta-paths per block, not 4 */
 #define HAN_FLAG_K1_4WAVE      16   /* measurements only: the round-2 form of the bf16 x 6 kernel (4 waves x 2 row tiles,
                                        two waves per SIMD) instead of 8 waves x 1 tile (four per SIMD)                     */
+/* han_project_fwd, heads wider than the 64 columns of a K1 / K2 row (hid_units > 64, models/gat.py:42-57): such a head runs
+ * as ceil(F'/64) column slices, each a K = 1, F' = 64 call with the SAME seed -- so the slices share the per-head
+ * input-dropout and attention-dropout draws, as one head must -- and slice s draws its projected-row dropout
+ * (layers.py:31-32, one draw per column) from stream 2 + 4 s.  The caller adds the slices' partial scores
+ * (b1 / b2 in slice 0 only) and hands the totals to K2 (han_node_attn_fwd: f2_src).                              */
+#define HAN_FLAG_FTS_SLICE(s)     (((s) & 0xFF) << 8)
+#define HAN_FLAG_FTS_SLICE_OF(fl) (((fl) >> 8) & 0xFF)
 /* `flags` of han_sem_attn_fwd / han_sem_attn_bwd */
 #define HAN_FLAG_K3_EXACT_PIPE  8   /* fp32 MFMA kernels also for large inputs (default: bf16 x 6 from 65 536 rows) */
 
@@ -172,10 +179,15 @@ size_t han_row_split_workspace(int64_t n_chunks);
  * at out + i*out_stride (so the K heads land directly in M[:,p,:],
  * models/gat.py:46,58-60).  Training extras (all or none may be NULL): pre (N,D)
  * pre-activation, lse (N,K) log-sum-exp of the scores, aggp (N,D) and tsum (N,K)
- * -- the LeakyReLU'-weighted aggregates that make df1 row-local in the backward. */
+ * -- the LeakyReLU'-weighted aggregates that make df1 row-local in the backward.
+ * f2_src (NT,K) or NULL: when given (K = 1, F' = 64 only) the neighbour score is GATHERED from this table
+ * instead of being recomputed from the row -- the slices of a head wider than 64 columns share the head's
+ * scores (f1 / f2_src then hold the totals over the slices; a2 / b2 are not read).  The backward needs nothing
+ * new: han_node_attn_bwd_cols already takes f2 and df1 as inputs, and its slices' df1 / df2 add up (the
+ * softmax backward is linear in d alpha); the caller adds (df2_total - df2_slice) x a2_slice to dH.          */
 int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float *edge_val,
                       const void *H,
-                      int table_dtype, const int32_t *table_gid, const float *f1,
+                      int table_dtype, const int32_t *table_gid, const float *f1, const float *f2_src,
                       const float *a2, const float *b2, const float *c, const float *res,
                       float *out, int64_t out_stride, float *pre, float *lse, float *aggp,
                       float *tsum, int64_t N, int64_t E, int K, int FP, float slope,

@@ -48,7 +48,7 @@ def project_fwd(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seed=0, row_off
     if table_dtype == torch.bfloat16:       # bf16 storage: round to nearest even, keep bit = bit 0 of the bf16
         H, it = H.to(torch.bfloat16), torch.int16
     if fts_drop > 0:      # keep bits ride in mantissa bit 0 (han_project_fwd contract)
-        bits = torch.tensor(rng_ref.fts_mask(seed, N, D, fts_drop, row_offset)).to(it)
+        bits = torch.tensor(rng_ref.fts_mask(seed, N, D, fts_drop, row_offset, (int(flags) >> 8) & 0xFF)).to(it)
         H = ((H.view(it) & ~1) | bits).view(H.dtype)
     hk = _f64(H).view(N, K, FP)
     f1 = (hk * _f64(a1)[None]).sum(-1) + _f64(b1)
@@ -107,12 +107,12 @@ def project_bwd_input(dH, W, K, FP, out=None, in_drop=0.0, seed=0, row_offset=0,
     return out
 
 
-def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset, table_gid=None):
+def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset, table_gid=None, f2_src=None):
     K, FP = a2.shape
     rows = _rows_of(graph)
     cols = graph.colidx.long()
     h = _f64(H_tab)
-    f2 = (h.view(-1, K, FP) * _f64(a2)[None]).sum(-1) + _f64(b2)
+    f2 = (h.view(-1, K, FP) * _f64(a2)[None]).sum(-1) + _f64(b2) if f2_src is None else _f64(f2_src)
     u = _f64(f1)[rows] + f2[cols]                                  # (E,K)
     w = _f64(graph.values)[:, None] if graph.values is not None else torch.ones((1, 1), dtype=torch.float64)
     u = w * u                                                      # layers.py:95-96
@@ -139,12 +139,12 @@ def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset,
 
 
 def node_attn_fwd(graph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=0.0, fts_drop=0.0,
-                  seed=0, row_offset=0, activation=1, table_gid=None, res=None, seed_dev=None):
+                  seed=0, row_offset=0, activation=1, table_gid=None, res=None, seed_dev=None, f2_src=None):
     seed = _eff(seed, seed_dev)
     K, FP = a2.shape
     N = graph.n_rows
     rows, cols, alpha, am, sg, lse, hd = _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop,
-                                                     seed, row_offset, table_gid)
+                                                     seed, row_offset, table_gid, f2_src)
     hk = hd.view(-1, K, FP)[cols]                                    # (E,K,FP)
     agg = torch.zeros((N, K, FP), dtype=torch.float64).index_add(0, rows, (alpha * am)[:, :, None] * hk)
     pre = agg.reshape(N, D) + _f64(c)

@@ -92,6 +92,17 @@ def group_masks(seed, n, f, K, FP, rowptr, colidx, drop, row_offset=0):
     Returns the oracle's mask dict: seq (K,N,F), coef (E,K), fts (N,K*FP)."""
     import torch
     from tests import rng_ref
+    if FP > 64:       # a head wider than 64 columns: one head per group (seed + k, head index 0), slices of 64 columns
+        S = -(-FP // 64)       # that share the head's draws except for the per-column projected-row dropout (stream 2 + 4 s)
+        seq, coef, fts = [], [], []
+        for k in range(K):
+            sd = (int(seed) + k) & ((1 << 64) - 1)
+            seq.append(rng_ref.seq_mask(sd, n, f, 1, drop, row_offset))
+            coef.append(rng_ref.coef_mask_csr(sd, rowptr, colidx, 1, drop, row_offset))
+            fts.append(np.concatenate([rng_ref.fts_mask(sd, n, 64, drop, row_offset, slice_index=s_)
+                                       for s_ in range(S)], 1)[:, :FP])
+        return {"seq": torch.tensor(np.concatenate(seq, 0)), "coef": torch.tensor(np.concatenate(coef, 1)),
+                "fts": torch.tensor(np.concatenate(fts, 1))}
     FPk = next(w for w in (4, 8, 16, 32, 64) if FP <= w)
     kg = 64 // FPk
     seq, coef, fts = [], [], []

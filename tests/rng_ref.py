@@ -72,11 +72,12 @@ def coef_mask_csr(seed, rowptr, colidx, K, drop, row_offset=0):
     return coef_draws(seed, rows, colidx, K, drop)
 
 
-def fts_mask(seed, n, d, drop, row_offset=0):
-    """(N,D) -- layers.py:32: counter (row, d//4), field d%4."""
+def fts_mask(seed, n, d, drop, row_offset=0, slice_index=0):
+    """(N,D) -- layers.py:32: counter (row, d//4), field d%4.  slice_index: column slice of a head wider than 64
+    columns (HAN_FLAG_FTS_SLICE): stream 2 + 4 * slice."""
     rows = np.arange(n)[:, None] + row_offset
     ds = np.arange(d)[None, :]
-    x, y = han_rand64(seed, STREAM_FTS, rows, ds // 4)
+    x, y = han_rand64(seed, STREAM_FTS + 4 * int(slice_index), rows, ds // 4)
     return (field(x, y, ds % 4) < _thr(drop)).astype(np.float64)
 
 

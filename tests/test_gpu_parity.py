@@ -542,7 +542,10 @@ def test_dropout_statistics(dev):
                                     # a last layer wider than the K3 / classifier kernels (256, 192 columns)
                                     (8, 32, 128), (3, 64, 40),
                                     (8, 8, 200), (8, 16, 256),                                       # mp_att_size 129 .. 256: K3 kernels (round 3)
-                                    (8, 8, 300)])                                                    # mp_att_size above the K3 kernels
+                                    (8, 8, 300),                                                     # mp_att_size above the tuned K3 kernels
+                                    # round 3: heads wider than 64 columns (hid_units > 64) as slices of one head:
+                                    # gathered f2 in K2, shared per-head draws, per-slice projected-row dropout streams
+                                    (2, 128, 128), (1, 100, 64), (3, 96, 40), (8, 128, 128)])
 @pytest.mark.parametrize("drop", [0.0, 0.6])
 def test_other_head_shapes_match_oracle(dev, K, FP, A, drop, monkeypatch):
     """hid_units=[F'], n_heads=[K,1] other than 8x8 and mp_att_size other than 128 (models/gat.py:37,42-57
@@ -560,11 +563,12 @@ def test_other_head_shapes_match_oracle(dev, K, FP, A, drop, monkeypatch):
     @contextlib.contextmanager
     def hip_only():      # shapes on the HIP kernels end to end: no library GEMM / torch elementwise in the product path
         with monkeypatch.context() as mp:
-            if K * FP <= 128 and A <= 256:
-                def _no_torch(*a, **k):
-                    raise AssertionError("torch.matmul / torch.tanh in a path the HIP kernels cover")
-                mp.setattr(torch, "matmul", _no_torch)
-                mp.setattr(torch, "tanh", _no_torch)
+            def _no_torch(*a, **k):      # round 3: EVERY shape (any width, any mp_att_size, any head width)
+                raise AssertionError("torch.matmul / torch.tanh / softmax in a path the HIP kernels cover")
+            for name in ("matmul", "tanh", "softmax", "mm", "bmm", "einsum"):
+                mp.setattr(torch, name, _no_torch)
+            mp.setattr(torch.nn.functional, "softmax", _no_torch)
+            mp.setattr(torch.nn.functional, "cross_entropy", _no_torch)
             yield
     assert (model.K, model.FP, model.A) == (K, FP, A) and tuple(model.w_omega.shape) == (K * FP, A)
     lg, fe, att = ho.hetegat_multi_inference([prob["x"]] * p, 3, n, False, 0.0, 0.0, prob["biases"],
@@ -1665,6 +1669,90 @@ def test_multi_layer_stack_matches_oracle(dev, drop, residual):
     assert abs(float(loss.detach()) - float(loss_ref.detach())) < 5e-4 * max(1.0, float(loss_ref.detach()))
     for k in ht.param_order(bp):
         assert rel_err(getattr(model, k).grad.cpu().numpy(), bpo[k].grad.numpy()) < GTOL, k
+
+
+@pytest.mark.parametrize("drop,residual", [(0.0, False), (0.6, False), (0.6, True)])
+def test_wide_head_in_a_deeper_layer(dev, drop, residual, monkeypatch):
+    """hid_units=[8,96], n_heads=[8,2,1] (models/gat.py:48-57 leaves the widths free): the second layer's heads
+    are 96 columns wide -- two 64-column slices of one head each (layers.WideHeadAttention: shared scores, gathered
+    f2, shared per-head draws) -- and send their input gradient back into the first layer; the last layer is 192
+    columns wide (run-time-width K3 / classifier kernels).  Loss and every gradient against the float64 oracle on
+    the same hash masks, with no torch GEMM / softmax anywhere in the product path."""
+    from han_amd import layers, ops, rng as hrng
+    n = 120
+    prob = make_problem(63, n, 11, 2, 3, [0.05, 0.4], hid_units=[8, 96], n_heads=(8, 2, 1), residual=residual)
+    model, bp = build_model(prob, dev)
+    x, graphs = gpu_inputs(prob, dev)
+    hrng.manual_seed(23)
+    seeds = [hrng.next_seed() for _ in range(4)]
+    hrng.manual_seed(23)
+    model.zero_grad_flat()
+    with monkeypatch.context() as mp:
+        def _no_torch(*a, **k):
+            raise AssertionError("torch GEMM / softmax in the product path")
+        for name in ("matmul", "tanh", "softmax", "mm", "bmm", "einsum"):
+            mp.setattr(torch, name, _no_torch)
+        M = model.node_level([x, x], graphs, drop, drop, True, ops.ACT_ELU)
+        assert tuple(M.shape) == (n, 2, 192)
+        Z, _ = model.semantic(M)
+        loss, _, logits = model.classifier_loss(Z, _t(prob["labels"], dev, torch.int32),
+                                                _t(prob["mask"].astype(np.uint8), dev, torch.uint8),
+                                                1.0 / int(prob["mask"].sum()))
+        loss.backward()
+    masks, keep = None, 1.0
+    if drop > 0:
+        keep = rng_ref.keep_prob32(drop)
+        masks = []
+        for q in range(2):
+            rp, ci = ho.bias_to_csr(prob["biases"][q])
+            m0 = group_masks(seeds[q], n, 11, 8, 8, rp, ci, drop)
+            m0["layers"] = [group_masks(seeds[2 + q], n, 64, 2, 96, rp, ci, drop)]
+            masks.append(m0)
+    bpo = {k: v.clone().requires_grad_(True) for k, v in bp.items()}
+    og = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]
+    lg_ref, _, _ = ht.hetegat_forward([torch.tensor(prob["x"][0])] * 2, og, bpo, keep_in=keep, keep_coef=keep, masks=masks)
+    loss_ref = ht.masked_softmax_cross_entropy(lg_ref, torch.tensor(prob["onehot"]), torch.tensor(prob["mask"]))
+    loss_ref.backward()
+    assert rel_err(logits.cpu().numpy(), lg_ref.detach().numpy()) < 1e-4
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 5e-4 * max(1.0, float(loss_ref.detach()))
+    for k in ht.param_order(bp):
+        assert rel_err(getattr(model, k).grad.cpu().numpy(), bpo[k].grad.numpy()) < GTOL, k
+
+
+def test_wide_single_head_api_and_bf16_tables(dev):
+    """attn_head(seq, out_sz = 100, ...) (utils/layers.py:7 leaves out_sz free) with return_coef and the residual
+    branch, and a model with 128-wide heads on bf16 tables (same slices, bf16 rows)."""
+    import torch.nn.functional as Fnn
+    from han_amd import layers
+    n = 50
+    prob = make_problem(7, n, 9, 1, 3, [0.2], hid_units=[100], n_heads=(1, 1))
+    head = prob["params"]["heads"][0][0]
+    params = {k: _t(v, dev) for k, v in head.items()}
+    x = _t(prob["x"], dev)
+    ref, ref_coef = ho.attn_head(prob["x"], head, prob["biases"][0], return_coef=True)
+    with torch.no_grad():
+        out, coefs = layers.attn_head(x, 100, _t(prob["biases"][0], dev), Fnn.elu, params=params, return_coef=True)
+    assert out.shape == (1, n, 100)
+    assert np.abs(out.cpu().numpy() - ref).max() < TOL
+    assert np.abs(coefs.to_dense().cpu().numpy() - ref_coef[0]).max() < 1e-5
+    rngr = np.random.default_rng(8)
+    res = {"W": rngr.standard_normal((9, 100)) * 0.3, "b": rngr.standard_normal(100) * 0.1}
+    ref_res = ho.attn_head(prob["x"], head, prob["biases"][0], residual=True, res_params=res)
+    with torch.no_grad():
+        out_res = layers.attn_head(x, 100, _t(prob["biases"][0], dev), Fnn.elu, residual=True,
+                                   params={**params, "res_W": _t(res["W"], dev), "res_b": _t(res["b"], dev)})
+    assert np.abs(out_res.cpu().numpy() - ref_res).max() < TOL
+    # bf16 tables: forward within the bf16 storage error of the fp32-table model, gradients finite and close
+    from han_amd.gat import HeteGAT_multi
+    prob2 = make_problem(8, 80, 12, 2, 3, [0.1, 0.3], hid_units=[128], n_heads=(2, 1))
+    m32, bp = build_model(prob2, dev)
+    m16 = HeteGAT_multi().build(2, 12, 3, (128,), (2, 1), 128, device=dev, table_dtype=torch.bfloat16)
+    load_params(m16, bp)
+    x2, graphs2 = gpu_inputs(prob2, dev)
+    with torch.no_grad():
+        l32 = m32.inference([x2] * 2, 3, 80, False, 0.0, 0.0, graphs2, [128], [2, 1])[0]
+        l16 = m16.inference([x2] * 2, 3, 80, False, 0.0, 0.0, graphs2, [128], [2, 1])[0]
+    assert rel_err(l16.cpu().numpy(), l32.cpu().numpy()) < 2e-2
 
 
 def test_locality_pass_is_a_pure_relabelling(dev):

@@ -306,9 +306,11 @@ def test_model_variables_and_initialisers():
     assert tuple(m4.W_1.shape) == (2, 96, 32) and tuple(m4.w_omega.shape) == (32, 128)
     m5 = HeteGAT_multi().build(2, 10, 3, (10,), (4, 1), device="cpu")          # any head width up to 64
     assert tuple(m5.W.shape) == (2, 10, 40) and tuple(m5.a1.shape) == (2, 4, 10)
-    with pytest.raises(NotImplementedError):
-        HeteGAT_multi().build(2, 10, 3, (65,), (1, 1), device="cpu")           # head wider than the 64-column group
-    m6 = HeteGAT_multi().build(2, 10, 3, (32,), (8, 1), device="cpu")          # final width 256: K3 / classifier via torch
+    m7 = HeteGAT_multi().build(2, 10, 3, (65,), (2, 1), device="cpu")          # heads wider than the 64-column group: slices
+    assert tuple(m7.W.shape) == (2, 10, 130) and tuple(m7.a1.shape) == (2, 2, 65) and tuple(m7.w_omega.shape) == (130, 128)
+    with pytest.raises(ValueError):
+        HeteGAT_multi().build(2, 10, 3, (0,), (1, 1), device="cpu")
+    m6 = HeteGAT_multi().build(2, 10, 3, (32,), (8, 1), device="cpu")          # final width 256: run-time-width K3 / classifier kernels
     assert tuple(m6.w_omega.shape) == (256, 128) and tuple(m6.Wc.shape) == (1, 256, 3)
     assert tuple(HeteGAT_multi().build(2, 10, 40, device="cpu").Wc.shape) == (1, 64, 40)   # up to 64 classes
     assert tuple(HeteGAT_multi().build(2, 10, 100, mp_att_size=200, device="cpu").w_omega.shape) == (64, 200)
@@ -494,6 +496,48 @@ def test_multi_layer_stack_on_cpu_backend(cpu_ops, drop, residual):
         assert np.abs(lg_np[0] - lg_ref.detach().numpy()).max() < 1e-10
 
 
+@pytest.mark.parametrize("drop,residual", [(0.0, False), (0.6, True)])
+def test_wide_head_in_a_deeper_layer_on_cpu_backend(cpu_ops, drop, residual):
+    """Host logic of layers.WideHeadAttention inside a stack (hid_units=[8,96], n_heads=[8,2,1]): slices of one
+    head with shared scores / draws, totals of df1 / df2 across the slices, the input gradient into layer 0."""
+    from han_amd import ops, rng as hrng
+    from han_amd.gat import HeteGAT_multi
+    n = 40
+    prob = make_problem(64, n, 9, 2, 3, [0.15, 0.4], hid_units=[8, 96], n_heads=(8, 2, 1), residual=residual)
+    bp = ht.to_batched(prob["params"])
+    model = HeteGAT_multi().build(2, 9, 3, (8, 96), (8, 2, 1), device="cpu", residual=residual)
+    load_params(model, bp)
+    x = torch.tensor(prob["x"][0], dtype=torch.float32)
+    hrng.manual_seed(9)
+    seeds = [hrng.next_seed() for _ in range(4)]
+    hrng.manual_seed(9)
+    model.zero_grad_flat()
+    M = model.node_level([x, x], _cpu_graphs(prob), drop, drop, True, ops.ACT_ELU)
+    assert tuple(M.shape) == (n, 2, 192)
+    Z, _ = model.semantic(M)
+    loss, _, logits = model.classifier_loss(Z, torch.tensor(prob["labels"], dtype=torch.int32),
+                                            torch.tensor(prob["mask"].astype(np.uint8)), 1.0 / int(prob["mask"].sum()))
+    loss.backward()
+    masks, keep = None, 1.0
+    if drop > 0:
+        keep = rng_ref.keep_prob32(drop)
+        masks = []
+        for q in range(2):
+            rp, ci = ho.bias_to_csr(prob["biases"][q])
+            m0 = group_masks(seeds[q], n, 9, 8, 8, rp, ci, drop)
+            m0["layers"] = [group_masks(seeds[2 + q], n, 64, 2, 96, rp, ci, drop)]
+            masks.append(m0)
+    bpo = {k: v.clone().requires_grad_(True) for k, v in bp.items()}
+    og = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]
+    lg_ref, _, _ = ht.hetegat_forward([torch.tensor(prob["x"][0])] * 2, og, bpo, keep_in=keep, keep_coef=keep, masks=masks)
+    loss_ref = ht.masked_softmax_cross_entropy(lg_ref, torch.tensor(prob["onehot"]), torch.tensor(prob["mask"]))
+    loss_ref.backward()
+    assert np.abs(logits.detach().numpy() - lg_ref.detach().numpy()).max() < 1e-4
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-5
+    for k in ht.param_order(bp):
+        assert rel_err(getattr(model, k).grad.numpy(), bpo[k].grad.numpy()) < 1e-4, k
+
+
 def test_mat_loader_follows_the_reference_script(tmp_path):
     """han_amd.process.load_data_mat == ex_acm3025.py:57-87 on a synthetic .mat with the
     ACM3025 keys: the '- I' on the meta-path matrices, masks, zeroed label rows, and
@@ -600,7 +644,9 @@ def test_arbitrary_activation_callable_on_cpu_backend(cpu_ops):
 @pytest.mark.parametrize("K,FP,A", [(8, 16, 128), (4, 8, 128), (3, 8, 48), (12, 8, 80),
                                     (5, 12, 128), (3, 20, 64), (2, 3, 32), (1, 50, 100),
                                     (8, 32, 128), (3, 64, 40),         # 256 / 192 wide: above the K3 kernels
-                                    (8, 8, 200)])                      # attention size above the K3 kernels
+                                    (8, 8, 200),                       # attention size above the K3 kernels
+                                    # heads wider than 64 columns: slices of one head (layers.WideHeadAttention)
+                                    (2, 128, 64), (1, 100, 128), (3, 96, 40)])
 @pytest.mark.parametrize("drop", [0.0, 0.6])
 def test_general_head_widths_on_cpu_backend(cpu_ops, K, FP, A, drop):
     """Host logic of the widths other than 8 x 8 (han_amd.gat.node_level / semantic / classifier_loss): head
