@@ -215,7 +215,7 @@ class NodeLevelAttention(torch.autograd.Function):
                                       fts_drop=in_drop, seed=int(cfg["seeds"][p]), row_offset=row_offset,
                                       activation=cfg["act"],
                                       table_gid=plan.gid if plan is not None else None, res=R,
-                                      seed_dev=seed_dev)
+                                      seed_dev=seed_dev, f2=None if multi else f2)
             if train:
                 saved.append((H, f1, f2) + sv + (R, proj_keep[p]))
 

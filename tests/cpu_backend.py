@@ -139,7 +139,7 @@ def _edge_terms(graph, H_tab, f1, a2, b2, coef_drop, fts_drop, seed, row_offset,
 
 
 def node_attn_fwd(graph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=0.0, fts_drop=0.0,
-                  seed=0, row_offset=0, activation=1, table_gid=None, res=None, seed_dev=None, f2_src=None):
+                  seed=0, row_offset=0, activation=1, table_gid=None, res=None, seed_dev=None, f2_src=None, f2=None):
     seed = _eff(seed, seed_dev)
     K, FP = a2.shape
     N = graph.n_rows

@@ -852,6 +852,91 @@ def test_sp_attn_head_weighted_adjacency_values(dev, drop, monkeypatch):
             assert rel_err(leaf[k].grad.cpu().numpy(), ref_leaf[k].grad.numpy()) < GTOL, k
 
 
+@pytest.mark.parametrize("K,FP", [(8, 8), (16, 4), (4, 16), (2, 32), (1, 64)])
+@pytest.mark.parametrize("drop", [0.0, 0.6])
+def test_tiled_forward_on_dense_graphs_matches_oracle(dev, K, FP, drop, monkeypatch):
+    """HAN_FLAG_TILED: graphs at least half dense (DBLP APTPA is 78 % dense) run their K2 forward on the LDS-tiled
+    kernels -- table in 256-row tiles through LDS, scores read from the K1 table, projected-row dropout applied once
+    per staged element, one attention-dropout hash per (edge, four heads) handed out by ds_bpermute.  n = 600 = two
+    full tiles + a partial one, rows with several 64-entry pieces per tile and partial last steps; every head shape;
+    inference and loss + all gradients with both dropouts on the oracle's exact masks; and the same numbers (to the
+    order of the sums) as the gather kernels."""
+    from han_amd import ops, rng as hrng
+    n, f, p = 600, 13, 2
+    prob = make_problem(300 + K, n, f, p, 3, [0.8, 0.55], hid_units=[FP], n_heads=(K, 1))
+    model, bp = build_model(prob, dev)
+    x, graphs = gpu_inputs(prob, dev)
+    calls = []
+    real = ops._use_tiles
+    monkeypatch.setattr(ops, "_use_tiles", lambda g, t: calls.append(real(g, t)) or calls[-1])
+    lg, fe, att = ho.hetegat_multi_inference([prob["x"]] * p, 3, n, False, 0.0, 0.0, prob["biases"], [FP], [K, 1],
+                                             prob["params"])
+    with torch.no_grad():
+        logits, final_embed, att_val = model.inference([x] * p, 3, n, False, 0.0, 0.0, graphs, [FP], [K, 1])
+    assert calls and all(calls)                       # both meta-paths took the tiled kernels
+    assert np.abs(logits[0].cpu().numpy() - lg[0]).max() < TOL
+    assert np.abs(final_embed.cpu().numpy() - fe).max() < TOL
+    monkeypatch.setattr(ops, "TILED", False)
+    with torch.no_grad():
+        logits_g = model.inference([x] * p, 3, n, False, 0.0, 0.0, graphs, [FP], [K, 1])[0]
+    monkeypatch.setattr(ops, "TILED", True)
+    assert not calls[-1] and float((logits_g - logits).abs().max()) < 1e-5
+    hrng.manual_seed(777)
+    seeds = [hrng.next_seed() for _ in range(p)]
+    hrng.manual_seed(777)
+    masks, keep = None, 1.0
+    if drop > 0:
+        keep = rng_ref.keep_prob32(drop)
+        masks = [group_masks(seeds[q], n, f, K, FP, *ho.bias_to_csr(prob["biases"][q]), drop) for q in range(p)]
+    loss_ref, gref, lg_ref = _oracle_grads(prob, bp, masks=masks, keep=keep, dense=False)
+    loss, grads, lgg, _ = _gpu_loss_and_grads(model, prob, dev, attn_drop=drop, ffd_drop=drop)
+    assert calls[-1]
+    assert np.abs(lgg - lg_ref).max() < 5 * TOL
+    assert abs(loss - loss_ref) < 5e-4
+    for k in ht.PARAM_ORDER:
+        assert rel_err(grads[k], gref[k]) < GTOL, k
+
+
+def test_tiled_forward_edge_values_and_ragged_rows(dev):
+    """The tiled kernels with sp_attn_head's logit-scaling values, rows of very different lengths (empty rows, rows
+    that end inside a tile, a full row) and a table of exactly one tile; against the gather kernels on the same
+    inputs (bitwise-equal masks: the draws are keyed by (row, neighbour, head), not by the order of the walk)."""
+    from han_amd import ops
+    from han_amd.graph import CSRGraph
+    gen = torch.Generator(device=dev).manual_seed(5)
+    for n in (256, 257, 700):
+        dens = torch.rand((n, 1), device=dev, generator=gen) ** 0.3          # most rows dense, some nearly empty
+        dens[3] = 0.0
+        dens[n - 1] = 1.0
+        adj = torch.rand((n, n), device=dev, generator=gen) < dens
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = adj.sum(1).cumsum(0)
+        colidx = adj.nonzero()[:, 1].to(torch.int32).contiguous()
+        vals = (torch.rand(colidx.numel(), device=dev, generator=gen) * 3 - 1).contiguous()
+        for values in (None, vals):
+            g = CSRGraph(rowptr, colidx, n, values=values)
+            assert g.sorted_rows() and g.nnz * 2 >= n * n
+            a1, a2 = (torch.randn((8, 8), device=dev, generator=gen) * 0.3 for _ in range(2))
+            b1, b2 = (torch.randn(8, device=dev, generator=gen) * 0.1 for _ in range(2))
+            c = torch.randn(64, device=dev, generator=gen) * 0.1
+            X = torch.randn((n, 20), device=dev, generator=gen)
+            W = torch.randn((20, 64), device=dev, generator=gen) * 0.2
+            H, f1, f2 = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.5, fts_drop=0.5, seed=11)
+            res = []
+            for tiled in (True, False):
+                ops.TILED = tiled
+                try:
+                    oe, _ = ops.node_attn_fwd(g, H, f1, a2, b2, c, f2=f2)
+                    ot, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, train=True, coef_drop=0.5, fts_drop=0.5, seed=11, f2=f2)
+                finally:
+                    ops.TILED = True
+                res.append((oe, ot) + sv)
+            for a_, b_ in zip(*res):
+                scale = float(b_.abs().max()) + 1.0
+                assert float((a_ - b_).abs().max()) < 2e-5 * scale
+            assert float(res[0][0][3].abs().max()) < 1.0 and torch.isfinite(res[0][1]).all()      # the empty row: act(c)
+
+
 def test_return_coef_and_hetegat_class(dev):
     """attn_head(..., return_coef=True) (layers.py:43-44) and HeteGAT.inference(...,
     return_coef=True) (models/gat.py:132-203: shared inputs, head-mean coefficients per
