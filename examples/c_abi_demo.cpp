@@ -154,9 +154,9 @@ int main(int argc, char **argv) {
     if (wb_sp) HIP_OK(hipMalloc(&ws_sp, wb_sp));
     if (wb_pb) HIP_OK(hipMalloc(&ws_pb, wb_pb));
     HAN_OK(han_node_attn_fwd(drp, dci, nullptr, dH, HAN_DTYPE_F32, nullptr, df1, nullptr, da2, db2, dc, nullptr, dM, D,
-                             dpre, dlse, daggp, dtsum, N, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0,
+                             nullptr, dlse, daggp, dtsum, N, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0,
                              HAN_ACT_ELU, 0, nullptr, st));
-    HAN_OK(han_node_attn_bwd_rows(ddOut, D, dpre, daggp, dtsum, df1, dlse, dc, nullptr, dgs, HAN_DTYPE_F32, ddf1,
+    HAN_OK(han_node_attn_bwd_rows(ddOut, D, dM, D, daggp, dtsum, df1, dlse, dc, nullptr, dgs, HAN_DTYPE_F32, ddf1,
                                   ddc, ws_rows, wb_rows, N, K, FP, HAN_ACT_ELU, st));
     HAN_OK(han_node_attn_bwd_cols(dcp, dri, nullptr, dgs, nullptr, dH, HAN_DTYPE_F32, df2, ddf1, da1, da2, ddH,
                                   ddf2, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0, 0, 0, nullptr, st));

@@ -49,7 +49,7 @@ SIGNATURES = {
                                     c_uint64, P, I64, P]),
     "han_node_attn_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
     "han_gs_row_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "han_node_attn_bwd_rows": (c_int, [P, I64, P, P, P, P, P, P, P, P, c_int, P, P, P, c_size_t, I64,
+    "han_node_attn_bwd_rows": (c_int, [P, I64, P, I64, P, P, P, P, P, P, P, c_int, P, P, P, c_size_t, I64,
                                        c_int, c_int, c_int, P]),
     "han_node_attn_bwd_cols": (c_int, [P, P, P, P, P, P, c_int, P, P, P, P, P, P, I64, I64, c_int, c_int,
                                        c_float, c_float, c_float, c_uint64, P, I64, I64, c_int, P, P]),

@@ -258,7 +258,7 @@ __device__ __forceinline__ void write_row(const FwdArgs &a, const int64_t row, c
             float4_t ap;
 #pragma unroll
             for (int t = 0; t < 4; ++t) ap[t] = st.accp[t] * scale;
-            *reinterpret_cast<float4_t *>(a.pre + row * HAN_D + 4 * q) = pv;
+            if (a.pre) *reinterpret_cast<float4_t *>(a.pre + row * HAN_D + 4 * q) = pv;      // optional: the backward reads `out`
             *reinterpret_cast<float4_t *>(a.aggp + row * HAN_D + 4 * q) = ap;
             if ((4 * q) % FP == 0) {
                 a.lse[row * K + head] = st.l > 0.f ? st.m + __logf(st.l) : HAN_NEG_BIG;
@@ -725,7 +725,9 @@ __global__ __launch_bounds__(256) void node_attn_fwd_finish_kernel(const FwdArgs
 struct BwdRowsArgs {
     const float *dOut;
     int64_t dout_stride;
-    const float *pre, *aggp, *tsum, *f1, *lse, *c;
+    const float *out;      // the forward's OUTPUT rows (after the activation): ELU is inverted, the pre-activation is not stored
+    int64_t out_stride;
+    const float *aggp, *tsum, *f1, *lse, *c;
     const float *res;   // residual term that was added to pre (or null)
     void *gs;      // fused [g | stats] rows (GsRow), g in fp32 or bf16
     float *df1;
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsAr
     // all 16 lanes of a group run the same trip count -> the in-head sums are safe
     for (int64_t row = grp0; row < a.N; row += ngrp) {
         const float4_t d4 = *reinterpret_cast<const float4_t *>(a.dOut + row * a.dout_stride + 4 * q);
-        const float4_t p4 = *reinterpret_cast<const float4_t *>(a.pre + row * HAN_D + 4 * q);
+        const float4_t o4 = *reinterpret_cast<const float4_t *>(a.out + row * a.out_stride + 4 * q);
         const float4_t ap4 = *reinterpret_cast<const float4_t *>(a.aggp + row * HAN_D + 4 * q);
         float4_t g4;
         float4_t r4 = {0.f, 0.f, 0.f, 0.f};
@@ -754,14 +756,18 @@ __global__ __launch_bounds__(256) void node_attn_bwd_rows_kernel(const BwdRowsAr
         float sp = 0.f, dp = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float da = (a.activation == HAN_ACT_ELU && p4[t] <= 0.f) ? __expf(p4[t]) : 1.f;
+            // ELU'(pre) and pre from the output: out > 0: 1, out;  out <= 0: out + 1 (= e^pre), log(out + 1).  An output
+            // that rounded to -1 has derivative 0; its pre-activation (below -17) is then irrelevant: any finite value
+            const bool neg = a.activation == HAN_ACT_ELU && o4[t] <= 0.f;
+            const float da = neg ? o4[t] + 1.f : 1.f;
+            const float pt = neg ? (da > 0.f ? __logf(da) : 0.f) : o4[t];
             g4[t] = d4[t] * da;
             dc[t] += g4[t];                             // dc = sum_i g_i: row-local, exact g
             // bf16 g table: every consumer (the transposed-graph pass) sees the ROUNDED g, so the
             // row-local sums s_i and df1_i are formed from the rounded value too -- otherwise
             // sum_j dl_ij (gathered side) and df1_i (this side) disagree by the rounding of g
             if (BF) g4[t] = __uint_as_float(han_f32_to_bf16_bits(g4[t]) << 16);
-            sp += g4[t] * (p4[t] - c4[t] - r4[t]);      // g . (the aggregate alone)
+            sp += g4[t] * (pt - c4[t] - r4[t]);         // g . (the aggregate alone)
             dp += g4[t] * ap4[t];
         }
         sp = head_sum<FP>(sp);
@@ -1354,7 +1360,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
     if ((flags & HAN_FLAG_TILED) && !f2_src) return HAN_E_BADARG;      // the tiled kernels read the scores from the table
     const bool train = pre || lse || aggp || tsum;
-    if (train && !(pre && lse && aggp && tsum)) return HAN_E_BADARG;
+    if (train && !(lse && aggp && tsum)) return HAN_E_BADARG;      // pre is optional: the backward works from `out`
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
     if ((coef_drop > 0.f || fts_drop > 0.f) && !train) return HAN_E_BADARG;
     if (N == 0) return 0;
@@ -1412,20 +1418,20 @@ extern "C" size_t han_node_attn_bwd_workspace(int64_t N, int K, int FP) {
     return (size_t)kReduceBlocks * 64 * sizeof(float);
 }
 
-extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *pre,
+extern "C" int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *out, int64_t out_stride,
                                       const float *aggp, const float *tsum, const float *f1,
                                       const float *lse, const float *c, const float *res, void *gs,
                                       int table_dtype, float *df1, float *dc, void *workspace,
                                       size_t workspace_bytes, int64_t N, int K, int FP, int activation,
                                       void *stream) {
-    if (!dOut || !pre || !aggp || !tsum || !f1 || !lse || !c || !gs || !df1 || !dc || !workspace ||
-        N < 0 || dout_stride < HAN_D)
+    if (!dOut || !out || !aggp || !tsum || !f1 || !lse || !c || !gs || !df1 || !dc || !workspace ||
+        N < 0 || dout_stride < HAN_D || out_stride < HAN_D)
         return HAN_E_BADARG;
     if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
     if (workspace_bytes < han_node_attn_bwd_workspace(N, K, FP)) return HAN_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     BwdRowsArgs a;
-    a.dOut = dOut; a.dout_stride = dout_stride; a.pre = pre; a.aggp = aggp; a.tsum = tsum;
+    a.dOut = dOut; a.dout_stride = dout_stride; a.out = out; a.out_stride = out_stride; a.aggp = aggp; a.tsum = tsum;
     a.f1 = f1; a.lse = lse; a.c = c; a.res = res; a.gs = gs; a.df1 = df1;
     a.slab = (float *)workspace; a.N = N; a.activation = activation;
     const int grid = han_grid_for(N, 16, kReduceBlocks);

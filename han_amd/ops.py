@@ -337,7 +337,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
     this table instead of being recomputed (slices of a head wider than 64 columns: f1 / f2_src hold the head's
     totals).  f2 (NT,K): the table rows' scores as project_fwd returned them -- with them a small dense graph
     (_use_tiles) runs on the LDS-tiled kernels, which read the scores instead of recomputing them.
-    Returns out, saved where saved = (pre, lse, aggp, tsum) if train else None."""
+    Returns out, saved where saved = (out, lse, aggp, tsum) if train else None: saved[0] is the OUTPUT view itself,
+    which node_attn_bwd_rows reads (it must stay unmodified until then); the pre-activation is not stored."""
     lib = _lib.load()
     K, FP = a2.shape
     _check_heads(K, FP)
@@ -376,12 +377,13 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
     saved = None
     ptrs = [None, None, None, None]
     if train:
-        pre = torch.empty((N, D), dtype=torch.float32, device=dev)
+        # the pre-activation is not stored (round 3): the backward inverts the activation on `out`, which the
+        # caller keeps anyway (it is a slice of M, the input of K3) -- 256 B per row less to write, keep and read
         aggp = torch.empty((N, D), dtype=torch.float32, device=dev)
         lse = torch.empty((N, K), dtype=torch.float32, device=dev)
         tsum = torch.empty((N, K), dtype=torch.float32, device=dev)
-        saved = (pre, lse, aggp, tsum)
-        ptrs = [pre.data_ptr(), lse.data_ptr(), aggp.data_ptr(), tsum.data_ptr()]
+        saved = (out, lse, aggp, tsum)
+        ptrs = [None, lse.data_ptr(), aggp.data_ptr(), tsum.data_ptr()]
     split, _keep = _row_split_arg(graph, "f")
     timing = K2_TIMING
     if timing is not None:
@@ -447,20 +449,22 @@ def gs_views(gs, K=8, FP=8, table_dtype=torch.float32):
     return g, stats
 
 
-def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=8, FP=8,
+def node_attn_bwd_rows(dOut, out, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=8, FP=8,
                        table_dtype=torch.float32, res=None, dc_out=None, gs_out=None):
-    """Row-local half of the K2 backward.  dOut (N,D) view (unit inner stride).
+    """Row-local half of the K2 backward.  dOut (N,D) view (unit inner stride); out (N,D) view: the forward's
+    output rows (saved[0] of node_attn_fwd), from which the pre-activation is recovered.
     Returns gs (N, row_bytes) uint8 -- the fused table [g | (f1, lse, s, 0) x K] the transposed-graph
     pass gathers from (gs_views() splits it) --, df1 (N,K), dc (D,) [written to dc_out when given].
     gs_out: optional preallocated destination (e.g. the local block of an exchange table)."""
     lib = _lib.load()
     _check_heads(K, FP)
-    N = pre.shape[0]
-    dev = pre.device
+    N = out.shape[0]
+    dev = out.device
     _chk(dOut, "dOut", (N, D), device=dev, contiguous=False)
-    if dOut.stride(1) != 1:
-        raise ValueError("dOut: rows must be contiguous")
-    for t, n, s in ((pre, "pre", (N, D)), (aggp, "aggp", (N, D)), (tsum, "tsum", (N, K)),
+    _chk(out, "out", (N, D), device=dev, contiguous=False)
+    if dOut.stride(1) != 1 or out.stride(1) != 1:
+        raise ValueError("dOut / out: rows must be contiguous")
+    for t, n, s in ((aggp, "aggp", (N, D)), (tsum, "tsum", (N, K)),
                     (f1, "f1", (N, K)), (lse, "lse", (N, K)), (c, "c", (D,))):
         _chk(t, n, s, device=dev)
     rb = gs_row_bytes(K, FP, table_dtype)
@@ -473,7 +477,7 @@ def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=ACT_ELU, K=
     dc = _out(dc_out, "dc_out", (D,), dev)
     ws = _ws(lib.han_node_attn_bwd_workspace(N, K, FP), dev, "rows")
     _lib.check(lib.han_node_attn_bwd_rows(
-        dOut.data_ptr(), dOut.stride(0) if N > 1 else D, pre.data_ptr(), aggp.data_ptr(),
+        dOut.data_ptr(), dOut.stride(0) if N > 1 else D, out.data_ptr(), out.stride(0) if N > 1 else D, aggp.data_ptr(),
         tsum.data_ptr(), f1.data_ptr(), lse.data_ptr(), c.data_ptr(),
         res.data_ptr() if res is not None else None, gs.data_ptr(),
         DTYPE_CODE[table_dtype], df1.data_ptr(), dc.data_ptr(), ws.data_ptr(), ws.numel(), N, K, FP,

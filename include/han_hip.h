@@ -184,7 +184,8 @@ size_t han_row_split_workspace(int64_t n_chunks);
  * layers.py:95-98) -- NULL is the binary adjacency every shipped config uses.
  * f1 (N,K) for the local rows; a2 (K,FP); b2 (K); c (D).  out row i is written
  * at out + i*out_stride (so the K heads land directly in M[:,p,:],
- * models/gat.py:46,58-60).  Training extras (all or none may be NULL): pre (N,D)
+ * models/gat.py:46,58-60).  Training extras (lse, aggp, tsum: all or none NULL; pre: optional, the
+ * backward does not need it): pre (N,D)
  * pre-activation, lse (N,K) log-sum-exp of the scores, aggp (N,D) and tsum (N,K)
  * -- the LeakyReLU'-weighted aggregates that make df1 row-local in the backward.
  * NT: rows of the table H (the tiled kernels walk it; 0 = unknown, gather kernels only).
@@ -221,8 +222,10 @@ int han_node_attn_coefs(const int64_t *rowptr, const int32_t *colidx, const floa
  * per meta-path (one collective instead of one for g and one for the statistics).            */
 size_t han_gs_row_bytes(int K, int FP, int table_dtype);
 
-/* Backward, step 1 (row-local): from dOut (N,D; row stride dout_stride) and
- * the saved pre/aggp/tsum/f1/lse compute
+/* Backward, step 1 (row-local): from dOut (N,D; row stride dout_stride), the forward's OUTPUT rows `out`
+ * (N,D; row stride out_stride -- e.g. M[:,p,:]) and the saved aggp/tsum/f1/lse compute
+ *   pre = act^-1(out): identity, or for ELU  out > 0: out,  out <= 0: log(out + 1)  (round 3: the pre-activation
+ *         is no longer stored -- 256 B per row less to write, to keep and to read; act'(pre) = out > 0 ? 1 : out + 1)
  *   g = dOut * act'(pre)   (rounded to table_dtype; the sums below use the rounded value)
  *   s_i[k] = g_i[k] . (pre_i - c)[k]
  *   df1_i[k] = g_i[k] . aggp_i[k] - s_i[k] * tsum_i[k]        -> df1 (N,K)
@@ -230,7 +233,7 @@ size_t han_gs_row_bytes(int K, int FP, int table_dtype);
  *   dc += sum_i g_i  (written, not accumulated; unrounded g)  -> dc (D)
  * workspace: han_node_attn_bwd_workspace() bytes.                          */
 size_t han_node_attn_bwd_workspace(int64_t N, int K, int FP);
-int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *pre,
+int han_node_attn_bwd_rows(const float *dOut, int64_t dout_stride, const float *out, int64_t out_stride,
                            const float *aggp, const float *tsum, const float *f1,
                            const float *lse, const float *c, const float *res, void *gs,
                            int table_dtype, float *df1, float *dc, void *workspace,

@@ -161,7 +161,7 @@ def node_attn_fwd(graph, H_tab, f1, a2, b2, c, out=None, train=False, coef_drop=
         tsum = torch.zeros((N, K), dtype=torch.float64).index_add(0, rows, alpha * sg)
         empty = graph.degrees() == 0
         lse = torch.where(empty[:, None], torch.full_like(lse, -1e30), lse)
-        saved = tuple(t.to(torch.float32) for t in (pre, lse, aggp, tsum))
+        saved = (out,) + tuple(t.to(torch.float32) for t in (lse, aggp, tsum))      # saved[0] = the output view (ops contract)
     return out, saved
 
 
@@ -179,11 +179,16 @@ def gs_views(gs, K=8, FP=8, table_dtype=torch.float32):
     return gs[:, :gb].view(table_dtype), gs[:, gb:gb + 16 * K].view(torch.float32).unflatten(1, (K, 4))
 
 
-def node_attn_bwd_rows(dOut, pre, aggp, tsum, f1, lse, c, activation=1, K=8, FP=8,
+def node_attn_bwd_rows(dOut, out, aggp, tsum, f1, lse, c, activation=1, K=8, FP=8,
                        table_dtype=torch.float32, res=None, dc_out=None, gs_out=None):
-    N = pre.shape[0]
-    p = _f64(pre)
-    da = torch.where(p <= 0, torch.exp(p), torch.ones_like(p)) if activation == 1 else torch.ones_like(p)
+    N = out.shape[0]
+    o = _f64(out)
+    if activation == 1:       # the pre-activation from the output: ELU inverted (han_node_attn_bwd_rows)
+        da = torch.where(o <= 0, o + 1.0, torch.ones_like(o))
+        p = torch.where(o <= 0, torch.log(da.clamp_min(1e-300)), o)
+        p = torch.where(da > 0, p, torch.zeros_like(p))
+    else:
+        da, p = torch.ones_like(o), o
     g = _f64(dOut) * da
     dc = g.sum(0)
     g = _f64(g.to(torch.float32).to(table_dtype))     # the stored g is what both backward halves use
