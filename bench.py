@@ -701,12 +701,18 @@ def main():
             "config": {"workload": f"{args.workload}: N={n} nodes, P={p} meta-paths, "
                                    f"E={e_global} "
                                    f"edges, F={wl['f']}, K=8 heads x F'=8, A=128, C={wl['c']}",
-                       "graph_recipe": "per row the self-loop + (deg-1) uniform neighbours drawn with a torch "
-                                       "generator on the device, duplicates kept (multigraph terms), columns sorted "
-                                       "per row -- deviates from SURVEY.md 8d's distinct-neighbour / "
-                                       "numpy default_rng(1234+p) recipe; byte counts are identical",
+                       "graph_recipe": ("per row the self-loop + (deg-1) uniform neighbours drawn with a torch "
+                                        "generator on the device, duplicates kept (multigraph terms), columns sorted "
+                                        "per row -- deviates from SURVEY.md 8d's distinct-neighbour / "
+                                        "numpy default_rng(1234+p) recipe; byte counts are identical")
+                       if args.workload.startswith("syn-") else
+                       "han_amd.synth: symmetric Bernoulli(density) adjacency + I per meta-path at the data set's edge "
+                       "counts (dense generation, ids ascending per row)",
                        "parallelism": f"node-partition x{world}" if world > 1 else
                        ("single GPU, epoch replayed from a hipGraph" if use_graph else "single GPU"),
+                       **({"captured_epoch": {"c_abi_calls": getattr(trainer, "graph_abi_calls", None),
+                                              "kernel_nodes_per_epoch": "profiles/r03_*_like_graph_kernel_stats.csv "
+                                                                        "(calls / 53 epochs)"}} if use_graph else {}),
                        **({"exchange": exchange} if exchange is not None else {}),
                        **({"replication": trainer_replicate_info} if trainer_replicate_info else {}),
                        **({"reorder": reorder_info} if reorder_info is not None else {}),

@@ -135,7 +135,12 @@ def load():
     return lib
 
 
+CALLS = 0      # C-ABI entry-point calls so far in this process (bench.py: calls recorded into a captured epoch)
+
+
 def check(code: int, what: str = ""):
+    global CALLS
+    CALLS += 1
     if code != 0:
         msg = load().han_error_string(code)
         raise HanLibraryError(f"{what or 'libhan_hip'} failed ({code}): "

@@ -266,9 +266,12 @@ class HANTrainer:
                 out = self._epoch_body()
             torch.cuda.current_stream().wait_stream(side)
             return out
+        from . import _lib
         g = torch.cuda.CUDAGraph()
+        calls0 = _lib.CALLS
         with torch.cuda.graph(g):
             self._static_out = self._epoch_body()   # recorded, not run (opt.t advanced by step())
+        self.graph_abi_calls = _lib.CALLS - calls0   # C-ABI calls recorded into the epoch (each is 1-3 kernel nodes)
         self._graph = g
         g.replay()
         return self._static_out
