@@ -427,7 +427,9 @@ __device__ __forceinline__ uint32_t tiled_field(const uint32_t hx, const uint32_
     return (head & 1) ? (wsel >> 16) : (wsel & 0xFFFFu);
 }
 
-template <int FP, bool TRAIN, bool VAL, bool MASKED>
+// LEAN: the same step with the rows and scores gathered from global memory (tables that live in the L2s): the
+// projected-row dropout is then applied per edge and the score is scaled as it is used
+template <int FP, bool TRAIN, bool VAL, bool MASKED, bool LEAN = false>
 __device__ __forceinline__ void tiled_fwd_step(const FwdArgs &a, const float *tileH, const float *tileF, const int4 jj,
                                                const float4_t wv4, const int r, const uint32_t hoff, const uint32_t foff,
                                                const int j0, const float f1s, const uint32_t gi, const int g, const int q,
@@ -443,8 +445,13 @@ __device__ __forceinline__ void tiled_fwd_step(const FwdArgs &a, const float *ti
     for (int u = 0; u < 4; ++u) {
         valid[u] = !MASKED || (4 * g + u) < r;
         if (MASKED) j[u] = valid[u] ? j[u] : j0;           // a slot past the piece must not index outside the tile
-        hv[u] = *reinterpret_cast<const float4_t *>(tileH + ((uint32_t)j[u] * HAN_D + hoff));
-        f2v[u] = tileF[(uint32_t)j[u] * K + foff];
+        if (LEAN) {
+            hv[u] = *reinterpret_cast<const float4_t *>(tileH + ((int64_t)j[u] * HAN_D + hoff));
+            f2v[u] = tileF[(int64_t)j[u] * K + foff];
+        } else {
+            hv[u] = *reinterpret_cast<const float4_t *>(tileH + ((uint32_t)j[u] * HAN_D + hoff));
+            f2v[u] = tileF[(uint32_t)j[u] * K + foff];
+        }
     }
     uint32_t hx = 0, hy = 0;
     if (TRAIN && drop_c) {      // one hash per (edge, four heads): lane q of the group takes edge q & 3, head quad (q >> 2) % KQ
@@ -458,8 +465,15 @@ __device__ __forceinline__ void tiled_fwd_step(const FwdArgs &a, const float *ti
     float mc = m;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        float x = f1s + f2v[u];                             // (f1_i + f2_j) * log2 e
+        float x = LEAN ? __builtin_fmaf(f2v[u], kLog2e, f1s) : f1s + f2v[u];      // (f1_i + f2_j) * log2 e
         if (VAL) x *= wv4[u];
+        if (LEAN && TRAIN && a.lsb_mask) {                  // layers.py:31-32 per edge (the tiled form does it per staged element)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int bits = __float_as_int(hv[u][t]);
+                hv[u][t] = __int_as_float(bits & han_bit_mask<0>(bits));
+            }
+        }
         if (TRAIN) {
             sg[u] = x > 0.f ? 1.f : a.slope;
             if (VAL) sg[u] *= wv4[u];
@@ -625,6 +639,86 @@ __global__ __launch_bounds__(kTileBlock) void node_attn_fwd_tiled_kernel(const F
     st.merge(16);
     st.merge(32);
     write_row<FP, TRAIN>(a, row, st, q, head, c4, row_ok && g == 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same lean per-edge arithmetic WITHOUT tiles (HAN_FLAG_LEAN): small graphs whose table lives in the L2s (a few
+// thousand rows) but are not dense enough for the tiled form to pay (ACM PSP 24 %, DBLP APCPA 30 %).  One wave per
+// row, rows and scores gathered from global memory (the 4-byte score gather is what a large table could not afford: a
+// line per edge), the same steps of 16 edges, ids one piece ahead; whole rows of any length, any id order.
+// ---------------------------------------------------------------------------------------------
+template <int FP, bool TRAIN, bool VAL>
+__global__ __launch_bounds__(256) void node_attn_fwd_lean_kernel(const FwdArgs a_in) {
+    FwdArgs a = a_in;
+    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
+    constexpr int K = HAN_D / FP;
+    __shared__ __attribute__((aligned(16))) int colw_all[4 * 64];
+    __shared__ __attribute__((aligned(16))) float valw_all[VAL ? 4 * 64 : 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int *colw = colw_all + wv * 64;
+    float *valw = valw_all + (VAL ? wv * 64 : 0);
+    const int g = lane >> 4, q = lane & 15;
+    const int head = (4 * q) / FP;
+    const float4_t c4 = *reinterpret_cast<const float4_t *>(a.c + 4 * q);
+    const bool drop_c = TRAIN && a.thr_coef < HAN_KEEP_ALL;
+    const float *Hf = reinterpret_cast<const float *>(a.H);
+    int baddr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) baddr[u] = (g * 16 + u + 4 * (head >> 2)) * 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave0; row < a.N; row += nwaves) {
+        int64_t cur = a.rowptr[row];
+        const int64_t e = a.rowptr[row + 1];
+        const float f1s = a.f1[row * K + head] * kLog2e;
+        const uint32_t gi = (uint32_t)(row + a.row_offset);
+        float m = HAN_NEG_BIG, l = 0.f, tl = 0.f;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, accp[4] = {0.f, 0.f, 0.f, 0.f};
+        auto load_ids = [&](const int64_t at, int &col, float &val) {
+            const int left = (int)((e - at) < 64 ? (e - at) : 64);
+            if (left > 0) {
+                col = a.colidx[at + (lane < left ? lane : left - 1)];
+                if (VAL) val = a.edge_val[at + (lane < left ? lane : left - 1)];
+            }
+        };
+        int nxt_col = 0;
+        float nxt_val = 1.f;
+        load_ids(cur, nxt_col, nxt_val);
+        while (cur < e) {                                   // wave-uniform
+            const int cnt = (int)((e - cur) < 64 ? (e - cur) : 64);
+            const int mycol = nxt_col;
+            const float myval = nxt_val;
+            load_ids(cur + cnt, nxt_col, nxt_val);
+            colw[lane] = mycol;
+            if (VAL) valw[lane] = myval;
+            const int nfull = cnt >> 4;
+            int4 jj = *reinterpret_cast<const int4 *>(colw + 4 * g);
+            float4_t w4 = {1.f, 1.f, 1.f, 1.f};
+            if (VAL) w4 = *reinterpret_cast<const float4_t *>(valw + 4 * g);
+            for (int it = 0; it < nfull; ++it) {
+                const int nx = ((it + 1) & 3) * 16 + 4 * g;
+                const int4 jn = *reinterpret_cast<const int4 *>(colw + nx);
+                float4_t wn = {1.f, 1.f, 1.f, 1.f};
+                if (VAL) wn = *reinterpret_cast<const float4_t *>(valw + nx);
+                tiled_fwd_step<FP, TRAIN, VAL, false, true>(a, Hf, a.f2g, jj, w4, 16, (uint32_t)(4 * q), (uint32_t)head, 0, f1s, gi, g,
+                                                            q, head, drop_c, baddr, m, l, tl, acc, accp);
+                jj = jn;
+                w4 = wn;
+            }
+            if (nfull * 16 < cnt)
+                tiled_fwd_step<FP, TRAIN, VAL, true, true>(a, Hf, a.f2g, jj, w4, cnt - nfull * 16, (uint32_t)(4 * q), (uint32_t)head, 0,
+                                                           f1s, gi, g, q, head, drop_c, baddr, m, l, tl, acc, accp);
+            cur += cnt;
+        }
+        RowState<TRAIN> st;
+        st.m = m * kLn2;
+        st.l = l;
+        st.tl = tl;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { st.acc[t] = acc[t]; st.accp[t] = accp[t]; }
+        st.merge(16);
+        st.merge(32);
+        write_row<FP, TRAIN>(a, row, st, q, head, c4, g == 0);
+    }
 }
 
 // Split rows, step 1: one wave per chunk of a long row -> un-normalised partial state.
@@ -1326,6 +1420,13 @@ static hipError_t launch_fwd_tiled_v(const FwdArgs &a, bool train, int64_t NT, h
     return e;
 }
 
+template <int FPC, bool VAL>
+static void launch_fwd_lean_v(const FwdArgs &a, bool train, hipStream_t st) {
+    const int grid = attn_grid(a.N);
+    if (train) node_attn_fwd_lean_kernel<FPC, true, VAL><<<grid, 256, 0, st>>>(a);
+    else node_attn_fwd_lean_kernel<FPC, false, VAL><<<grid, 256, 0, st>>>(a);
+}
+
 // the binary-adjacency instantiation (every shipped config) carries no edge-value registers
 template <int FPC, bool BF>
 static void launch_fwd(const FwdArgs &a, bool train, bool low, bool has_split, hipStream_t st) {
@@ -1358,7 +1459,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
         return HAN_E_BADARG;
     if (!split_ok(split)) return HAN_E_BADARG;
     if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
-    if ((flags & HAN_FLAG_TILED) && !f2_src) return HAN_E_BADARG;      // the tiled kernels read the scores from the table
+    if ((flags & (HAN_FLAG_TILED | HAN_FLAG_LEAN)) && !f2_src) return HAN_E_BADARG;      // these kernels read the scores from the table
     const bool train = pre || lse || aggp || tsum;
     if (train && !(lse && aggp && tsum)) return HAN_E_BADARG;      // pre is optional: the backward works from `out`
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
@@ -1391,6 +1492,13 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
         if (edge_val) { HAN_DISPATCH_FP(FP, { te = launch_fwd_tiled_v<FPC, true>(a, train, table_rows, st); }) }
         else { HAN_DISPATCH_FP(FP, { te = launch_fwd_tiled_v<FPC, false>(a, train, table_rows, st); }) }
         if (te != hipSuccess) return (int)te;
+        HAN_CHECK_LAUNCH();
+        return 0;
+    }
+    if ((flags & HAN_FLAG_LEAN) && table_dtype == HAN_DTYPE_F32 && !table_gid && f2_src) {
+        // small graph, table in the L2s: scores gathered, one hash per (edge, four heads); whole rows (no row split)
+        if (edge_val) { HAN_DISPATCH_FP(FP, { launch_fwd_lean_v<FPC, true>(a, train, st); }) }
+        else { HAN_DISPATCH_FP(FP, { launch_fwd_lean_v<FPC, false>(a, train, st); }) }
         HAN_CHECK_LAUNCH();
         return 0;
     }

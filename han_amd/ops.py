@@ -17,6 +17,7 @@ ACT_IDENTITY = 0
 ACT_ELU = 1
 FLAG_XCD_ORDER = 1         # HAN_FLAG_XCD_ORDER: XCD-aware work order for graphs with locality
 FLAG_TILED = 128           # HAN_FLAG_TILED: LDS-tiled K2 kernels for small dense graphs with ascending ids per row
+FLAG_LEAN = 256            # HAN_FLAG_LEAN: the lean per-edge arithmetic with gathered rows / scores (small tables, long rows)
 FLAG_MASKED_EDGES = 64     # HAN_FLAG_MASKED_EDGES: negative entries of the transposed graph are skipped in place
 FLAG_K1_EXACT_PIPE = 2     # HAN_FLAG_K1_EXACT_PIPE / _MATRIX_PIPE: force one of the two K1 forward kernels (tests, measurements)
 FLAG_K1_MATRIX_PIPE = 4
@@ -150,6 +151,16 @@ def _use_tiles(graph: CSRGraph, table) -> bool:
     profiles/r03_k2_tiled_vs_gather.jsonl).  They need fp32 rows and ascending ids within every row."""
     return (TILED and table.dtype == torch.float32 and graph.n_rows > 0
             and graph.nnz * 2 >= graph.n_rows * graph.n_cols and graph.sorted_rows())
+
+
+LEAN = True                # tests / measurements: False keeps the classic gather kernels
+
+
+def _use_lean(graph: CSRGraph, table) -> bool:
+    """The lean K2 forward (HAN_FLAG_LEAN): tables that live in the L2s (<= 16384 rows: 4 MB) with long rows (mean
+    degree >= 64), where the classic gather kernels are bound by vector-instruction issue, not by memory."""
+    return (LEAN and table.dtype == torch.float32 and 0 < graph.n_cols <= 16384
+            and graph.nnz >= 64 * graph.n_rows)
 
 
 def _check_heads(K: int, FP: int):
@@ -360,7 +371,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         _chk(f2_src, "f2_src", (graph.n_cols, 1), device=dev)
         f2 = f2_src
     tiled = f2 is not None and table_gid is None and _use_tiles(graph, H_tab)
-    if tiled:
+    lean = f2 is not None and table_gid is None and not tiled and _use_lean(graph, H_tab)
+    if tiled or lean:
         _chk(f2, "f2", (graph.n_cols, K), device=dev)
     if graph.device != dev:
         raise ValueError("graph and tables must be on the same device")
@@ -393,12 +405,12 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         graph.rowptr.data_ptr(), graph.colidx.data_ptr(),
         graph.values.data_ptr() if graph.values is not None else None, H_tab.data_ptr(), tcode,
         table_gid.data_ptr() if table_gid is not None else None, f1.data_ptr(),
-        f2.data_ptr() if (tiled or f2_src is not None) else None,
+        f2.data_ptr() if (tiled or lean or f2_src is not None) else None,
         a2.data_ptr(), b2.data_ptr(), c.data_ptr(), res.data_ptr() if res is not None else None,
         out.data_ptr(), out.stride(0) if N > 1 else D,
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.n_cols, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
         int(seed), _dev_word(seed_dev), int(row_offset), int(activation),
-        (FLAG_XCD_ORDER if graph.has_locality() else 0) | (FLAG_TILED if tiled else 0),
+        (FLAG_XCD_ORDER if graph.has_locality() else 0) | (FLAG_TILED if tiled else 0) | (FLAG_LEAN if lean else 0),
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_fwd")
     if timing is not None:
         ev1.record()

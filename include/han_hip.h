@@ -50,6 +50,11 @@ extern "C" {
                                   applied once per staged element and the attention-dropout hash once per (edge, four heads).
                                   Such graphs are bound by vector-instruction issue, not by memory.  Taken for fp32 tables whose
                                   index is the global id (table_gid NULL); pays from about half-dense graphs on.              */
+#define HAN_FLAG_LEAN 256      /* han_node_attn_fwd on small graphs whose table lives in the L2s (a few thousand rows) with long rows:
+                                  the same lean per-edge arithmetic as HAN_FLAG_TILED (scores gathered from f2_src instead of
+                                  recomputed, one attention-dropout hash per (edge, four heads)) without the tiles -- any
+                                  density, any id order.  fp32 tables, table_gid NULL.  Not for large tables: the 4-byte score
+                                  gather would cost a memory line per edge there.                                              */
 #define HAN_FLAG_MASKED_EDGES 64 /* han_node_attn_bwd_cols: entries of rowidx below 0 are skipped IN PLACE (their destination's
                                   g row is identically zero -- a destination outside the loss mask of a one-layer model);
                                   the remaining terms are summed in the positions and order of the full pass, so the

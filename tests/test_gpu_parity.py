@@ -857,21 +857,25 @@ def test_sp_attn_head_weighted_adjacency_values(dev, drop, monkeypatch):
 
 @pytest.mark.parametrize("K,FP", [(8, 8), (16, 4), (4, 16), (2, 32), (1, 64)])
 @pytest.mark.parametrize("drop", [0.0, 0.6])
-def test_tiled_forward_on_dense_graphs_matches_oracle(dev, K, FP, drop, monkeypatch):
+@pytest.mark.parametrize("mode", ["tiled", "lean"])
+def test_tiled_forward_on_dense_graphs_matches_oracle(dev, K, FP, drop, mode, monkeypatch):
     """HAN_FLAG_TILED: graphs at least half dense (DBLP APTPA is 78 % dense) run their K2 forward on the LDS-tiled
     kernels -- table in 256-row tiles through LDS, scores read from the K1 table, projected-row dropout applied once
     per staged element, one attention-dropout hash per (edge, four heads) handed out by ds_bpermute.  n = 600 = two
     full tiles + a partial one, rows with several 64-entry pieces per tile and partial last steps; every head shape;
     inference and loss + all gradients with both dropouts on the oracle's exact masks; and the same numbers (to the
-    order of the sums) as the gather kernels."""
+    order of the sums) as the gather kernels.  mode "lean" (HAN_FLAG_LEAN): the same per-edge arithmetic with rows and
+    scores gathered from global memory -- what small graphs below half density run."""
     from han_amd import ops, rng as hrng
+    monkeypatch.setattr(ops, "TILED", mode == "tiled")
+    monkeypatch.setattr(ops, "LEAN", mode == "lean")
     n, f, p = 600, 13, 2
     prob = make_problem(300 + K, n, f, p, 3, [0.8, 0.55], hid_units=[FP], n_heads=(K, 1))
     model, bp = build_model(prob, dev)
     x, graphs = gpu_inputs(prob, dev)
     calls = []
-    real = ops._use_tiles
-    monkeypatch.setattr(ops, "_use_tiles", lambda g, t: calls.append(real(g, t)) or calls[-1])
+    real = ops._use_tiles if mode == "tiled" else ops._use_lean
+    monkeypatch.setattr(ops, "_use_tiles" if mode == "tiled" else "_use_lean", lambda g, t: calls.append(real(g, t)) or calls[-1])
     lg, fe, att = ho.hetegat_multi_inference([prob["x"]] * p, 3, n, False, 0.0, 0.0, prob["biases"], [FP], [K, 1],
                                              prob["params"])
     with torch.no_grad():
@@ -880,9 +884,11 @@ def test_tiled_forward_on_dense_graphs_matches_oracle(dev, K, FP, drop, monkeypa
     assert np.abs(logits[0].cpu().numpy() - lg[0]).max() < TOL
     assert np.abs(final_embed.cpu().numpy() - fe).max() < TOL
     monkeypatch.setattr(ops, "TILED", False)
-    with torch.no_grad():
+    monkeypatch.setattr(ops, "LEAN", False)
+    with torch.no_grad():      # the classic gather kernels on the same inputs
         logits_g = model.inference([x] * p, 3, n, False, 0.0, 0.0, graphs, [FP], [K, 1])[0]
-    monkeypatch.setattr(ops, "TILED", True)
+    monkeypatch.setattr(ops, "TILED", mode == "tiled")
+    monkeypatch.setattr(ops, "LEAN", mode == "lean")
     assert not calls[-1] and float((logits_g - logits).abs().max()) < 1e-5
     hrng.manual_seed(777)
     seeds = [hrng.next_seed() for _ in range(p)]
@@ -926,17 +932,18 @@ def test_tiled_forward_edge_values_and_ragged_rows(dev):
             W = torch.randn((20, 64), device=dev, generator=gen) * 0.2
             H, f1, f2 = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.5, fts_drop=0.5, seed=11)
             res = []
-            for tiled in (True, False):
-                ops.TILED = tiled
+            for mode in ("tiled", "lean", "gather"):
+                ops.TILED, ops.LEAN = mode == "tiled", mode == "lean"
                 try:
                     oe, _ = ops.node_attn_fwd(g, H, f1, a2, b2, c, f2=f2)
                     ot, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, train=True, coef_drop=0.5, fts_drop=0.5, seed=11, f2=f2)
                 finally:
-                    ops.TILED = True
-                res.append((oe, ot) + sv)
-            for a_, b_ in zip(*res):
-                scale = float(b_.abs().max()) + 1.0
-                assert float((a_ - b_).abs().max()) < 2e-5 * scale
+                    ops.TILED = ops.LEAN = True
+                res.append((oe, ot.clone()) + sv[1:])
+            for r in res[:2]:
+                for a_, b_ in zip(r, res[2]):
+                    scale = float(b_.abs().max()) + 1.0
+                    assert float((a_ - b_).abs().max()) < 2e-5 * scale
             assert float(res[0][0][3].abs().max()) < 1.0 and torch.isfinite(res[0][1]).all()      # the empty row: act(c)
 
 

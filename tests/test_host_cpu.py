@@ -79,6 +79,13 @@ def test_sorted_rows_property_gates_the_tiled_kernels():
     tab = torch.zeros((6, 64))
     assert dense.sorted_rows() and ops._use_tiles(dense, tab) and not ops._use_tiles(dense, tab.to(torch.bfloat16))
     assert not ops._use_tiles(g, torch.zeros((4, 64)))                 # 6 of 16 entries: below half dense
+    # the lean forward: tables that fit the L2s (<= 16384 rows) with long rows (mean degree >= 64), any id order
+    rp2 = torch.arange(0, 100 * 70 + 1, 70, dtype=torch.int64)
+    long_rows = CSRGraph(rp2, torch.randint(0, 100, (7000,), dtype=torch.int32), 100)
+    assert ops._use_lean(long_rows, torch.zeros((100, 64))) and not ops._use_lean(long_rows, torch.zeros((100, 64), dtype=torch.bfloat16))
+    assert not ops._use_lean(g, torch.zeros((4, 64)))
+    big = CSRGraph(torch.zeros(20001, dtype=torch.int64), torch.zeros(0, dtype=torch.int32), 20000)
+    assert not ops._use_lean(big, torch.zeros((20000, 64)))
 
 
 def test_partition_shards_cover_the_graph():

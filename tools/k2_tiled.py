@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""K2 on small dense graphs (the reference's own data-set shapes): the LDS-tiled kernels (HAN_FLAG_TILED) against
-the gather kernels on the same inputs -- time per launch and the largest difference of the outputs.
+"""K2 on small dense graphs (the reference's own data-set shapes): the LDS-tiled (HAN_FLAG_TILED) and lean (HAN_FLAG_LEAN)
+forward kernels against the gather kernels on the same inputs -- time per launch and the largest difference of the outputs.
 One JSON line per (graph, kernel).  `python tools/k2_tiled.py [n=4057 dens=0.78,0.30,0.24]`"""
 import json
 import os
@@ -30,9 +30,9 @@ def main():
         H, f1, f2 = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.6, fts_drop=0.6, seed=3)
         dOut = rnd(n, 64)
         res = {}
-        for tiled in (False, True):
-            ops.TILED = tiled
-            used = ops._use_tiles(g, H)
+        for mode in ("gather", "tiled", "lean"):
+            ops.TILED, ops.LEAN = mode == "tiled", mode == "lean"
+            used = ops._use_tiles(g, H) if mode == "tiled" else (ops._use_lean(g, H) if mode == "lean" else True)
             out_e, _ = ops.node_attn_fwd(g, H, f1, a2, b2, c, f2=f2)
             t_e = timeit(lambda: ops.node_attn_fwd(g, H, f1, a2, b2, c, f2=f2))
             out_t, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, train=True, coef_drop=0.6, fts_drop=0.6, seed=3, f2=f2)
@@ -40,15 +40,18 @@ def main():
             gs, df1, _ = ops.node_attn_bwd_rows(dOut, sv[0], sv[2], sv[3], f1, sv[1], c)
             dH, df2 = ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, coef_drop=0.6, fts_drop=0.6, seed=3)
             t_b = timeit(lambda: ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, coef_drop=0.6, fts_drop=0.6, seed=3))
-            res[tiled] = dict(used=used, eval_ms=t_e, train_ms=t_t, bwd_ms=t_b, out_e=out_e, out_t=out_t, pre=sv[0],
+            res[mode] = dict(used=used, eval_ms=t_e, train_ms=t_t, bwd_ms=t_b, out_e=out_e, out_t=out_t, pre=sv[0],
                               lse=sv[1], aggp=sv[2], tsum=sv[3], dH=dH, df2=df2)
-        a, b = res[False], res[True]
-        diff = {k: float((a[k] - b[k]).abs().max()) for k in ("out_e", "out_t", "pre", "lse", "aggp", "tsum", "dH", "df2")}
-        print(json.dumps({"n": n, "density": dens, "edges": g.nnz, "tiled_used": b["used"],
-                          "gather_ms": {k: round(a[k], 4) for k in ("eval_ms", "train_ms", "bwd_ms")},
-                          "tiled_ms": {k: round(b[k], 4) for k in ("eval_ms", "train_ms", "bwd_ms")},
-                          "max_abs_diff": {k: float(f"{v:.3g}") for k, v in diff.items()}}), flush=True)
-    ops.TILED = True
+        a = res["gather"]
+        line = {"n": n, "density": dens, "edges": g.nnz,
+                "gather_ms": {k: round(a[k], 4) for k in ("eval_ms", "train_ms", "bwd_ms")}}
+        for mode in ("tiled", "lean"):
+            b = res[mode]
+            diff = {k: float((a[k] - b[k]).abs().max()) for k in ("out_e", "out_t", "pre", "lse", "aggp", "tsum")}
+            line[mode] = {"taken": b["used"], "eval_ms": round(b["eval_ms"], 4), "train_ms": round(b["train_ms"], 4),
+                          "max_abs_diff": {k: float(f"{v:.3g}") for k, v in diff.items()}}
+        print(json.dumps(line), flush=True)
+    ops.TILED = ops.LEAN = True
 
 
 if __name__ == "__main__":
