@@ -919,6 +919,7 @@ struct BwdColsArgs {
     int64_t src_offset, dst_offset;
     int xcd_order;
     int masked;          // HAN_FLAG_MASKED_EDGES
+    int lean;            // HAN_FLAG_LEAN
     int64_t split_deg;
     int64_t n_long, n_chunks;
     const int64_t *long_rows, *long_ptr, *chunk_start, *chunk_end;
@@ -958,12 +959,28 @@ __device__ __forceinline__ SrcRow load_src(const BwdColsArgs &a, const int64_t s
 // identically zero: a destination outside the loss mask of a one-layer model); they keep their POSITION in the
 // row -- so every remaining term is added by the same lane group in the same order as in the full pass and the
 // sums are bit-identical -- but nothing is loaded for them.
-template <int FP, int U, bool BF, bool VAL, bool FAST, bool ALLV, bool MASKED = false>
+// DEDUP (U = 4 steps of HAN_FLAG_LEAN launches: small graphs, where this pass is bound by vector-instruction issue):
+// the attention-dropout hash of an edge serves four heads, so ONE lane of the 16-lane group computes it (lane q: edge
+// q & 3, head quad (q >> 2) % KQ) and the others fetch their 16-bit field with ds_bpermute, instead of all 16 hashing.
+template <int FP, int U, bool BF, bool VAL, bool FAST, bool ALLV, bool MASKED = false, bool DEDUP = false>
 __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)[U], const float (&ew)[U],
                                             const bool (&valid)[U], const SrcRow &sr, const int q, const int head, const bool drop_c,
                                             float (&acc)[4], float &dfacc) {
     constexpr int K = HAN_D / FP;
     constexpr int KQ = (K + 3) / 4;
+    static_assert(!DEDUP || (U == 4 && !MASKED), "the shared hash is built for full 4-edge steps");
+    uint32_t hx = 0, hy = 0;
+    int baddr0 = 0;
+    if (DEDUP && (FAST || drop_c)) {
+        const int uu = q & 3;
+        const int iu = uu == 0 ? i[0] : (uu == 1 ? i[1] : (uu == 2 ? i[2] : i[U - 1]));
+        const int64_t gid_i = ((!FAST && a.gid) ? (int64_t)a.gid[iu] : (int64_t)iu) + a.dst_offset;
+        const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, (uint32_t)gid_i,
+                                        sr.gj * (uint32_t)KQ + (uint32_t)((q >> 2) % KQ));
+        hx = rn.x;
+        hy = rn.y;
+        baddr0 = (int)(((__lane_id() & 48) + 4 * (head >> 2)) * 4);
+    }
     float4_t gv[U], st[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -988,7 +1005,9 @@ __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)
         float alpha = __expf(han_lrelu(x, a.slope) - st[u][1]);
         alpha = (ALLV || valid[u]) ? alpha : 0.f;
         float am = 1.f;
-        if (FAST || drop_c) {
+        if (DEDUP) {
+            if (FAST || drop_c) am = tiled_field(hx, hy, baddr0 + 4 * u, head) < a.thr_coef ? a.inv_keep_coef : 0.f;
+        } else if (FAST || drop_c) {
             const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF,
                                             (uint32_t)(((!FAST && a.gid) ? (int64_t)a.gid[(MASKED && !valid[u]) ? 0 : i[u]] : (int64_t)i[u]) + a.dst_offset),
                                             sr.gj * (uint32_t)KQ + (uint32_t)(head >> 2));
@@ -1015,7 +1034,7 @@ __device__ __forceinline__ void write_src(const BwdColsArgs &a, const int64_t sr
     if ((4 * q) % FP == 0) a.df2[src * K + head] = dfacc;
 }
 
-template <int FP, int RPW, int U, bool BF, bool VAL, bool FAST, bool MASKED = false>
+template <int FP, int RPW, int U, bool BF, bool VAL, bool FAST, bool MASKED = false, bool DEDUP = false>
 __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsArgs a_in) {
     BwdColsArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
@@ -1071,7 +1090,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
                         valid[u] = MASKED ? i[u] >= 0 : true;
                         ew[u] = VAL ? __shfl(myval, idx, 64) : 1.f;
                     }
-                    bwd_consume<FP, U, BF, VAL, FAST, !MASKED, MASKED>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+                    bwd_consume<FP, U, BF, VAL, FAST, !MASKED, MASKED, DEDUP && U == 4>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
                 }
                 if (U > 4 && (st + 4) * 4 <= cnt) {             // long unrolls: one half step before the singles
                     int i[4];
@@ -1084,7 +1103,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
                         valid[u] = MASKED ? i[u] >= 0 : true;
                         ew[u] = VAL ? __shfl(myval, idx, 64) : 1.f;
                     }
-                    bwd_consume<FP, 4, BF, VAL, FAST, !MASKED, MASKED>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+                    bwd_consume<FP, 4, BF, VAL, FAST, !MASKED, MASKED, DEDUP>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
                     st += 4;
                 }
                 for (; st * 4 < cnt; ++st) {                    // tail: single steps of 4 edges
@@ -1391,7 +1410,9 @@ static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split,
 template <int FPC, bool BF, bool VAL>
 static void launch_bwd_cols_v(const BwdColsArgs &a, bool low, bool has_split, hipStream_t st) {
     const bool fast = a.thr_coef < HAN_KEEP_ALL && !a.gid;
-    if (a.masked) {      // opt-in masked backward: the general instantiations, dead entries skipped in place
+    if (a.lean && !a.masked && !low && !BF) {      // small graphs (HAN_FLAG_LEAN): VALU-bound, one hash per (edge, four heads)
+        node_attn_bwd_cols_kernel<FPC, 1, 4, false, VAL, false, false, true><<<attn_grid(a.NS), 256, 0, st>>>(a);
+    } else if (a.masked) {      // opt-in masked backward: the general instantiations, dead entries skipped in place
         if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF, VAL, false, true><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
         else node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL, false, true><<<attn_grid(a.NS), 256, 0, st>>>(a);
     } else if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF, VAL, false><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
@@ -1577,6 +1598,7 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
     a.inv_keep_fts = 1.f / (1.f - fts_drop);
     a.src_offset = src_offset; a.dst_offset = dst_offset; a.xcd_order = (flags & HAN_FLAG_XCD_ORDER) ? 1 : 0;
     a.masked = (flags & HAN_FLAG_MASKED_EDGES) ? 1 : 0;
+    a.lean = (flags & HAN_FLAG_LEAN) ? 1 : 0;
     const bool has_split = split && split->n_long > 0;
     a.split_deg = has_split ? split->split_deg : INT64_MAX;
     a.n_long = has_split ? split->n_long : 0;

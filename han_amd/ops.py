@@ -532,7 +532,8 @@ def node_attn_bwd_cols(graph_t: CSRGraph, gs_tab, H, f2, df1, a1, a2, coef_drop=
         tcode, f2.data_ptr(), df1.data_ptr(), a1.data_ptr(), a2.data_ptr(), dH.data_ptr(), df2.data_ptr(),
         NS, graph_t.nnz, K, FP, LEAKY_SLOPE, _check_drop(coef_drop, "coef_drop"), fts_drop,
         int(seed), _dev_word(seed_dev), int(src_offset), int(dst_offset),
-        (FLAG_XCD_ORDER if graph_t.has_locality() else 0) | (FLAG_MASKED_EDGES if graph_t.masked else 0),
+        (FLAG_XCD_ORDER if graph_t.has_locality() else 0) | (FLAG_MASKED_EDGES if graph_t.masked else 0)
+        | (FLAG_LEAN if (not graph_t.masked and _use_lean(graph_t, H)) else 0),
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_bwd_cols")
     if timing is not None:
         ev1.record()

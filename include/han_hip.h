@@ -54,7 +54,8 @@ extern "C" {
                                   the same lean per-edge arithmetic as HAN_FLAG_TILED (scores gathered from f2_src instead of
                                   recomputed, one attention-dropout hash per (edge, four heads)) without the tiles -- any
                                   density, any id order.  fp32 tables, table_gid NULL.  Not for large tables: the 4-byte score
-                                  gather would cost a memory line per edge there.                                              */
+                                  gather would cost a memory line per edge there.  han_node_attn_bwd_cols: the same hash sharing in
+                                  its full 4-edge steps (everything else as the gather form).                               */
 #define HAN_FLAG_MASKED_EDGES 64 /* han_node_attn_bwd_cols: entries of rowidx below 0 are skipped IN PLACE (their destination's
                                   g row is identically zero -- a destination outside the loss mask of a one-layer model);
                                   the remaining terms are summed in the positions and order of the full pass, so the

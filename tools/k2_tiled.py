@@ -47,8 +47,9 @@ def main():
                 "gather_ms": {k: round(a[k], 4) for k in ("eval_ms", "train_ms", "bwd_ms")}}
         for mode in ("tiled", "lean"):
             b = res[mode]
-            diff = {k: float((a[k] - b[k]).abs().max()) for k in ("out_e", "out_t", "pre", "lse", "aggp", "tsum")}
+            diff = {k: float((a[k] - b[k]).abs().max()) for k in ("out_e", "out_t", "pre", "lse", "aggp", "tsum", "dH", "df2")}
             line[mode] = {"taken": b["used"], "eval_ms": round(b["eval_ms"], 4), "train_ms": round(b["train_ms"], 4),
+                          "bwd_ms": round(b["bwd_ms"], 4),
                           "max_abs_diff": {k: float(f"{v:.3g}") for k, v in diff.items()}}
         print(json.dumps(line), flush=True)
     ops.TILED = ops.LEAN = True
