@@ -721,6 +721,170 @@ __global__ __launch_bounds__(256) void node_attn_fwd_lean_kernel(const FwdArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The lean forward with ONE LANE PER HEAD for the reference shape (8 heads x 8 columns; see
+// node_attn_bwd_cols_h8_kernel): 8 groups of 8 lanes, lane h of a group owns the 8 columns of head h of one edge,
+// 16 edges per step (two per group).  Score, LeakyReLU, exp, the dropout field and the softmax sums exist once per
+// (edge, head) and are computed once.
+// ---------------------------------------------------------------------------------------------
+template <bool TRAIN, bool VAL>
+__global__ __launch_bounds__(256) void node_attn_fwd_h8_kernel(const FwdArgs a_in) {
+    FwdArgs a = a_in;
+    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
+    __shared__ __attribute__((aligned(16))) int colw_all[4 * 64];
+    __shared__ __attribute__((aligned(16))) float valw_all[VAL ? 4 * 64 : 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int *colw = colw_all + wv * 64;
+    float *valw = valw_all + (VAL ? wv * 64 : 0);
+    const int g8 = lane >> 3, h = lane & 7;
+    const bool drop_c = TRAIN && a.thr_coef < HAN_KEEP_ALL;
+    const bool drop_f = TRAIN && a.lsb_mask;
+    const float *Hf = reinterpret_cast<const float *>(a.H);
+    const int pu = h & 1, pc = (h >> 1) & 1;       // this lane hashes for (edge pu of its group, head quad pc)
+    int baddr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) baddr[u] = ((lane & 56) + 2 * (h >> 2) + u) * 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave0; row < a.N; row += nwaves) {
+        int64_t cur = a.rowptr[row];
+        const int64_t e = a.rowptr[row + 1];
+        const float f1s = a.f1[row * 8 + h] * kLog2e;
+        const uint32_t gi = (uint32_t)(row + a.row_offset);
+        float m = HAN_NEG_BIG, l = 0.f, tl = 0.f;
+        float acc[8], accp[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { acc[t] = 0.f; accp[t] = 0.f; }
+        auto load_ids = [&](const int64_t at, int &col, float &val) {
+            const int left = (int)((e - at) < 64 ? (e - at) : 64);
+            if (left > 0) {
+                col = a.colidx[at + (lane < left ? lane : left - 1)];
+                if (VAL) val = a.edge_val[at + (lane < left ? lane : left - 1)];
+            }
+        };
+        int nxt_col = 0;
+        float nxt_val = 1.f;
+        load_ids(cur, nxt_col, nxt_val);
+        while (cur < e) {                                   // wave-uniform
+            const int cnt = (int)((e - cur) < 64 ? (e - cur) : 64);
+            colw[lane] = nxt_col;
+            if (VAL) valw[lane] = nxt_val;
+            load_ids(cur + cnt, nxt_col, nxt_val);
+            for (int it = 0; it * 16 < cnt; ++it) {         // 16 edges per step: group g8 takes 16 it + 2 g8, + 1
+                const int2 jj = *reinterpret_cast<const int2 *>(colw + it * 16 + 2 * g8);
+                float2 ww = {1.f, 1.f};
+                if (VAL) ww = *reinterpret_cast<const float2 *>(valw + it * 16 + 2 * g8);
+                const int r = cnt - it * 16;
+                int j[2] = {jj.x, jj.y};
+                const float ew[2] = {ww.x, ww.y};
+                bool valid[2];
+                float hv[2][8], f2v[2], ev[2], sg[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    valid[u] = 2 * g8 + u < r;
+                    j[u] = valid[u] ? j[u] : 0;
+                    const float4_t h0 = *reinterpret_cast<const float4_t *>(Hf + (int64_t)j[u] * HAN_D + 8 * h);
+                    const float4_t h1 = *reinterpret_cast<const float4_t *>(Hf + (int64_t)j[u] * HAN_D + 8 * h + 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { hv[u][t] = h0[t]; hv[u][4 + t] = h1[t]; }
+                    f2v[u] = a.f2g[(int64_t)j[u] * 8 + h];
+                }
+                uint32_t hx = 0, hy = 0;
+                if (drop_c) {
+                    const int ju = pu ? j[1] : j[0];
+                    const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi, (uint32_t)ju * 2u + (uint32_t)pc);
+                    hx = rn.x;
+                    hy = rn.y;
+                }
+                float mc = m;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float x = __builtin_fmaf(f2v[u], kLog2e, f1s);      // (f1_i + f2_j) * log2 e
+                    if (VAL) x *= ew[u];
+                    if (TRAIN) {
+                        sg[u] = x > 0.f ? 1.f : a.slope;
+                        if (VAL) sg[u] *= ew[u];
+                    }
+                    if (drop_f) {                           // layers.py:31-32, after the score was taken (it comes from the table)
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const int bits = __float_as_int(hv[u][t]);
+                            hv[u][t] = __int_as_float(bits & han_bit_mask<0>(bits));
+                        }
+                    }
+                    ev[u] = valid[u] ? fmaxf(x, a.slope * x) : HAN_NEG_BIG;
+                    mc = fmaxf(mc, ev[u]);
+                }
+                const float sc = han_exp2(m - mc);
+                l *= sc;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] *= sc;
+                if (TRAIN) {
+                    tl *= sc;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) accp[t] *= sc;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float p = valid[u] ? han_exp2(ev[u] - mc) : 0.f;
+                    l += p;
+                    float pd = p;
+                    if (drop_c) pd = tiled_field(hx, hy, baddr[u], h) < a.thr_coef ? p : 0.f;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) acc[t] += pd * hv[u][t];
+                    if (TRAIN) {
+                        tl += p * sg[u];
+                        const float pds = pd * sg[u];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) accp[t] += pds * hv[u][t];
+                    }
+                }
+                m = mc;
+            }
+            cur += cnt;
+        }
+        // merge the 8 groups (log2 units), then normalise, bias, activation (layers.py:35,46) and the training extras
+#pragma unroll
+        for (int off = 8; off <= 32; off <<= 1) {
+            const float m_o = __shfl_xor(m, off, 64), l_o = __shfl_xor(l, off, 64);
+            const float M = fmaxf(m, m_o);
+            const float sa = han_exp2(m - M), sb = han_exp2(m_o - M);
+            l = l * sa + l_o * sb;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = acc[t] * sa + __shfl_xor(acc[t], off, 64) * sb;
+            if (TRAIN) {
+                tl = tl * sa + __shfl_xor(tl, off, 64) * sb;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) accp[t] = accp[t] * sa + __shfl_xor(accp[t], off, 64) * sb;
+            }
+            m = M;
+        }
+        if (g8 == 0) {
+            const float inv = l > 0.f ? 1.f / l : 0.f;
+            const float scale = TRAIN ? inv * a.inv_keep_coef * (a.lsb_mask ? a.inv_keep_fts : 1.f) : inv;
+            float4_t ov[2], ap[2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const float4_t c4 = *reinterpret_cast<const float4_t *>(a.c + 8 * h + 4 * v);
+                float4_t r4 = {0.f, 0.f, 0.f, 0.f};
+                if (a.res) r4 = *reinterpret_cast<const float4_t *>(a.res + row * HAN_D + 8 * h + 4 * v);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float pv = acc[4 * v + t] * scale + c4[t] + r4[t];
+                    ov[v][t] = a.activation == HAN_ACT_ELU ? han_elu(pv) : pv;
+                    ap[v][t] = accp[4 * v + t] * scale;
+                    if (TRAIN && a.pre) a.pre[row * HAN_D + 8 * h + 4 * v + t] = pv;
+                }
+                *reinterpret_cast<float4_t *>(a.out + row * a.out_stride + 8 * h + 4 * v) = ov[v];
+                if (TRAIN) *reinterpret_cast<float4_t *>(a.aggp + row * HAN_D + 8 * h + 4 * v) = ap[v];
+            }
+            if (TRAIN) {
+                a.lse[row * 8 + h] = l > 0.f ? m * kLn2 + __logf(l) : HAN_NEG_BIG;
+                a.tsum[row * 8 + h] = tl * inv;
+            }
+        }
+    }
+}
+
 // Split rows, step 1: one wave per chunk of a long row -> un-normalised partial state.
 template <int FP, bool TRAIN, int U, bool BF, bool VAL>
 __global__ __launch_bounds__(256) void node_attn_fwd_chunk_kernel(const FwdArgs a_in) {
@@ -1141,6 +1305,144 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One lane per head (the reference shape, 8 heads x 8 columns) for small graphs (HAN_FLAG_LEAN): a wave is 8 groups
+// of 8 lanes, lane h of a group owns ALL 8 columns of head h of one edge, so everything that exists once per
+// (edge, head) -- score, LeakyReLU, exp, dropout field, the dl term -- is computed once instead of by the two lanes
+// that share a head in the 16-lane map, the dot product g_i . H~_j is in-lane (no DPP), and a step covers 8 edges.
+// 3x fewer vector instructions per edge in this pass, which on small graphs is bound by exactly that
+// (profiles/r03_pmc_k2_small_dense.json).  Not for large tables: 118-164 registers for the same rows in flight lost
+// to the 16-lane map there (the bf16 lane-map experiment).  fp32 tables, table index == global id.
+// ---------------------------------------------------------------------------------------------
+template <bool VAL>
+__global__ __launch_bounds__(256) void node_attn_bwd_cols_h8_kernel(const BwdColsArgs a_in) {
+    BwdColsArgs a = a_in;
+    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
+    constexpr int RB = GsRow<8, false>::bytes;
+    constexpr int GB = GsRow<8, false>::g_bytes;
+    __shared__ __attribute__((aligned(16))) int colw_all[4 * 64];
+    __shared__ __attribute__((aligned(16))) float valw_all[VAL ? 4 * 64 : 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int *colw = colw_all + wv * 64;
+    float *valw = valw_all + (VAL ? wv * 64 : 0);
+    const int g8 = lane >> 3, h = lane & 7;
+    const bool drop_c = a.thr_coef < HAN_KEEP_ALL;
+    const float *Hf = reinterpret_cast<const float *>(a.H);
+    const char *gsb = reinterpret_cast<const char *>(a.gs);
+    // the hash of (edge u, head quad c) is computed by lane 2c + u of the group (lanes 4..7 duplicate 0..3)
+    const int pu = h & 1, pc = (h >> 1) & 1;
+    int baddr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) baddr[u] = ((lane & 56) + 2 * (h >> 2) + u) * 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t src = wave0; src < a.NS; src += nwaves) {
+        int64_t cur = a.colptr[src];
+        const int64_t e = a.colptr[src + 1];
+        const uint32_t gj = (uint32_t)(src + a.src_offset);
+        const float f2h = a.f2[src * 8 + h];
+        float hd[8], mk[8];
+        {
+            const float4_t h0 = *reinterpret_cast<const float4_t *>(Hf + src * HAN_D + 8 * h);
+            const float4_t h1 = *reinterpret_cast<const float4_t *>(Hf + src * HAN_D + 8 * h + 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { hd[t] = h0[t]; hd[4 + t] = h1[t]; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                mk[t] = 1.f;
+                if (a.lsb_mask) {
+                    mk[t] = han_keep_bit<false>(hd[t]) ? a.inv_keep_fts : 0.f;
+                    hd[t] *= mk[t];
+                }
+            }
+        }
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float dfacc = 0.f;
+        auto load_ids = [&](const int64_t at, int &col, float &val) {
+            const int left = (int)((e - at) < 64 ? (e - at) : 64);
+            if (left > 0) {
+                col = a.rowidx[at + (lane < left ? lane : left - 1)];
+                if (VAL) val = a.edge_val[at + (lane < left ? lane : left - 1)];
+            }
+        };
+        int nxt_row = 0;
+        float nxt_val = 1.f;
+        load_ids(cur, nxt_row, nxt_val);
+        while (cur < e) {                                   // wave-uniform
+            const int cnt = (int)((e - cur) < 64 ? (e - cur) : 64);
+            colw[lane] = nxt_row;
+            if (VAL) valw[lane] = nxt_val;
+            load_ids(cur + cnt, nxt_row, nxt_val);
+            for (int it = 0; it * 16 < cnt; ++it) {         // 16 edges per step: group g8 takes 16 it + 2 g8, + 1
+                const int2 ii = *reinterpret_cast<const int2 *>(colw + it * 16 + 2 * g8);
+                float2 ww = {1.f, 1.f};
+                if (VAL) ww = *reinterpret_cast<const float2 *>(valw + it * 16 + 2 * g8);
+                const int r = cnt - it * 16;                // edges left in this piece (>= 16: all slots are edges)
+                int i[2] = {ii.x, ii.y};
+                const float ew[2] = {ww.x, ww.y};
+                bool valid[2];
+                float4_t g0[2], g1[2], st[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    valid[u] = 2 * g8 + u < r;
+                    i[u] = valid[u] ? i[u] : 0;
+                    const char *rowp = gsb + (int64_t)i[u] * RB;
+                    g0[u] = *reinterpret_cast<const float4_t *>(rowp + 32 * h);
+                    g1[u] = *reinterpret_cast<const float4_t *>(rowp + 32 * h + 16);
+                    st[u] = *reinterpret_cast<const float4_t *>(rowp + GB + 16 * h);
+                }
+                uint32_t hx = 0, hy = 0;
+                if (drop_c) {
+                    const int iu = pu ? i[1] : i[0];
+                    const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, (uint32_t)((int64_t)iu + a.dst_offset),
+                                                    gj * 2u + (uint32_t)pc);
+                    hx = rn.x;
+                    hy = rn.y;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float x = st[u][0] + f2h;
+                    if (VAL) x *= ew[u];
+                    float sg = x > 0.f ? 1.f : a.slope;
+                    if (VAL) sg *= ew[u];
+                    float alpha = __expf(han_lrelu(x, a.slope) - st[u][1]);
+                    alpha = valid[u] ? alpha : 0.f;
+                    float am = 1.f;
+                    if (drop_c) am = tiled_field(hx, hy, baddr[u], h) < a.thr_coef ? a.inv_keep_coef : 0.f;
+                    float dot = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dot += g0[u][t] * hd[t] + g1[u][t] * hd[4 + t];
+                    dfacc += alpha * sg * (am * dot - st[u][2]);
+                    const float w = alpha * am;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc[t] += w * g0[u][t];
+                        acc[4 + t] += w * g1[u][t];
+                    }
+                }
+            }
+            cur += cnt;
+        }
+#pragma unroll
+        for (int off = 8; off <= 32; off <<= 1) {
+            dfacc += __shfl_xor(dfacc, off, 64);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] += __shfl_xor(acc[t], off, 64);
+        }
+        if (g8 == 0) {
+            const float d1 = a.df1[src * 8 + h];
+            float4_t o0, o1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                o0[t] = acc[t] * mk[t] + d1 * a.a1[8 * h + t] + dfacc * a.a2[8 * h + t];
+                o1[t] = acc[4 + t] * mk[4 + t] + d1 * a.a1[8 * h + 4 + t] + dfacc * a.a2[8 * h + 4 + t];
+            }
+            *reinterpret_cast<float4_t *>(a.dH + src * HAN_D + 8 * h) = o0;
+            *reinterpret_cast<float4_t *>(a.dH + src * HAN_D + 8 * h + 4) = o1;
+            a.df2[src * 8 + h] = dfacc;
+        }
+    }
+}
+
 // Split source rows: one wave per chunk -> partial sums; one 16-lane group per long row adds them.
 template <int FP, int U, bool BF, bool VAL>
 __global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsArgs a_in) {
@@ -1410,7 +1712,9 @@ static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split,
 template <int FPC, bool BF, bool VAL>
 static void launch_bwd_cols_v(const BwdColsArgs &a, bool low, bool has_split, hipStream_t st) {
     const bool fast = a.thr_coef < HAN_KEEP_ALL && !a.gid;
-    if (a.lean && !a.masked && !low && !BF) {      // small graphs (HAN_FLAG_LEAN): VALU-bound, one hash per (edge, four heads)
+    if (a.lean && !a.masked && !low && !BF && FPC == 8 && !a.gid) {      // small graphs, 8 x 8: one lane per head
+        node_attn_bwd_cols_h8_kernel<VAL><<<attn_grid(a.NS), 256, 0, st>>>(a);
+    } else if (a.lean && !a.masked && !low && !BF) {      // small graphs (HAN_FLAG_LEAN): VALU-bound, one hash per (edge, four heads)
         node_attn_bwd_cols_kernel<FPC, 1, 4, false, VAL, false, false, true><<<attn_grid(a.NS), 256, 0, st>>>(a);
     } else if (a.masked) {      // opt-in masked backward: the general instantiations, dead entries skipped in place
         if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF, VAL, false, true><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
@@ -1444,7 +1748,10 @@ static hipError_t launch_fwd_tiled_v(const FwdArgs &a, bool train, int64_t NT, h
 template <int FPC, bool VAL>
 static void launch_fwd_lean_v(const FwdArgs &a, bool train, hipStream_t st) {
     const int grid = attn_grid(a.N);
-    if (train) node_attn_fwd_lean_kernel<FPC, true, VAL><<<grid, 256, 0, st>>>(a);
+    if (FPC == 8) {       // the reference shape: one lane per head
+        if (train) node_attn_fwd_h8_kernel<true, VAL><<<grid, 256, 0, st>>>(a);
+        else node_attn_fwd_h8_kernel<false, VAL><<<grid, 256, 0, st>>>(a);
+    } else if (train) node_attn_fwd_lean_kernel<FPC, true, VAL><<<grid, 256, 0, st>>>(a);
     else node_attn_fwd_lean_kernel<FPC, false, VAL><<<grid, 256, 0, st>>>(a);
 }
 
