@@ -102,7 +102,7 @@ int main(int argc, char **argv) {
     HAN_OK(han_project_fwd(dX, HAN_DTYPE_F32, F, dW, da1, da2, db1, db2, dH, HAN_DTYPE_F32, df1, df2, ws, ws_bytes,
                            N, F, K, FP, 0.f, 0.f, 0, nullptr, 0, /*keep*/ nullptr, /*flags*/ 0, st));
     HAN_OK(han_node_attn_fwd(drp, dci, nullptr, dH, HAN_DTYPE_F32, nullptr, df1, nullptr, da2, db2, dc, nullptr, dM, D,
-                             nullptr, nullptr, nullptr, nullptr, N, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0,
+                             nullptr, nullptr, nullptr, nullptr, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0,
                              HAN_ACT_ELU, /*flags*/ 0, nullptr, st));
     HAN_OK(han_sem_attn_fwd(dM, dwo, dbo, duo, dZ, dbeta, N, 1, D, A, /*flags*/ 0, st));
     HIP_OK(hipStreamSynchronize(st));
@@ -154,7 +154,7 @@ int main(int argc, char **argv) {
     if (wb_sp) HIP_OK(hipMalloc(&ws_sp, wb_sp));
     if (wb_pb) HIP_OK(hipMalloc(&ws_pb, wb_pb));
     HAN_OK(han_node_attn_fwd(drp, dci, nullptr, dH, HAN_DTYPE_F32, nullptr, df1, nullptr, da2, db2, dc, nullptr, dM, D,
-                             nullptr, dlse, daggp, dtsum, N, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0,
+                             nullptr, dlse, daggp, dtsum, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0,
                              HAN_ACT_ELU, 0, nullptr, st));
     HAN_OK(han_node_attn_bwd_rows(ddOut, D, dM, D, daggp, dtsum, df1, dlse, dc, nullptr, dgs, HAN_DTYPE_F32, ddf1,
                                   ddc, ws_rows, wb_rows, N, K, FP, HAN_ACT_ELU, st));

@@ -43,7 +43,7 @@ SIGNATURES = {
                                 c_uint64, P, I64, P, P]),
     "han_project_bwd_input": (c_int, [P, P, P, I64, I64, c_int, c_int, c_int, c_float, c_uint64, P, I64, P]),
     "han_row_split_workspace": (c_size_t, [I64]),
-    "han_node_attn_fwd": (c_int, [P, P, P, P, c_int, P, P, P, P, P, P, P, P, I64, P, P, P, P, I64, I64, I64, c_int,
+    "han_node_attn_fwd": (c_int, [P, P, P, P, c_int, P, P, P, P, P, P, P, P, I64, P, P, P, P, I64, I64, c_int,
                                   c_int, c_float, c_float, c_float, c_uint64, P, I64, c_int, c_int, P, P]),
     "han_node_attn_coefs": (c_int, [P, P, P, P, P, P, P, c_int, I64, I64, c_int, c_int, c_float, c_float,
                                     c_uint64, P, I64, P]),

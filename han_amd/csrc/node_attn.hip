@@ -396,45 +396,42 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-tiled kernels for SMALL DENSE graphs (the reference's own data sets: ACM PSP is 24 % dense, DBLP APCPA /
-// APTPA 30 % / 78 %).  On such graphs (a few thousand rows, thousands of neighbours per row) the gather kernels
-// are not bound by memory but by VALU issue (profiles/r03_pmc_k2_small_dense.json: 73-85 % VALU-active, one wave
-// per row and ~4000 waves in all), so these kernels are built to spend fewer vector instructions per edge:
-//   * a block of 16 waves owns 16 rows (one wave per row, four 16-lane groups taking four neighbours each per
-//     step) and walks the TABLE in tiles of kTileRows rows staged once into LDS; the ids of a row ascend, so the
-//     entries of a row inside a tile are one contiguous piece of its CSR row, found by comparing the ids it loads;
-//   * the neighbour score f2_j comes from the K1 table (staged with the tile, pre-multiplied by log2 e so that the
-//     softmax runs on v_exp_f32 directly) instead of a dot product + lane reduction per edge;
-//   * training: the projected-row dropout is applied ONCE per staged element, not per edge, and the attention-dropout
-//     hash is computed once per (edge, four heads) by one lane of the group and handed out by ds_bpermute, not by
-//     every lane;
-//   * the four ids of a group's step are one 16-byte LDS read of the wave's staged ids.
-// Same arithmetic per edge as the gather kernels up to the order of the sums.  Needs: fp32 tables, table index ==
-// global id, ids ascending within each row (HAN_FLAG_TILED asserts it), the f2 table.
+// Lean kernels for SMALL graphs with long rows (HAN_FLAG_LEAN; the reference's own data sets: a few thousand
+// nodes, ACM PSP 24 % dense, DBLP APCPA / APTPA 30 % / 78 %).  There the gather kernels above are not bound by
+// memory but by vector-instruction issue (profiles/r03_pmc_k2_small_dense.json: 73-85 % VALU-active, one wave per
+// row and ~4000 waves in all), so these kernels spend fewer vector instructions per edge:
+//   * the neighbour score f2_j is READ from the K1 table (a 4-byte gather next to the row: free while the table lives
+//     in the L2s, a memory line per edge on a large table -- hence small graphs only) instead of a dot product + lane
+//     reduction per edge, and the softmax runs in log2 units (v_exp_f32 directly);
+//   * the attention-dropout hash is computed once per (edge, four heads) by one lane of the group and handed out by
+//     ds_bpermute, not by every lane;
+//   * the ids of a step are one LDS read of the wave's staged ids, loaded one 64-entry piece ahead;
+//   * for the reference shape (8 heads x 8 columns) one lane owns a whole head of an edge (8 groups of 8 lanes, 16
+//     edges per step): everything that exists once per (edge, head) is computed once, dot products are in-lane.
+// Same arithmetic per edge as the gather kernels up to the order of the sums.  fp32 tables, table index == global id.
+// (An LDS-tiled form -- 16 rows per block walking the table in 256-row tiles -- was built first and measured: staging
+// alone changed nothing, and with the same lean step it lost to these kernels at every density)
 // ---------------------------------------------------------------------------------------------
-constexpr int kTileRows = 256;        // 64 KB of rows + up to 16 KB of scores (and 4 float4 per thread of the next tile in registers)
-constexpr int kTileBlock = 1024;      // 16 waves: one row each
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
 __device__ __forceinline__ float han_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // the 16-bit field `head & 3` of the hash that lane (group base + u + 4 * (head >> 2)) computed
-__device__ __forceinline__ uint32_t tiled_field(const uint32_t hx, const uint32_t hy, const int src_addr, const int head) {
+__device__ __forceinline__ uint32_t lean_field(const uint32_t hx, const uint32_t hy, const int src_addr, const int head) {
     const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)hx);
     const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)hy);
     const uint32_t wsel = (head & 2) ? y : x;
     return (head & 1) ? (wsel >> 16) : (wsel & 0xFFFFu);
 }
 
-// LEAN: the same step with the rows and scores gathered from global memory (tables that live in the L2s): the
-// projected-row dropout is then applied per edge and the score is scaled as it is used
-template <int FP, bool TRAIN, bool VAL, bool MASKED, bool LEAN = false>
-__device__ __forceinline__ void tiled_fwd_step(const FwdArgs &a, const float *tileH, const float *tileF, const int4 jj,
-                                               const float4_t wv4, const int r, const uint32_t hoff, const uint32_t foff,
-                                               const int j0, const float f1s, const uint32_t gi, const int g, const int q,
-                                               const int head, const bool drop_c, const int (&baddr)[4],
-                                               float &m, float &l, float &tl, float (&acc)[4], float (&accp)[4]) {
+// one step of 16 edges in the 16-lane map (group g takes the entries 4 g .. 4 g + 3 of the step)
+template <int FP, bool TRAIN, bool VAL, bool MASKED>
+__device__ __forceinline__ void lean_fwd_step(const FwdArgs &a, const float *tileH, const float *tileF, const int4 jj,
+                                              const float4_t wv4, const int r, const uint32_t hoff, const uint32_t foff,
+                                              const int j0, const float f1s, const uint32_t gi, const int g, const int q,
+                                              const int head, const bool drop_c, const int (&baddr)[4],
+                                              float &m, float &l, float &tl, float (&acc)[4], float (&accp)[4]) {
     constexpr int K = HAN_D / FP;
     constexpr int KQ = (K + 3) / 4;
     int j[4] = {jj.x, jj.y, jj.z, jj.w};
@@ -444,14 +441,9 @@ __device__ __forceinline__ void tiled_fwd_step(const FwdArgs &a, const float *ti
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         valid[u] = !MASKED || (4 * g + u) < r;
-        if (MASKED) j[u] = valid[u] ? j[u] : j0;           // a slot past the piece must not index outside the tile
-        if (LEAN) {
-            hv[u] = *reinterpret_cast<const float4_t *>(tileH + ((int64_t)j[u] * HAN_D + hoff));
-            f2v[u] = tileF[(int64_t)j[u] * K + foff];
-        } else {
-            hv[u] = *reinterpret_cast<const float4_t *>(tileH + ((uint32_t)j[u] * HAN_D + hoff));
-            f2v[u] = tileF[(uint32_t)j[u] * K + foff];
-        }
+        if (MASKED) j[u] = valid[u] ? j[u] : j0;           // a slot past the piece reads a row that exists
+        hv[u] = *reinterpret_cast<const float4_t *>(tileH + ((int64_t)j[u] * HAN_D + hoff));
+        f2v[u] = tileF[(int64_t)j[u] * K + foff];
     }
     uint32_t hx = 0, hy = 0;
     if (TRAIN && drop_c) {      // one hash per (edge, four heads): lane q of the group takes edge q & 3, head quad (q >> 2) % KQ
@@ -465,9 +457,9 @@ __device__ __forceinline__ void tiled_fwd_step(const FwdArgs &a, const float *ti
     float mc = m;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        float x = LEAN ? __builtin_fmaf(f2v[u], kLog2e, f1s) : f1s + f2v[u];      // (f1_i + f2_j) * log2 e
+        float x = __builtin_fmaf(f2v[u], kLog2e, f1s);      // (f1_i + f2_j) * log2 e
         if (VAL) x *= wv4[u];
-        if (LEAN && TRAIN && a.lsb_mask) {                  // layers.py:31-32 per edge (the tiled form does it per staged element)
+        if (TRAIN && a.lsb_mask) {                          // layers.py:31-32, after the score was taken (it comes from the table)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int bits = __float_as_int(hv[u][t]);
@@ -497,7 +489,7 @@ __device__ __forceinline__ void tiled_fwd_step(const FwdArgs &a, const float *ti
         if (MASKED) p = valid[u] ? p : 0.f;
         l += p;
         float pd = p;
-        if (TRAIN && drop_c) pd = tiled_field(hx, hy, baddr[u], head) < a.thr_coef ? p : 0.f;
+        if (TRAIN && drop_c) pd = lean_field(hx, hy, baddr[u], head) < a.thr_coef ? p : 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] += pd * hv[u][t];
         if (TRAIN) {
@@ -510,143 +502,8 @@ __device__ __forceinline__ void tiled_fwd_step(const FwdArgs &a, const float *ti
     m = mc;
 }
 
-template <int FP, bool TRAIN, bool VAL>
-__global__ __launch_bounds__(kTileBlock) void node_attn_fwd_tiled_kernel(const FwdArgs a_in, const int64_t NT) {
-    FwdArgs a = a_in;
-    han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
-    constexpr int K = HAN_D / FP;
-    extern __shared__ __attribute__((aligned(16))) char tiled_smem[];
-    float *tileH = reinterpret_cast<float *>(tiled_smem);                  // [kTileRows][64]  (dropped rows in training)
-    float *tileF = tileH + kTileRows * HAN_D;                              // [kTileRows][K]   f2 * log2 e
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int *colw = reinterpret_cast<int *>(tileF + kTileRows * K) + wv * 64;   // this wave's 64 ids
-    float *valw = reinterpret_cast<float *>(colw - wv * 64 + 16 * 64) + wv * 64;
-    const int g = lane >> 4, q = lane & 15;
-    const int head = (4 * q) / FP;
-    const float4_t c4 = *reinterpret_cast<const float4_t *>(a.c + 4 * q);
-    const bool drop_c = TRAIN && a.thr_coef < HAN_KEEP_ALL;
-    const bool drop_f = TRAIN && a.lsb_mask;
-    const int64_t row_raw = (int64_t)blockIdx.x * 16 + wv;
-    const bool row_ok = row_raw < a.N;
-    const int64_t row = row_ok ? row_raw : a.N - 1;
-    int64_t cur = a.rowptr[row];
-    const int64_t e = row_ok ? a.rowptr[row + 1] : cur;
-    const float f1s = a.f1[row * K + head] * kLog2e;
-    const uint32_t gi = (uint32_t)(row + a.row_offset);
-    int baddr[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) baddr[u] = (g * 16 + u + 4 * (head >> 2)) * 4;
-    float m = HAN_NEG_BIG, l = 0.f, tl = 0.f;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f}, accp[4] = {0.f, 0.f, 0.f, 0.f};
-    // the next tile travels in registers while this one is being used: the loads are issued right after the
-    // barrier that publishes a tile and are first needed one tile later
-    constexpr int NPH = kTileRows * 16 / kTileBlock;                       // float4 of rows per thread and tile
-    constexpr int NPF = (kTileRows * K + kTileBlock - 1) / kTileBlock;     // scores per thread and tile
-    float4_t pre_h[NPH];
-    float pre_f[NPF];
-    auto fetch = [&](const int64_t jn) {
-        const int tr = (int)((NT - jn) < kTileRows ? (NT - jn) : kTileRows);
-#pragma unroll
-        for (int k = 0; k < NPH; ++k) {
-            const int idx = threadIdx.x + k * kTileBlock;
-            if (idx < tr * 16)
-                pre_h[k] = *reinterpret_cast<const float4_t *>(reinterpret_cast<const float *>(a.H) + jn * HAN_D + (int64_t)idx * 4);
-        }
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-            const int idx = threadIdx.x + k * kTileBlock;
-            if (idx < tr * K) pre_f[k] = a.f2g[jn * K + idx];
-        }
-    };
-    if (NT > 0) fetch(0);
-    // the ids (and values) of the NEXT piece are loaded before the current one is processed: a piece ends where the
-    // next begins, whether that is in this tile or the next one
-    auto load_ids = [&](const int64_t at, int &col, float &val) {
-        const int left = (int)((e - at) < 64 ? (e - at) : 64);
-        if (left > 0) {
-            col = a.colidx[at + (lane < left ? lane : left - 1)];
-            if (VAL) val = a.edge_val[at + (lane < left ? lane : left - 1)];
-        }
-    };
-    int nxt_col = 0;
-    float nxt_val = 1.f;
-    load_ids(cur, nxt_col, nxt_val);
-    for (int64_t j0 = 0; j0 < NT; j0 += kTileRows) {
-        const int trows = (int)((NT - j0) < kTileRows ? (NT - j0) : kTileRows);
-        __syncthreads();                                   // the previous tile has been consumed by every wave
-#pragma unroll
-        for (int k = 0; k < NPH; ++k) {
-            const int idx = threadIdx.x + k * kTileBlock;
-            if (idx < trows * 16) {
-                float4_t v = pre_h[k];
-                if (drop_f) {      // layers.py:31-32 once per staged element: AND with the sign-extended keep bit
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int bits = __float_as_int(v[t]);
-                        v[t] = __int_as_float(bits & han_bit_mask<0>(bits));
-                    }
-                }
-                *reinterpret_cast<float4_t *>(tileH + idx * 4) = v;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-            const int idx = threadIdx.x + k * kTileBlock;
-            if (idx < trows * K) tileF[idx] = pre_f[k] * kLog2e;
-        }
-        __syncthreads();
-        if (j0 + kTileRows < NT) fetch(j0 + kTileRows);
-        const int jend = (int)(j0 + trows);
-        const uint32_t hoff = (uint32_t)(4 * q) - (uint32_t)j0 * HAN_D;     // tile index of (j, 4q) = j * 64 + hoff  (mod 2^32)
-        const uint32_t foff = (uint32_t)head - (uint32_t)j0 * K;
-        bool more = cur < e;
-        while (more) {                                     // wave-uniform
-            const int left = (int)((e - cur) < 64 ? (e - cur) : 64);
-            const int mycol = nxt_col;
-            const float myval = nxt_val;
-            // ids ascend: the entries of this tile are a prefix of the 64 just loaded
-            const int cnt = __popcll(__ballot(lane < left && mycol < jend));
-            load_ids(cur + cnt, nxt_col, nxt_val);
-            colw[lane] = mycol;
-            if (VAL) valw[lane] = myval;
-            const int nfull = cnt >> 4;
-            int4 jj = *reinterpret_cast<const int4 *>(colw + 4 * g);
-            float4_t w4 = {1.f, 1.f, 1.f, 1.f};
-            if (VAL) w4 = *reinterpret_cast<const float4_t *>(valw + 4 * g);
-            for (int it = 0; it < nfull; ++it) {            // full steps: group g takes the entries 16 it + 4 g .. + 3
-                const int nx = ((it + 1) & 3) * 16 + 4 * g;                 // the ids of the next step, one step ahead
-                const int4 jn = *reinterpret_cast<const int4 *>(colw + nx);
-                float4_t wn = {1.f, 1.f, 1.f, 1.f};
-                if (VAL) wn = *reinterpret_cast<const float4_t *>(valw + nx);
-                tiled_fwd_step<FP, TRAIN, VAL, false>(a, tileH, tileF, jj, w4, 16, hoff, foff, (int)j0, f1s, gi, g, q, head,
-                                                      drop_c, baddr, m, l, tl, acc, accp);
-                jj = jn;
-                w4 = wn;
-            }
-            if (nfull * 16 < cnt)                           // the last, partial step of the piece (nfull < 4 here)
-                tiled_fwd_step<FP, TRAIN, VAL, true>(a, tileH, tileF, jj, w4, cnt - nfull * 16, hoff, foff, (int)j0, f1s, gi, g,
-                                                     q, head, drop_c, baddr, m, l, tl, acc, accp);
-            cur += cnt;
-            more = cnt == 64 && cur < e;                    // all 64 were inside the tile: there may be more
-        }
-    }
-    RowState<TRAIN> st;
-    st.m = m * kLn2;                                        // back to natural-log units for the merge and the log-sum-exp
-    st.l = l;
-    st.tl = tl;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { st.acc[t] = acc[t]; st.accp[t] = accp[t]; }
-    st.merge(16);
-    st.merge(32);
-    write_row<FP, TRAIN>(a, row, st, q, head, c4, row_ok && g == 0);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same lean per-edge arithmetic WITHOUT tiles (HAN_FLAG_LEAN): small graphs whose table lives in the L2s (a few
-// thousand rows) but are not dense enough for the tiled form to pay (ACM PSP 24 %, DBLP APCPA 30 %).  One wave per
-// row, rows and scores gathered from global memory (the 4-byte score gather is what a large table could not afford: a
-// line per edge), the same steps of 16 edges, ids one piece ahead; whole rows of any length, any id order.
-// ---------------------------------------------------------------------------------------------
+// The lean forward, any head shape (16-lane map): one wave per row, rows and scores gathered from global memory,
+// steps of 16 edges, ids one piece ahead; whole rows of any length, any id order.
 template <int FP, bool TRAIN, bool VAL>
 __global__ __launch_bounds__(256) void node_attn_fwd_lean_kernel(const FwdArgs a_in) {
     FwdArgs a = a_in;
@@ -699,13 +556,13 @@ __global__ __launch_bounds__(256) void node_attn_fwd_lean_kernel(const FwdArgs a
                 const int4 jn = *reinterpret_cast<const int4 *>(colw + nx);
                 float4_t wn = {1.f, 1.f, 1.f, 1.f};
                 if (VAL) wn = *reinterpret_cast<const float4_t *>(valw + nx);
-                tiled_fwd_step<FP, TRAIN, VAL, false, true>(a, Hf, a.f2g, jj, w4, 16, (uint32_t)(4 * q), (uint32_t)head, 0, f1s, gi, g,
+                lean_fwd_step<FP, TRAIN, VAL, false>(a, Hf, a.f2g, jj, w4, 16, (uint32_t)(4 * q), (uint32_t)head, 0, f1s, gi, g,
                                                             q, head, drop_c, baddr, m, l, tl, acc, accp);
                 jj = jn;
                 w4 = wn;
             }
             if (nfull * 16 < cnt)
-                tiled_fwd_step<FP, TRAIN, VAL, true, true>(a, Hf, a.f2g, jj, w4, cnt - nfull * 16, (uint32_t)(4 * q), (uint32_t)head, 0,
+                lean_fwd_step<FP, TRAIN, VAL, true>(a, Hf, a.f2g, jj, w4, cnt - nfull * 16, (uint32_t)(4 * q), (uint32_t)head, 0,
                                                            f1s, gi, g, q, head, drop_c, baddr, m, l, tl, acc, accp);
             cur += cnt;
         }
@@ -828,7 +685,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_h8_kernel(const FwdArgs a_i
                     const float p = valid[u] ? han_exp2(ev[u] - mc) : 0.f;
                     l += p;
                     float pd = p;
-                    if (drop_c) pd = tiled_field(hx, hy, baddr[u], h) < a.thr_coef ? p : 0.f;
+                    if (drop_c) pd = lean_field(hx, hy, baddr[u], h) < a.thr_coef ? p : 0.f;
 #pragma unroll
                     for (int t = 0; t < 8; ++t) acc[t] += pd * hv[u][t];
                     if (TRAIN) {
@@ -1170,7 +1027,7 @@ __device__ __forceinline__ void bwd_consume(const BwdColsArgs &a, const int (&i)
         alpha = (ALLV || valid[u]) ? alpha : 0.f;
         float am = 1.f;
         if (DEDUP) {
-            if (FAST || drop_c) am = tiled_field(hx, hy, baddr0 + 4 * u, head) < a.thr_coef ? a.inv_keep_coef : 0.f;
+            if (FAST || drop_c) am = lean_field(hx, hy, baddr0 + 4 * u, head) < a.thr_coef ? a.inv_keep_coef : 0.f;
         } else if (FAST || drop_c) {
             const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF,
                                             (uint32_t)(((!FAST && a.gid) ? (int64_t)a.gid[(MASKED && !valid[u]) ? 0 : i[u]] : (int64_t)i[u]) + a.dst_offset),
@@ -1407,7 +1264,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_h8_kernel(const BwdCol
                     float alpha = __expf(han_lrelu(x, a.slope) - st[u][1]);
                     alpha = valid[u] ? alpha : 0.f;
                     float am = 1.f;
-                    if (drop_c) am = tiled_field(hx, hy, baddr[u], h) < a.thr_coef ? a.inv_keep_coef : 0.f;
+                    if (drop_c) am = lean_field(hx, hy, baddr[u], h) < a.thr_coef ? a.inv_keep_coef : 0.f;
                     float dot = 0.f;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) dot += g0[u][t] * hd[t] + g1[u][t] * hd[4 + t];
@@ -1729,23 +1586,6 @@ static void launch_bwd_cols_v(const BwdColsArgs &a, bool low, bool has_split, hi
 }
 
 template <int FPC, bool VAL>
-static hipError_t launch_fwd_tiled_v(const FwdArgs &a, bool train, int64_t NT, hipStream_t st) {
-    const size_t lds = (size_t)(kTileRows * HAN_D + kTileRows * (HAN_D / FPC) + 2 * 16 * 64) * sizeof(float);
-    const int grid = (int)((a.N + 15) / 16);
-    hipError_t e;
-    if (train) {
-        e = hipFuncSetAttribute((const void *)node_attn_fwd_tiled_kernel<FPC, true, VAL>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) node_attn_fwd_tiled_kernel<FPC, true, VAL><<<grid, kTileBlock, lds, st>>>(a, NT);
-    } else {
-        e = hipFuncSetAttribute((const void *)node_attn_fwd_tiled_kernel<FPC, false, VAL>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) node_attn_fwd_tiled_kernel<FPC, false, VAL><<<grid, kTileBlock, lds, st>>>(a, NT);
-    }
-    return e;
-}
-
-template <int FPC, bool VAL>
 static void launch_fwd_lean_v(const FwdArgs &a, bool train, hipStream_t st) {
     const int grid = attn_grid(a.N);
     if (FPC == 8) {       // the reference shape: one lane per head
@@ -1777,8 +1617,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
                                  const float *b2,
                                  const float *c, const float *res, float *out, int64_t out_stride, float *pre,
                                  float *lse,
-                                 float *aggp, float *tsum, int64_t N, int64_t table_rows, int64_t E, int K, int FP,
-                                 float slope,
+                                 float *aggp, float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
                                  float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev,
                                  int64_t row_offset, int activation, int flags, const han_row_split_t *split,
                                  void *stream) {
@@ -1787,7 +1626,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
         return HAN_E_BADARG;
     if (!split_ok(split)) return HAN_E_BADARG;
     if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
-    if ((flags & (HAN_FLAG_TILED | HAN_FLAG_LEAN)) && !f2_src) return HAN_E_BADARG;      // these kernels read the scores from the table
+    if ((flags & HAN_FLAG_LEAN) && !f2_src) return HAN_E_BADARG;      // the lean kernels read the scores from the table
     const bool train = pre || lse || aggp || tsum;
     if (train && !(lse && aggp && tsum)) return HAN_E_BADARG;      // pre is optional: the backward works from `out`
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
@@ -1814,15 +1653,6 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     a.split_ws = has_split ? (float *)split->workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool low = (double)E < kLowDegree * (double)N;
-    if ((flags & HAN_FLAG_TILED) && table_dtype == HAN_DTYPE_F32 && !table_gid && table_rows > 0 && f2_src) {
-        // small dense graph with ascending column ids: the table goes through LDS tiles (whole rows, any degree)
-        hipError_t te = hipSuccess;
-        if (edge_val) { HAN_DISPATCH_FP(FP, { te = launch_fwd_tiled_v<FPC, true>(a, train, table_rows, st); }) }
-        else { HAN_DISPATCH_FP(FP, { te = launch_fwd_tiled_v<FPC, false>(a, train, table_rows, st); }) }
-        if (te != hipSuccess) return (int)te;
-        HAN_CHECK_LAUNCH();
-        return 0;
-    }
     if ((flags & HAN_FLAG_LEAN) && table_dtype == HAN_DTYPE_F32 && !table_gid && f2_src) {
         // small graph, table in the L2s: scores gathered, one hash per (edge, four heads); whole rows (no row split)
         if (edge_val) { HAN_DISPATCH_FP(FP, { launch_fwd_lean_v<FPC, true>(a, train, st); }) }

@@ -92,21 +92,6 @@ class CSRGraph:
                 self._locality = bool(float(dist) < 0.05 * max(self.n_cols, 1))
         return self._locality
 
-    def sorted_rows(self) -> bool:
-        """True when the column ids ascend (weakly) within every row -- what the LDS-tiled K2 kernels need
-        (HAN_FLAG_TILED): the entries of a row that fall into one tile of the table are then one contiguous piece.
-        One pass, cached; from_bias / the transpose / the synthetic generators all produce sorted rows."""
-        if getattr(self, "_sorted", None) is None:
-            if self.nnz < 2:
-                self._sorted = self.nnz == 0 or bool(int(self.colidx[0]) >= 0)
-            else:
-                c = self.colidx
-                down = torch.nonzero(c[1:] < c[:-1]).flatten() + 1          # positions where the id drops ...
-                starts = torch.zeros(self.nnz + 1, dtype=torch.bool, device=self.device)
-                starts[self.rowptr.clamp(max=self.nnz)] = True                 # ... must be row starts
-                self._sorted = bool(starts[down].all()) and bool(int(c.min()) >= 0)
-        return self._sorted
-
     def with_masked_columns(self, live: torch.Tensor, remap: torch.Tensor | None = None,
                             n_cols: int | None = None) -> "CSRGraph":
         """The same rows with every entry whose column is not `live` replaced by -1 IN PLACE (positions kept),
@@ -117,7 +102,6 @@ class CSRGraph:
         g = CSRGraph(self.rowptr, new.contiguous(), self.n_cols if n_cols is None else n_cols, validate=False,
                      values=self.values, row_base=self.row_base)
         g._locality = False         # its column ids are no longer row ids
-        g._sorted = False           # -1 entries: never on the tiled kernels
         g.masked = True
         return g
 

@@ -16,8 +16,7 @@ from .graph import CSRGraph
 ACT_IDENTITY = 0
 ACT_ELU = 1
 FLAG_XCD_ORDER = 1         # HAN_FLAG_XCD_ORDER: XCD-aware work order for graphs with locality
-FLAG_TILED = 128           # HAN_FLAG_TILED: LDS-tiled K2 kernels for small dense graphs with ascending ids per row
-FLAG_LEAN = 256            # HAN_FLAG_LEAN: the lean per-edge arithmetic with gathered rows / scores (small tables, long rows)
+FLAG_LEAN = 256            # HAN_FLAG_LEAN: the lean K2 kernels of small graphs (scores read from the table, shared dropout hash, one lane per head at 8 x 8)
 FLAG_MASKED_EDGES = 64     # HAN_FLAG_MASKED_EDGES: negative entries of the transposed graph are skipped in place
 FLAG_K1_EXACT_PIPE = 2     # HAN_FLAG_K1_EXACT_PIPE / _MATRIX_PIPE: force one of the two K1 forward kernels (tests, measurements)
 FLAG_K1_MATRIX_PIPE = 4
@@ -139,18 +138,6 @@ def _row_split_arg(graph: CSRGraph, tag: str):
                           sp["chunk_start"].data_ptr(), sp["chunk_end"].data_ptr(), ws.data_ptr(),
                           ws.numel())
     return st, (sp, ws)
-
-
-TILED = True               # tests / measurements: False keeps every graph on the gather kernels
-
-
-def _use_tiles(graph: CSRGraph, table) -> bool:
-    """The LDS-tiled K2 forward kernels (HAN_FLAG_TILED) are taken for graphs at least half dense (DBLP APTPA, 78 %):
-    every block of 16 rows stages the whole table through LDS, two barriers per 256-row tile, which pays only when a
-    row has a few hundred entries per tile (measured: 1.4x / 1.3x at 78 %, 1.15x at 30 %, 0.9x at 24 % density --
-    profiles/r03_k2_tiled_vs_gather.jsonl).  They need fp32 rows and ascending ids within every row."""
-    return (TILED and table.dtype == torch.float32 and graph.n_rows > 0
-            and graph.nnz * 2 >= graph.n_rows * graph.n_cols and graph.sorted_rows())
 
 
 LEAN = True                # tests / measurements: False keeps the classic gather kernels
@@ -346,8 +333,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
     res (N,D) fp32: residual term added before the activation (layers.py:38-40).  `out`: optional (N,D) view with unit inner
     stride (e.g. M[:,p,:]).  f2_src (NT,1): one head of 64 columns only -- the neighbour scores are gathered from
     this table instead of being recomputed (slices of a head wider than 64 columns: f1 / f2_src hold the head's
-    totals).  f2 (NT,K): the table rows' scores as project_fwd returned them -- with them a small dense graph
-    (_use_tiles) runs on the LDS-tiled kernels, which read the scores instead of recomputing them.
+    totals).  f2 (NT,K): the table rows' scores as project_fwd returned them -- with them a small graph with long rows
+    (_use_lean) runs on the lean kernels, which read the scores instead of recomputing them.
     Returns out, saved where saved = (out, lse, aggp, tsum) if train else None: saved[0] is the OUTPUT view itself,
     which node_attn_bwd_rows reads (it must stay unmodified until then); the pre-activation is not stored."""
     lib = _lib.load()
@@ -370,9 +357,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
             raise ValueError("f2_src: only for one head of 64 columns (K = 1, F' = 64)")
         _chk(f2_src, "f2_src", (graph.n_cols, 1), device=dev)
         f2 = f2_src
-    tiled = f2 is not None and table_gid is None and _use_tiles(graph, H_tab)
-    lean = f2 is not None and table_gid is None and not tiled and _use_lean(graph, H_tab)
-    if tiled or lean:
+    lean = f2 is not None and table_gid is None and _use_lean(graph, H_tab)
+    if lean:
         _chk(f2, "f2", (graph.n_cols, K), device=dev)
     if graph.device != dev:
         raise ValueError("graph and tables must be on the same device")
@@ -405,12 +391,12 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         graph.rowptr.data_ptr(), graph.colidx.data_ptr(),
         graph.values.data_ptr() if graph.values is not None else None, H_tab.data_ptr(), tcode,
         table_gid.data_ptr() if table_gid is not None else None, f1.data_ptr(),
-        f2.data_ptr() if (tiled or lean or f2_src is not None) else None,
+        f2.data_ptr() if (lean or f2_src is not None) else None,
         a2.data_ptr(), b2.data_ptr(), c.data_ptr(), res.data_ptr() if res is not None else None,
         out.data_ptr(), out.stride(0) if N > 1 else D,
-        ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.n_cols, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
+        ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
         int(seed), _dev_word(seed_dev), int(row_offset), int(activation),
-        (FLAG_XCD_ORDER if graph.has_locality() else 0) | (FLAG_TILED if tiled else 0) | (FLAG_LEAN if lean else 0),
+        (FLAG_XCD_ORDER if graph.has_locality() else 0) | (FLAG_LEAN if lean else 0),
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_fwd")
     if timing is not None:
         ev1.record()

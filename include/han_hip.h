@@ -43,19 +43,13 @@ extern "C" {
                                   different source windows.  Speed only; off for graphs without structure, where it
                                   measured 9 % slower in the HBM regime (eight separate index / output streams). */
 
-#define HAN_FLAG_TILED 128     /* han_node_attn_fwd on small, very dense graphs (DBLP APTPA is 78 % dense): the caller asserts that
-                                  the ids of every row are ASCENDING, passes the table's scores (f2_src) and asks for the
-                                  LDS-tiled forward kernels -- a block of 16 waves owns 16 rows and walks the table in 256-row
-                                  tiles staged once into LDS; scores are read, not recomputed; the projected-row dropout is
-                                  applied once per staged element and the attention-dropout hash once per (edge, four heads).
-                                  Such graphs are bound by vector-instruction issue, not by memory.  Taken for fp32 tables whose
-                                  index is the global id (table_gid NULL); pays from about half-dense graphs on.              */
-#define HAN_FLAG_LEAN 256      /* han_node_attn_fwd on small graphs whose table lives in the L2s (a few thousand rows) with long rows:
-                                  the same lean per-edge arithmetic as HAN_FLAG_TILED (scores gathered from f2_src instead of
-                                  recomputed, one attention-dropout hash per (edge, four heads)) without the tiles -- any
-                                  density, any id order.  fp32 tables, table_gid NULL.  Not for large tables: the 4-byte score
-                                  gather would cost a memory line per edge there.  han_node_attn_bwd_cols: the same hash sharing in
-                                  its full 4-edge steps (everything else as the gather form).                               */
+#define HAN_FLAG_LEAN 256      /* small graphs whose table lives in the L2s (a few thousand rows) with long rows -- the reference's own
+                                  data sets -- are bound by vector-instruction issue, not by memory.  han_node_attn_fwd then reads
+                                  the neighbour scores from f2_src (a 4-byte gather per edge and head) instead of recomputing them,
+                                  runs the softmax in log2 units and computes ONE attention-dropout hash per (edge, four heads);
+                                  for 8 heads x 8 columns one lane owns a whole head of an edge.  han_node_attn_bwd_cols: the same
+                                  hash sharing, and the one-lane-per-head map for 8 x 8.  fp32 tables, table_gid NULL.  Not for
+                                  large tables: the score gather would cost a memory line per edge there.                      */
 #define HAN_FLAG_MASKED_EDGES 64 /* han_node_attn_bwd_cols: entries of rowidx below 0 are skipped IN PLACE (their destination's
                                   g row is identically zero -- a destination outside the loss mask of a one-layer model);
                                   the remaining terms are summed in the positions and order of the full pass, so the
@@ -194,11 +188,10 @@ size_t han_row_split_workspace(int64_t n_chunks);
  * backward does not need it): pre (N,D)
  * pre-activation, lse (N,K) log-sum-exp of the scores, aggp (N,D) and tsum (N,K)
  * -- the LeakyReLU'-weighted aggregates that make df1 row-local in the backward.
- * NT: rows of the table H (the tiled kernels walk it; 0 = unknown, gather kernels only).
  * f2_src (NT,K) or NULL: the scores of the table rows.  With K = 1, F' = 64 the neighbour score is GATHERED from
  * this table instead of being recomputed from the row -- the slices of a head wider than 64 columns share the
- * head's scores (f1 / f2_src then hold the totals over the slices; a2 / b2 are not read); with HAN_FLAG_TILED the
- * tiled kernels read it for any head shape; otherwise it is not read.  The backward needs nothing
+ * head's scores (f1 / f2_src then hold the totals over the slices; a2 / b2 are not read); with HAN_FLAG_LEAN the
+ * lean kernels read it for any head shape; otherwise it is not read.  The backward needs nothing
  * new: han_node_attn_bwd_cols already takes f2 and df1 as inputs, and its slices' df1 / df2 add up (the
  * softmax backward is linear in d alpha); the caller adds (df2_total - df2_slice) x a2_slice to dH.          */
 int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float *edge_val,
@@ -206,7 +199,7 @@ int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float 
                       int table_dtype, const int32_t *table_gid, const float *f1, const float *f2_src,
                       const float *a2, const float *b2, const float *c, const float *res,
                       float *out, int64_t out_stride, float *pre, float *lse, float *aggp,
-                      float *tsum, int64_t N, int64_t NT, int64_t E, int K, int FP, float slope,
+                      float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
                       float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset,
                       int activation, int flags, const han_row_split_t *split, void *stream);
 

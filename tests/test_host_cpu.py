@@ -63,27 +63,17 @@ def test_csr_from_bias_transpose_and_validation():
     assert gs.rowptr.tolist() == [0, 1, 3] and gs.colidx.tolist() == [1, 0, 1]
 
 
-def test_sorted_rows_property_gates_the_tiled_kernels():
-    """CSRGraph.sorted_rows(): ascending ids within every row (what HAN_FLAG_TILED asserts); ids may drop only at
-    row starts; masked graphs (-1 entries) never qualify; ops._use_tiles additionally wants half-dense fp32 tables."""
+def test_lean_kernels_are_for_small_tables_with_long_rows():
+    """ops._use_lean (HAN_FLAG_LEAN): fp32 tables that fit the L2s (<= 16384 rows) with long rows (mean degree >= 64),
+    any id order."""
     from han_amd import ops
     from han_amd.graph import CSRGraph
-    rp = torch.tensor([0, 3, 3, 5, 6], dtype=torch.int64)
-    g = CSRGraph(rp, torch.tensor([0, 2, 3, 1, 1, 0], dtype=torch.int32), 4)
-    assert g.sorted_rows() and g.transpose().sorted_rows()
-    assert not CSRGraph(rp, torch.tensor([0, 3, 2, 1, 1, 0], dtype=torch.int32), 4).sorted_rows()
-    assert CSRGraph(torch.zeros(3, dtype=torch.int64), torch.zeros(0, dtype=torch.int32), 2).sorted_rows()
-    live = torch.tensor([True, False, True, True])
-    assert not g.with_masked_columns(live).sorted_rows()
-    dense = CSRGraph.from_bias(torch.zeros((1, 6, 6)))                 # every entry an edge
-    tab = torch.zeros((6, 64))
-    assert dense.sorted_rows() and ops._use_tiles(dense, tab) and not ops._use_tiles(dense, tab.to(torch.bfloat16))
-    assert not ops._use_tiles(g, torch.zeros((4, 64)))                 # 6 of 16 entries: below half dense
-    # the lean forward: tables that fit the L2s (<= 16384 rows) with long rows (mean degree >= 64), any id order
     rp2 = torch.arange(0, 100 * 70 + 1, 70, dtype=torch.int64)
     long_rows = CSRGraph(rp2, torch.randint(0, 100, (7000,), dtype=torch.int32), 100)
-    assert ops._use_lean(long_rows, torch.zeros((100, 64))) and not ops._use_lean(long_rows, torch.zeros((100, 64), dtype=torch.bfloat16))
-    assert not ops._use_lean(g, torch.zeros((4, 64)))
+    assert ops._use_lean(long_rows, torch.zeros((100, 64)))
+    assert not ops._use_lean(long_rows, torch.zeros((100, 64), dtype=torch.bfloat16))
+    short = CSRGraph(torch.tensor([0, 3, 3, 5, 6], dtype=torch.int64), torch.tensor([0, 2, 3, 1, 1, 0], dtype=torch.int32), 4)
+    assert not ops._use_lean(short, torch.zeros((4, 64)))
     big = CSRGraph(torch.zeros(20001, dtype=torch.int64), torch.zeros(0, dtype=torch.int32), 20000)
     assert not ops._use_lean(big, torch.zeros((20000, 64)))
 

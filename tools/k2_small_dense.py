@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""K2 on small dense graphs (the reference's own data-set shapes): the LDS-tiled (HAN_FLAG_TILED) and lean (HAN_FLAG_LEAN)
-forward kernels against the gather kernels on the same inputs -- time per launch and the largest difference of the outputs.
-One JSON line per (graph, kernel).  `python tools/k2_tiled.py [n=4057 dens=0.78,0.30,0.24]`"""
+"""K2 on small dense graphs (the reference's own data-set shapes): the lean kernels (HAN_FLAG_LEAN: scores read from
+the table, shared dropout hash, one lane per head at 8 x 8) against the gather kernels on the same inputs -- time per
+launch and the largest difference of the outputs.  One JSON line per graph.
+`python tools/k2_small_dense.py [n=4057 dens=0.78,0.30,0.24]`"""
 import json
 import os
 import sys
@@ -30,9 +31,9 @@ def main():
         H, f1, f2 = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.6, fts_drop=0.6, seed=3)
         dOut = rnd(n, 64)
         res = {}
-        for mode in ("gather", "tiled", "lean"):
-            ops.TILED, ops.LEAN = mode == "tiled", mode == "lean"
-            used = ops._use_tiles(g, H) if mode == "tiled" else (ops._use_lean(g, H) if mode == "lean" else True)
+        for mode in ("gather", "lean"):
+            ops.LEAN = mode == "lean"
+            used = ops._use_lean(g, H) if mode == "lean" else True
             out_e, _ = ops.node_attn_fwd(g, H, f1, a2, b2, c, f2=f2)
             t_e = timeit(lambda: ops.node_attn_fwd(g, H, f1, a2, b2, c, f2=f2))
             out_t, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, train=True, coef_drop=0.6, fts_drop=0.6, seed=3, f2=f2)
@@ -45,14 +46,14 @@ def main():
         a = res["gather"]
         line = {"n": n, "density": dens, "edges": g.nnz,
                 "gather_ms": {k: round(a[k], 4) for k in ("eval_ms", "train_ms", "bwd_ms")}}
-        for mode in ("tiled", "lean"):
+        for mode in ("lean",):
             b = res[mode]
             diff = {k: float((a[k] - b[k]).abs().max()) for k in ("out_e", "out_t", "pre", "lse", "aggp", "tsum", "dH", "df2")}
             line[mode] = {"taken": b["used"], "eval_ms": round(b["eval_ms"], 4), "train_ms": round(b["train_ms"], 4),
                           "bwd_ms": round(b["bwd_ms"], 4),
                           "max_abs_diff": {k: float(f"{v:.3g}") for k, v in diff.items()}}
         print(json.dumps(line), flush=True)
-    ops.TILED = ops.LEAN = True
+    ops.LEAN = True
 
 
 if __name__ == "__main__":
