@@ -136,12 +136,51 @@ __global__ __launch_bounds__(256) void classifier_kernel(const ClsArgs a) {
             }
         }
     }
-    // block reduction: 16 groups -> one slab row.  Serialise the groups through
-    // Wm-sized scratch (one group adds at a time; 16 barriers, once per block).
+    // block reduction: 16 groups -> one slab row.
     __syncthreads();
     float *scr = Wm;                  // [D*C]
     __shared__ float sc2[MAXC + 2];   // db | loss | acc
     const int grp = threadIdx.x >> 4;
+    // Small class counts (the 16 groups' partial rows fit 33 KB of LDS): every group writes its row, ONE barrier,
+    // every thread adds the 16 partials of its columns in group order -- instead of 16 barrier rounds through one
+    // scratch row (at the size of the reference's data sets those rounds were half of this kernel's 14 us).
+    constexpr int PW = D * CM + CM + 2;                 // dW | db | loss | acc of one group
+    constexpr bool PAR = PW * 16 * 4 <= 34 * 1024;
+    __shared__ float part[PAR ? 16 * PW : 1];
+    if (PAR) {
+        float *mine = part + grp * PW;
+        if (BWD) {
+#pragma unroll
+            for (int c = 0; c < CM; ++c)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) mine[(64 * (t >> 2) + 4 * q + (t & 3)) * CM + c] = dW[t][c];
+            if (q == 0) {
+#pragma unroll
+                for (int c = 0; c < CM; ++c) mine[D * CM + c] = dbacc[c];
+            }
+        }
+        if (q == 0) {
+            mine[D * CM + CM] = loss_acc;
+            mine[D * CM + CM + 1] = acc_acc;
+        }
+        __syncthreads();
+        const int width = D * C + C + 2;
+        float *out = a.slab + (int64_t)blockIdx.x * width;
+        for (int i = threadIdx.x; i < width; i += 256) {
+            int src;                                        // column i of the slab row -> its slot in a group's partial row
+            if (i < D * C) src = (i / C) * CM + (i % C);
+            else if (i < D * C + C) src = D * CM + (i - D * C);
+            else src = D * CM + CM + (i - D * C - C);
+            float v = 0.f;
+            if (BWD || i >= D * C + C) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v += part[r * PW + src];
+            }
+            out[i] = v;
+        }
+        return;
+    }
+    // larger class bounds: serialise the groups through Wm-sized scratch (one group adds at a time; 16 barriers)
     for (int r = 0; r < 16; ++r) {
         if (grp == r) {
             if (BWD) {
