@@ -351,7 +351,9 @@ class WideHeadAttention(torch.autograd.Function):
 
     forward(Xin, W (P,F,S*64), a1 (P,S*64), b1 (P,), a2 (P,S*64), b2 (P,), c (P,S*64), Wr, br, xs, graphs, cfg) -> M (N,P,S*64);
     columns beyond F' carry zero weights (their outputs are exactly act(0 + 0) and are cut off by the caller).
-    cfg as for NodeLevelAttention; single GPU (a node partition would also have to exchange f2)."""
+    cfg as for NodeLevelAttention.  Under a node partition every slice's table travels like a narrow head's (halo plan or
+    all-gather, its own persistent exchange table) and so do the head's f2 totals (4 bytes per row); the forward is
+    never replicated (xs_full is not used) and the backward exchanges one [g | stats] table per slice."""
 
     @staticmethod
     def forward(ctx, Xin, W, a1, b1, a2, b2, c, Wr, br, xs, graphs, cfg):
@@ -360,9 +362,10 @@ class WideHeadAttention(torch.autograd.Function):
             Xin = Xin.contiguous()
             xs = tuple(Xin[:, p, :] for p in range(P))
         part = cfg.get("part")
-        if part is not None and part.active:
-            raise NotImplementedError("heads wider than 64 columns under a node partition (the slices' f2 totals would "
-                                      "have to be exchanged as well)")
+        multi = part is not None and part.active
+        row_offset = part.row_start if part is not None else 0
+        plans_f = cfg.get("plans_f") if multi else None
+        lay, grp = cfg.get("layer", 0), cfg.get("group", 0)
         S = W.shape[2] // D
         train = bool(cfg["train"])
         in_drop = float(cfg.get("in_drop", 0.0)) if train else 0.0
@@ -377,32 +380,40 @@ class WideHeadAttention(torch.autograd.Function):
             seed = int(cfg["seeds"][p])
             Ws = W[p].view(-1, S, D).permute(1, 0, 2).contiguous()          # (S,F,64)
             a1s, a2s, cs = a1[p].view(S, 1, D), a2[p].view(S, 1, D), c[p].view(S, D)
-            Hs, f1, f2, Rs = [], None, None, []
+            plan = plans_f[p] if plans_f is not None else None
+            exchange = (plan.exchange_async if plan is not None else part.all_gather_rows_async) if multi else None
+            Hs, Htabs, f1, f2, Rs = [], [], None, None, []
             for s_ in range(S):
                 fl = ops.flag_fts_slice(s_)
                 H, f1s, f2s = ops.project_fwd(xs[p], Ws[s_], a1s[s_], a2s[s_], b1[p:p + 1] if s_ == 0 else zero1,
                                               b2[p:p + 1] if s_ == 0 else zero1, in_drop=in_drop, fts_drop=in_drop,
-                                              seed=seed, table_dtype=tdt, seed_dev=seed_dev, flags=fl)
+                                              seed=seed, row_offset=row_offset, table_dtype=tdt, seed_dev=seed_dev, flags=fl)
                 Hs.append(H)
+                Htabs.append(exchange(H, ("wf", lay, grp, p, s_)) if multi else _Ready(H))
                 f1 = f1s if f1 is None else f1 + f1s
                 f2 = f2s if f2 is None else f2 + f2s
                 R = None
                 if Wr is not None:      # residual conv1d(seq, F', 1) of the DROPPED input (layers.py:38-40): same draws
                     Wrs = Wr[p].view(-1, S, D)[:, s_, :].contiguous()
                     R, _, _ = ops.project_fwd(xs[p], Wrs, a1s[s_], a2s[s_], zero1, zero1, in_drop=in_drop, fts_drop=0.0,
-                                              seed=seed, seed_dev=seed_dev)
+                                              seed=seed, row_offset=row_offset, seed_dev=seed_dev)
                     R = R + br[p].view(S, D)[s_]
                 Rs.append(R)
             if cfg.get("coef_sink") is not None:
+                if multi:
+                    raise NotImplementedError("return_coef is not provided under a node partition")
                 cfg["coef_sink"].append(ops.node_attn_coefs(graphs[p], f1, f2, coef_drop=coef_drop, seed=seed,
                                                             mean_heads=bool(cfg.get("coef_mean", False)),
                                                             seed_dev=seed_dev))
+            f2_tab = exchange(f2, ("wf2", lay, grp, p)).wait() if multi else f2      # the head's scores of every table row
             per_s = []
             for s_ in range(S):
-                _, sv = ops.node_attn_fwd(graphs[p], Hs[s_], f1, a2s[s_], b2[p:p + 1], cs[s_],
+                _, sv = ops.node_attn_fwd(plan.graph if plan is not None else graphs[p], Htabs[s_].wait(), f1, a2s[s_],
+                                          b2[p:p + 1], cs[s_],
                                           out=M[:, p, s_ * D:(s_ + 1) * D], train=train, coef_drop=coef_drop,
-                                          fts_drop=in_drop, seed=seed, activation=cfg["act"], res=Rs[s_],
-                                          seed_dev=seed_dev, f2_src=f2)
+                                          fts_drop=in_drop, seed=seed, row_offset=row_offset, activation=cfg["act"],
+                                          table_gid=plan.gid if plan is not None else None, res=Rs[s_],
+                                          seed_dev=seed_dev, f2_src=f2_tab)
                 if train:
                     per_s.append((Hs[s_],) + sv + (Rs[s_],))
             if train:
@@ -427,6 +438,11 @@ class WideHeadAttention(torch.autograd.Function):
         dM = dM.contiguous()
         graphs_t = cfg.get("graphs_t") or tuple(g.transpose() for g in graphs)
         seed_dev = cfg.get("seed_dev")
+        part = cfg.get("part")
+        multi = part is not None and part.active
+        row_offset = part.row_start if part is not None else 0
+        plans_b = cfg.get("plans_b") if multi else None
+        lay, grp = cfg.get("layer", 0), cfg.get("group", 0)
         dW = torch.empty((P, S, Fw, D), dtype=torch.float32, device=dev)
         da1, da2, dc = torch.empty_like(a1), torch.empty_like(a2), torch.empty_like(c)
         db1 = torch.empty((P,), dtype=torch.float32, device=dev)
@@ -439,27 +455,32 @@ class WideHeadAttention(torch.autograd.Function):
             f1, f2, per_s = ctx.saved_per_p[p]
             seed = int(cfg["seeds"][p])
             a1s, a2s, cs = a1[p].view(S, 1, D), a2[p].view(S, 1, D), c[p].view(S, D)
+            plan = plans_b[p] if plans_b is not None else None
+            exchange = (plan.exchange_async if plan is not None else part.all_gather_rows_async) if multi else None
             rows, df1 = [], None
             for s_ in range(S):       # row-local halves: g, the slice's share of df1
                 H, pre, lse, aggp, tsum, R = per_s[s_]
                 gs, df1s, _ = ops.node_attn_bwd_rows(dM[:, p, s_ * D:(s_ + 1) * D], pre, aggp, tsum, f1, lse, cs[s_],
                                                      activation=cfg["act"], K=1, FP=D, table_dtype=H.dtype, res=R,
                                                      dc_out=dc[p, s_ * D:(s_ + 1) * D])
-                rows.append(gs)
+                rows.append(exchange(gs, ("wb", lay, grp, p, s_)) if multi else _Ready(gs))      # one [g | stats] table per slice
                 df1 = df1s if df1 is None else df1 + df1s
                 if Wr is not None:
                     g32 = ops.gs_views(gs, 1, D, H.dtype)[0].to(torch.float32).contiguous()
-                    ops.project_bwd(xs[p], g32, 1, D, in_drop=ctx.in_drop, seed=seed, seed_dev=seed_dev, out=dWr[p, s_])
+                    ops.project_bwd(xs[p], g32, 1, D, in_drop=ctx.in_drop, seed=seed, row_offset=row_offset,
+                                    seed_dev=seed_dev, out=dWr[p, s_])
                     if dXin is not None:
                         Wrs = Wr[p].view(-1, S, D)[:, s_, :].contiguous()
                         dXin[:, p, :] += ops.project_bwd_input(g32, Wrs, 1, D, in_drop=ctx.in_drop, seed=seed,
-                                                               seed_dev=seed_dev)
+                                                               row_offset=row_offset, seed_dev=seed_dev)
             cols, df2 = [], None
             for s_ in range(S):       # transposed-graph halves with the head's df1; each returns its share of df2
                 H = per_s[s_][0]
-                dH, df2s = ops.node_attn_bwd_cols(graphs_t[p], rows[s_], H, f2, df1, a1s[s_], a2s[s_],
+                dH, df2s = ops.node_attn_bwd_cols(plan.graph if plan is not None else graphs_t[p], rows[s_].wait(), H, f2,
+                                                  df1, a1s[s_], a2s[s_],
                                                   coef_drop=ctx.coef_drop, fts_drop=ctx.in_drop, seed=seed,
-                                                  seed_dev=seed_dev)
+                                                  src_offset=row_offset, dst_offset=0,
+                                                  table_gid=plan.gid if plan is not None else None, seed_dev=seed_dev)
                 cols.append((dH, df2s))
                 df2 = df2s if df2 is None else df2 + df2s
             for s_ in range(S):
@@ -470,11 +491,12 @@ class WideHeadAttention(torch.autograd.Function):
                 o1 = torch.empty((1,), dtype=torch.float32, device=dev) if s_ else db1[p:p + 1]
                 o2 = torch.empty((1,), dtype=torch.float32, device=dev) if s_ else db2[p:p + 1]
                 ops.score_param_bwd(H, df1, df2, K=1, FP=D, out=(da1[p].view(S, 1, D)[s_], da2[p].view(S, 1, D)[s_], o1, o2))
-                ops.project_bwd(xs[p], dH, 1, D, in_drop=ctx.in_drop, seed=seed, seed_dev=seed_dev, out=dW[p, s_])
+                ops.project_bwd(xs[p], dH, 1, D, in_drop=ctx.in_drop, seed=seed, row_offset=row_offset, seed_dev=seed_dev,
+                                out=dW[p, s_])
                 if dXin is not None:
                     Ws = W[p].view(-1, S, D)[:, s_, :].contiguous()
                     dXin[:, p, :] += ops.project_bwd_input(dH, Ws, 1, D, in_drop=ctx.in_drop, seed=seed,
-                                                           seed_dev=seed_dev)
+                                                           row_offset=row_offset, seed_dev=seed_dev)
         ctx.saved_per_p = None
         fold = lambda t: t.permute(0, 2, 1, 3).reshape(P, Fw, S * D)
         return (dXin, fold(dW), da1, db1, da2, db2, dc, fold(dWr) if dWr is not None else None,

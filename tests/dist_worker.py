@@ -64,7 +64,9 @@ def run(rank, world, device, epochs, drop, out_path, port, use_cpu_backend):
     hrng.manual_seed(77)
     gen = torch.Generator().manual_seed(3)
     bf16 = os.environ.get("HAN_TEST_BF16") == "1"            # configs[4] storage: X, H and g tables in bf16
-    model = HeteGAT_multi().build(p, f, c, device=dev, generator=gen,
+    hid = int(os.environ.get("HAN_TEST_HID", "8"))       # e.g. 96: heads wider than 64 columns (layers.WideHeadAttention)
+    heads = (8, 1) if hid == 8 else (2, 1)
+    model = HeteGAT_multi().build(p, f, c, hid_units=(hid,), n_heads=heads, device=dev, generator=gen,
                                   table_dtype=torch.bfloat16 if bf16 else torch.float32)
     if bf16:
         x = x.to(torch.bfloat16)

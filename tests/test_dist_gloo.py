@@ -158,3 +158,22 @@ def test_masked_backward_is_bit_identical_to_the_full_pass(tmp_path, weighted):
     assert np.array_equal(outs["full8"]["flat"], outs["mask8"]["flat"])
     assert np.array_equal(outs["full8"]["hist"], outs["mask8"]["hist"])
     assert np.abs(outs["full1"]["flat"] - outs["full8"]["flat"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("graph,port", [("", 29871), ("band", 29881)])
+def test_wide_heads_under_a_node_partition(tmp_path, graph, port):
+    """hid_units = [96] (two heads of two 64-column slices each, layers.WideHeadAttention) on 2 ranks: every slice's
+    table and the heads' f2 totals are exchanged (all-gather on the random graphs, halo plans on the banded ones), the
+    backward moves one [g | stats] table per slice; parameters and metrics equal the single-process run."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    env = {"HAN_TEST_HID": "96"}
+    if graph:
+        env["HAN_TEST_GRAPH"] = graph
+    _launch(1, 2, 0.6, one, port, env)
+    _launch(2, 2, 0.6, two, port + 2, env)
+    a, b = np.load(one), np.load(two)
+    assert np.isfinite(a["flat"]).all()
+    if graph:
+        assert int(b["halo_plans"]) == 4
+    assert np.abs(a["flat"] - b["flat"]).max() < 1e-5
+    assert np.abs(a["hist"] - b["hist"]).max() < 1e-5

@@ -128,3 +128,20 @@ def test_masked_backward_real_kernels_bit_identical(dev, tmp_path, bf16):
     assert np.abs(outs["full1"]["flat"] - outs["mask1"]["flat"]).max() < tol
     assert np.abs(outs["full1"]["flat"] - outs["mask2"]["flat"]).max() < tol
     assert np.abs(outs["full1"]["hist"] - outs["mask2"]["hist"]).max() < tol
+
+
+@pytest.mark.parametrize("graph", ["", "band"])
+def test_wide_heads_two_ranks_real_kernels(dev, tmp_path, graph):
+    """hid_units = [96] under a node partition on the real kernels (layers.WideHeadAttention): per slice one exchanged
+    H table and one [g | stats] table, the heads' f2 totals gathered by K2 from their own exchanged table; all-gather
+    and halo mode, with dropout; equals the single-process run."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    env = {"HAN_TEST_HID": "96"}
+    if graph:
+        env["HAN_TEST_GRAPH"] = graph
+    _launch(1, 3, 0.6, one, 29691, env)
+    _launch(2, 3, 0.6, two, 29693, env)
+    a, b = np.load(one), np.load(two)
+    assert np.isfinite(a["flat"]).all()
+    assert np.abs(a["flat"] - b["flat"]).max() < 2e-5
+    assert np.abs(a["hist"] - b["hist"]).max() < 2e-5
