@@ -950,6 +950,49 @@ def test_lean_kernels_edge_values_and_ragged_rows(dev):
                 assert float(res[0][0][3].abs().max()) < 1.0 and torch.isfinite(res[0][1]).all()      # the empty row: act(c)
 
 
+def test_lean_kernels_row_length_edges(dev):
+    """Row lengths around every boundary of the lean kernels' walk -- 64-entry pieces, 16-edge steps, the two edges of
+    an 8-lane group, the four of a 16-lane group -- for the one-lane-per-head (8 x 8) and the 16-lane (4 x 16) forms,
+    forward (eval, training) and backward gather, against the gather kernels."""
+    from han_amd import ops
+    from han_amd.graph import CSRGraph
+    lens = [0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 79, 80, 81, 127, 128, 129, 191,
+            192, 193, 255, 256]
+    n = 256
+    gen = torch.Generator(device=dev).manual_seed(9)
+    deg = torch.tensor((lens * ((n + len(lens) - 1) // len(lens)))[:n], device=dev)
+    deg = torch.maximum(deg, torch.full_like(deg, 64 + 8))          # keep the mean degree above the lean threshold ...
+    deg[:len(lens)] = torch.tensor(lens, device=dev)                 # ... while the first rows take every edge length
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = deg.cumsum(0)
+    colidx = torch.cat([torch.randperm(n, generator=gen, device=dev)[:int(d)] for d in deg.tolist()]).to(torch.int32)
+    g = CSRGraph(rowptr, colidx.contiguous(), n)
+    gt = g.transpose()
+    for K, FP in ((8, 8), (4, 16)):
+        a1, a2 = (torch.randn((K, FP), device=dev, generator=gen) * 0.3 for _ in range(2))
+        b1, b2 = (torch.randn(K, device=dev, generator=gen) * 0.1 for _ in range(2))
+        c = torch.randn(64, device=dev, generator=gen) * 0.1
+        X = torch.randn((n, 12), device=dev, generator=gen)
+        W = torch.randn((12, 64), device=dev, generator=gen) * 0.3
+        dOut = torch.randn((n, 64), device=dev, generator=gen)
+        H, f1, f2 = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.3, fts_drop=0.3, seed=21)
+        res = []
+        for lean in (True, False):
+            ops.LEAN = lean
+            try:
+                assert ops._use_lean(g, H) == lean and ops._use_lean(gt, H) == lean
+                oe, _ = ops.node_attn_fwd(g, H, f1, a2, b2, c, f2=f2)
+                ot, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, train=True, coef_drop=0.3, fts_drop=0.3, seed=21, f2=f2)
+                gs, df1, dc = ops.node_attn_bwd_rows(dOut, ot, sv[2], sv[3], f1, sv[1], c, K=K, FP=FP)
+                dH, df2 = ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, coef_drop=0.3, fts_drop=0.3, seed=21)
+            finally:
+                ops.LEAN = True
+            res.append((oe, ot.clone()) + sv[1:] + (dH, df2))
+        for name, a_, b_ in zip(("eval", "train", "lse", "aggp", "tsum", "dH", "df2"), *res):
+            scale = float(b_.abs().max()) + 1.0
+            assert float((a_ - b_).abs().max()) < 5e-5 * scale, (K, FP, name)
+
+
 def test_return_coef_and_hetegat_class(dev):
     """attn_head(..., return_coef=True) (layers.py:43-44) and HeteGAT.inference(...,
     return_coef=True) (models/gat.py:132-203: shared inputs, head-mean coefficients per
