@@ -315,7 +315,11 @@ __global__ __launch_bounds__(256) void sem_attn_fwd_wave_b6_kernel(const float *
     constexpr int A = 64 * CA;
     constexpr int TA = A / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned char *Wt = reinterpret_cast<unsigned char *>(smem);      // [3][A][144 B]
+    // [3][A][128 B], XOR-swizzled: the 16-byte chunk g of row a sits at chunk g ^ ((a >> 1) & 7).  Two 128-B rows span
+    // the 64 banks, so the 16 lanes that read chunk g of 16 consecutive rows (8 of each parity) hit 64 different banks
+    // WITHOUT padding the rows to 144 B -- 48 KB instead of 54 KB at A = 128: three blocks per CU instead of two (round 3)
+    constexpr int FWLDB = 128;
+    unsigned char *Wt = reinterpret_cast<unsigned char *>(smem);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     // Womega (64 x A, row-major [k][a]) -> split, transposed: item (a, g) = 8 k-values 8g..8g+7 of column a
@@ -326,10 +330,10 @@ __global__ __launch_bounds__(256) void sem_attn_fwd_wave_b6_kernel(const float *
         for (int j = 0; j < 8; ++j) v[j] = Wg[(8 * g + j) * A + acol];
         sa_i32x4 fh, fm, fl;
         sa_split8(v, fh, fm, fl);
-        unsigned char *dst = Wt + acol * SA_WLDB + g * 16;
+        unsigned char *dst = Wt + acol * FWLDB + ((g ^ ((acol >> 1) & 7)) * 16);
         *reinterpret_cast<sa_i32x4 *>(dst) = fh;
-        *reinterpret_cast<sa_i32x4 *>(dst + A * SA_WLDB) = fm;
-        *reinterpret_cast<sa_i32x4 *>(dst + 2 * A * SA_WLDB) = fl;
+        *reinterpret_cast<sa_i32x4 *>(dst + A * FWLDB) = fm;
+        *reinterpret_cast<sa_i32x4 *>(dst + 2 * A * FWLDB) = fl;
     }
     __syncthreads();
     float bcol[TA], ucol[TA];
@@ -383,10 +387,10 @@ __global__ __launch_bounds__(256) void sem_attn_fwd_wave_b6_kernel(const float *
             f32x4 c = acc[t];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const unsigned char *wb = Wt + (16 * t + l15) * SA_WLDB + (32 * s2 + 8 * l4) * 2;
+                const unsigned char *wb = Wt + (16 * t + l15) * FWLDB + (((4 * s2 + l4) ^ ((l15 >> 1) & 7)) * 16);
                 const sa_i32x4 bh = *reinterpret_cast<const sa_i32x4 *>(wb);
-                const sa_i32x4 bm = *reinterpret_cast<const sa_i32x4 *>(wb + A * SA_WLDB);
-                const sa_i32x4 bl = *reinterpret_cast<const sa_i32x4 *>(wb + 2 * A * SA_WLDB);
+                const sa_i32x4 bm = *reinterpret_cast<const sa_i32x4 *>(wb + A * FWLDB);
+                const sa_i32x4 bl = *reinterpret_cast<const sa_i32x4 *>(wb + 2 * A * FWLDB);
                 c = sa_mfma(af[s2][1], bm, c);      // small terms first
                 c = sa_mfma(af[s2][2], bh, c);
                 c = sa_mfma(af[s2][0], bl, c);
@@ -1668,8 +1672,8 @@ int launch_fwd(const float *M, const float *w, const float *b, const float *u, f
     }
     if ((P == 1 || P == 2 || P == 4 || P == 8 || P == 16) && N * P >= 64 * 1024 && !(flags & HAN_FLAG_K3_EXACT_PIPE)) {
         // large inputs: the contraction on the bf16 matrix pipe (exact 3-way split, fp32-class accuracy)
-        const size_t blds = (size_t)3 * 64 * CA * SA_WLDB;
-        const int grid = han_grid_for(N * P, 64, 256 * 2);
+        const size_t blds = (size_t)3 * 64 * CA * 128;       // swizzled 128-B rows (sem_attn_fwd_wave_b6_kernel)
+        const int grid = han_grid_for(N * P, 64, 256 * 3);
         hipError_t e2 = hipSuccess;
 #define HAN_LAUNCH_FWD_B6(PV)                                                                            \
     e2 = hipFuncSetAttribute((const void *)sem_attn_fwd_wave_b6_kernel<CA, PV>,                          \
