@@ -173,10 +173,22 @@ static __global__ __launch_bounds__(256) void han_reduce_slabs_kernel(const floa
     __shared__ float part[16][17];
     const int nn = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int n = blockIdx.x * 16 + nn;
-    float s = 0.f;
-    if (n < width)
-        for (int b = sl; b < nblocks; b += 16) s += slab[(int64_t)b * row_stride + n];
-    part[sl][nn] = s;
+    // four independent partial sums per thread (rows sl, sl + 16, sl + 32, sl + 48 (mod 64)): the loads of a step do
+    // not wait for each other -- at the slab counts of small graphs the chain of dependent L2 round trips WAS the
+    // kernel (8 us for a 64-float result); the order of the additions is fixed, so the result stays reproducible
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (n < width) {
+        const float *col = slab + n;
+        int b = sl;
+        for (; b + 48 < nblocks; b += 64) {
+            s0 += col[(int64_t)b * row_stride];
+            s1 += col[(int64_t)(b + 16) * row_stride];
+            s2 += col[(int64_t)(b + 32) * row_stride];
+            s3 += col[(int64_t)(b + 48) * row_stride];
+        }
+        for (; b < nblocks; b += 16) s0 += col[(int64_t)b * row_stride];
+    }
+    part[sl][nn] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (sl == 0 && n < width) {
         float t = 0.f;
