@@ -27,11 +27,64 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+# --------------------------------------------------------------------------- rank launcher
+def _gpus_from_argv(argv):
+    """--gpus N / --gpus=N from the raw argument list (stdlib only: this runs before torch is imported)."""
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    return n
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(argv, port=None):
+    """The command that starts the N ranks of `python bench.py --gpus N ...`: torch.distributed.run on this
+    very file with the caller's arguments passed through unchanged (one process per GPU, rendezvous on 127.0.0.1)."""
+    n = _gpus_from_argv(argv)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or _free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks_if_needed(argv, environ=None, run=None):
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment (i.e. NOT already started by
+    torchrun): this process becomes a pure parent -- it starts the N ranks as child processes, lets rank 0's
+    JSON line through on the inherited stdout, and returns the children's exit code.  It runs before torch is
+    imported and never touches the GPU; nothing is exec'd.  Returns None when there is nothing to launch
+    (N = 1, or this process IS a rank)."""
+    environ = os.environ if environ is None else environ
+    n = _gpus_from_argv(argv)
+    if n <= 1 or "RANK" in environ:
+        return None
+    import subprocess
+    env = dict(environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launcher_command(argv)
+    rc = (run or subprocess.call)(cmd, env=env, cwd=ROOT)
+    return int(rc)
+
+
+if __name__ == "__main__":
+    _rc = launch_ranks_if_needed(sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming copy)
 HBM_COPY_GBS = 6290.0      # same guide: what a float4 streaming copy reaches; random whole-row gathers: 5.5-5.8 TB/s
@@ -496,7 +549,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:      # N > 1 without RANK was turned into N ranks by launch_ranks_if_needed above
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # a tree without the built library (a fresh checkout: the .so is git-ignored): compile it once,
     # before anything touches the GPU -- local rank 0 builds, the others wait for the file
@@ -599,6 +652,10 @@ def main():
     for _ in range(args.warmup):
         trainer.epoch()
     barrier()
+    comm = None
+    if part is not None:
+        from han_amd.dist import CommStats
+        comm = part.comm = CommStats()
     ops.K2_TIMING = None if trainer.use_graph else []      # a replayed graph records no events
     ms0 = torch.cuda.memory_stats(dev) if os.environ.get("HAN_BENCH_DIAG") else None
     t0 = time.perf_counter()
@@ -614,6 +671,22 @@ def main():
               "reserved GB %.1f allocated peak GB %.1f" % (ms1["reserved_bytes.all.current"] / 1e9,
                                                             ms1["allocated_bytes.all.peak"] / 1e9), file=sys.stderr)
     timing, ops.K2_TIMING = ops.K2_TIMING or [], None
+    comm_info = None
+    if part is not None:
+        part.comm = None
+        # max over ranks of the time the compute stream waited for collectives, per step
+        cw = torch.tensor([comm.wait_ms() / args.steps], dtype=torch.float64,
+                          device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(cw, op=dist.ReduceOp.MAX)
+        comm_info = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                     "exchange_bytes_received": int(comm.bytes_received // args.steps),
+                     "exchanges_per_step": comm.exchanges // args.steps,
+                     "grad_allreduce_bytes": int(comm.allreduce_bytes // args.steps),
+                     "comm_wait_ms": round(float(cw.item()), 3),
+                     "comm_note": "per rank and step (one epoch): exchange_bytes_received = table rows this rank "
+                                  "received (all-gather blocks of the other ranks / halo rows); comm_wait_ms = HIP "
+                                  "events on the compute stream around every wait for a collective (+ host time of "
+                                  "host-staged gloo collectives), max over ranks"}
     use_graph = trainer.use_graph
     masked_info = None
     if args.masked_backward and not use_graph:
@@ -696,6 +769,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
+            **(comm_info or {}),
             "dtype": "f32" if args.table_dtype == "f32" else "bf16 storage / f32 accumulate",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: N={n} nodes, P={p} meta-paths, "

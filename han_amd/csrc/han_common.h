@@ -94,6 +94,8 @@ __host__ __device__ __forceinline__ uint32_t han_keep_threshold(float keep_prob)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t han_f32_to_bf16_bits(float f) {
     const uint32_t u = __float_as_uint(f);
+    // a NaN stays a (quiet) NaN: the rounding add would carry 0x7FFFxxxx into the sign bit
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 

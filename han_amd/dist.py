@@ -26,11 +26,43 @@ Two exchange modes per (meta-path, direction), chosen at setup by `plan_exchange
 from __future__ import annotations
 
 import os
+import time
 
 import torch
 import torch.distributed as dist
 
 from .graph import CSRGraph
+
+
+class CommStats:
+    """What a measured region exchanged (bench.py's N > 1 line): bytes this rank RECEIVED in table
+    exchanges (all-gather: the other ranks' blocks; halo: the halo rows), the size of the all-reduced
+    gradient buffer, and HIP events on the compute stream around every wait for a collective -- the time
+    the compute stream stood still for the links (0 when the exchange was fully hidden behind kernels).
+    Attach with `part.comm = CommStats()`; None (the default) records nothing."""
+
+    def __init__(self):
+        self.bytes_received = 0
+        self.allreduce_bytes = 0
+        self.exchanges = 0
+        self.host_ms = 0.0          # host-staged (gloo rehearsal) collectives complete on the host: wall time there
+        self._events = []
+
+    def received(self, nbytes: int):
+        self.bytes_received += int(nbytes)
+        self.exchanges += 1
+
+    def bracket(self, device):
+        """(start, stop) events on the current stream of `device`, or None off the GPU."""
+        if device.type != "cuda":
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self._events.append((e0, e1))
+        return e0, e1
+
+    def wait_ms(self) -> float:
+        """Sum of the bracketed waits (call after a device synchronize)."""
+        return float(sum(e0.elapsed_time(e1) for e0, e1 in self._events)) + self.host_ms
 
 
 class NodePartition:
@@ -54,6 +86,7 @@ class NodePartition:
         # exercise the RCCL calls on a single-GPU box)
         self.active = self.world > 1 or os.environ.get("HAN_FORCE_COLLECTIVES") == "1"
         self._bufs: dict = {}       # exchange tables, allocated once per (tag, shape, dtype) and reused every step
+        self.comm: CommStats | None = None
 
     def buffer(self, tag, shape, dtype, device) -> torch.Tensor:
         """Persistent exchange buffer.  `tag` names the use (direction, layer, meta-path): a buffer is
@@ -174,14 +207,19 @@ class NodePartition:
         else:
             padded = local.contiguous()
         table = self.buffer(tag, (per * self.world,) + tail, local.dtype, local.device)
+        if self.comm is not None:
+            self.comm.received((self.world - 1) * padded.numel() * padded.element_size())
         if self._backend() == "nccl":
             work = dist.all_gather_into_tensor(table, padded, group=self.group, async_op=True)
-            return GatheredTable(table, work, keep=padded)
+            return GatheredTable(table, work, keep=padded, comm=self.comm)
         # gloo (CPU rehearsal / single-GPU multi-process tests): stage through host, as raw bytes
+        t0 = time.perf_counter()
         src = padded.cpu().contiguous().view(torch.uint8)
         parts = [torch.empty_like(src) for _ in range(self.world)]
         dist.all_gather(parts, src, group=self.group)
         table.copy_(torch.cat(parts, 0).view(table.dtype).view(table.shape))
+        if self.comm is not None:
+            self.comm.host_ms += (time.perf_counter() - t0) * 1e3
         return GatheredTable(table, None)
 
     def all_to_all_v(self, out: torch.Tensor, inp: torch.Tensor, recv_splits, send_splits, async_op=False):
@@ -194,6 +232,7 @@ class NodePartition:
             work = dist.all_to_all_single(out, inp.contiguous(), list(recv_splits), list(send_splits),
                                           group=self.group, async_op=async_op)
             return work if async_op else out
+        t0 = time.perf_counter()
         raw = out.dtype == torch.bfloat16 and inp.dim() >= 2        # gloo point-to-point: move bf16 rows as bytes
         src = inp.contiguous().cpu()
         dst = torch.empty(out.shape, dtype=out.dtype)
@@ -219,6 +258,8 @@ class NodePartition:
                     dist.recv(buf, peer, group=self.group)
                     dst[roff[peer]:roff[peer + 1]] = buf
         out.copy_(dst.view(out.dtype) if raw else dst)
+        if self.comm is not None:
+            self.comm.host_ms += (time.perf_counter() - t0) * 1e3
         return None if async_op else out
 
     def plan_exchange(self, g_local: CSRGraph, max_halo_fraction: float = 0.6):
@@ -234,12 +275,22 @@ class NodePartition:
     def all_reduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
         if not self.active:
             return flat
+        ev = None
+        if self.comm is not None:
+            self.comm.allreduce_bytes += flat.numel() * flat.element_size()
+            ev = self.comm.bracket(flat.device)
+        if ev is not None:
+            ev[0].record()
         if self._backend() == "nccl" or not flat.is_cuda:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if ev is not None:
+                ev[1].record()
         else:
             host = flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             flat.copy_(host)
+            if ev is not None:
+                ev[1].record()
         return flat
 
 
@@ -340,20 +391,27 @@ class HaloPlan:
         packed = part.buffer(None if tag is None else (tag, "pack"), (self.send_idx.numel(),) + tail,
                              local.dtype, local.device)
         torch.index_select(local, 0, self.send_idx, out=packed)
+        if part.comm is not None:
+            part.comm.received(self.n_halo * (table[0].numel() if table.shape[0] else 0) * table.element_size())
         work = part.all_to_all_v(table[self.n_local:], packed, self.recv_splits, self.send_splits,
                                  async_op=True)
-        return GatheredTable(table, work, keep=packed)
+        return GatheredTable(table, work, keep=packed, comm=part.comm)
 
 
 class GatheredTable:
     """Handle of an (possibly in-flight) all-gathered table."""
 
-    def __init__(self, table, work, keep=None):
-        self.table, self.work, self.keep = table, work, keep
+    def __init__(self, table, work, keep=None, comm: "CommStats | None" = None):
+        self.table, self.work, self.keep, self.comm = table, work, keep, comm
 
     def wait(self) -> torch.Tensor:
         if self.work is not None:
+            ev = self.comm.bracket(self.table.device) if self.comm is not None else None
+            if ev is not None:
+                ev[0].record()
             self.work.wait()          # the current stream waits for the collective
+            if ev is not None:
+                ev[1].record()
             self.work, self.keep = None, None
         return self.table
 

@@ -128,3 +128,55 @@ def test_cpu_baseline_leg_runs_on_one_sample(monkeypatch):
     assert c["all_cores"]["sample_n"] == c["one_thread"]["sample_n"] == 512
     assert c["cores"] == 2 and c["one_thread"]["threads"] == 1 and c["cores_effective"] > 0
     assert c["kind"] == "port" and c["value"] > 0
+
+
+def test_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus N` (no torchrun, no RANK in the environment) must start N ranks by
+    itself -- the parent passes its arguments through unchanged, relays the children's exit code, and is a no-op when
+    it IS a rank or N = 1."""
+    argv = ["--gpus", "4", "--steps", "3", "--warmup", "1", "--nodes", "200000"]
+    calls = []
+
+    def fake_run(cmd, env=None, cwd=None):
+        calls.append((cmd, env, cwd))
+        return 7
+
+    assert bench.launch_ranks_if_needed(argv, environ={"PATH": "/usr/bin"}, run=fake_run) == 7      # exit code relayed
+    (cmd, env, cwd), = calls
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-len(argv) - 1] == os.path.join(ROOT, "bench.py") and cmd[-len(argv):] == argv       # pass-through
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and cwd == ROOT
+    # already a rank (torchrun set RANK), or one GPU: nothing to launch
+    assert bench.launch_ranks_if_needed(argv, environ={"RANK": "0", "WORLD_SIZE": "4"}, run=fake_run) is None
+    assert bench.launch_ranks_if_needed(["--steps", "2"], environ={}, run=fake_run) is None
+    assert bench.launch_ranks_if_needed(["--gpus=1"], environ={}, run=fake_run) is None
+    assert bench._gpus_from_argv(["--gpus=8", "--steps", "1"]) == 8
+    assert len(calls) == 1
+
+
+def test_launcher_relays_a_failing_child():
+    """The real launcher path, end to end without a GPU: a child that dies (here: --gpus 2 with an invalid workload
+    makes every rank exit non-zero before it touches a device) must make the parent exit non-zero."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "no-such-workload",
+                        "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]      # no JSON line from a failed job
+
+
+MULTI_RANK_KEYS = {"rccl_ranks", "backend", "exchange_bytes_received", "comm_wait_ms", "grad_allreduce_bytes"}
+
+
+def test_multi_rank_lines_carry_the_exchange_keys():
+    """Every committed N > 1 line of round 4 says how many ranks really ran, over what backend, how many bytes each
+    received per step and how long the compute stream waited for them."""
+    seen = 0
+    for name, d in _lines("r04"):
+        if d["n_gpus"] > 1:
+            seen += 1
+            assert MULTI_RANK_KEYS <= set(d), (name, MULTI_RANK_KEYS - set(d))
+            assert d["rccl_ranks"] == d["n_gpus"] and d["exchange_bytes_received"] > 0 and d["comm_wait_ms"] >= 0
+    assert seen >= 1

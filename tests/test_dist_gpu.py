@@ -145,3 +145,24 @@ def test_wide_heads_two_ranks_real_kernels(dev, tmp_path, graph):
     assert np.isfinite(a["flat"]).all()
     assert np.abs(a["flat"] - b["flat"]).max() < 2e-5
     assert np.abs(a["hist"] - b["hist"]).max() < 2e-5
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself(dev):
+    """`python bench.py --gpus 2 ...` with no torchrun in the command and no RANK in the
+    environment starts its two ranks itself (here both on the one GPU, collectives staged through the host)
+    and rank 0's line says how many ranks ran and what they exchanged."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HAN_DIST_BACKEND="gloo", HAN_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nodes", "200000",
+                        "--steps", "3", "--warmup", "1"], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo"
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["exchange_bytes_received"] > 0 and d["comm_wait_ms"] >= 0 and d["grad_allreduce_bytes"] > 0
+    assert "node-partition x2" in d["config"]["parallelism"]
+    assert np.isfinite(d["final"]["train_loss"])
