@@ -611,6 +611,7 @@ def main():
                                   table_dtype=tdt)
     if tdt == torch.bfloat16:
         wl["x"] = wl["x"].to(torch.bfloat16)
+    e_per_path = [int(g.nnz) for g in wl["graphs"]]          # (this rank's rows; quoted only when they differ)
     e_local = torch.tensor([float(sum(g.nnz for g in wl["graphs"]))], dtype=torch.float64)
     if part is not None:
         e_local = e_local.to(dev) if dist.get_backend() == "nccl" else e_local
@@ -773,15 +774,16 @@ def main():
             "dtype": "f32" if args.table_dtype == "f32" else "bf16 storage / f32 accumulate",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: N={n} nodes, P={p} meta-paths, "
-                                   f"E={e_global} "
+                                   f"E={e_global} " + (f"{e_per_path} " if len(set(e_per_path)) > 1 and world == 1 else "") +
                                    f"edges, F={wl['f']}, K=8 heads x F'=8, A=128, C={wl['c']}",
                        "graph_recipe": ("per row the self-loop + (deg-1) uniform neighbours drawn with a torch "
                                         "generator on the device, duplicates kept (multigraph terms), columns sorted "
                                         "per row -- deviates from SURVEY.md 8d's distinct-neighbour / "
                                         "numpy default_rng(1234+p) recipe; byte counts are identical")
                        if args.workload.startswith("syn-") else
-                       "han_amd.synth: symmetric Bernoulli(density) adjacency + I per meta-path at the data set's edge "
-                       "counts (dense generation, ids ascending per row)",
+                       "han_amd.synth: per meta-path a symmetric random graph + I with EXACTLY the data set's entry count "
+                       "(SURVEY.md section 8; (nnz - N)/2 distinct pairs i < j drawn without replacement, mirrored; "
+                       "ids ascending per row)",
                        "parallelism": f"node-partition x{world}" if world > 1 else
                        ("single GPU, epoch replayed from a hipGraph" if use_graph else "single GPU"),
                        **({"captured_epoch": {"c_abi_calls": getattr(trainer, "graph_abi_calls", None),

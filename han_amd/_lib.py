@@ -25,7 +25,8 @@ class HanRowSplit(ctypes.Structure):
     _fields_ = [("split_deg", c_int64), ("n_long", c_int64), ("n_chunks", c_int64),
                 ("long_rows", c_void_p), ("long_ptr", c_void_p), ("chunk_long", c_void_p),
                 ("chunk_start", c_void_p), ("chunk_end", c_void_p), ("workspace", c_void_p),
-                ("workspace_bytes", c_size_t)]
+                ("workspace_bytes", c_size_t), ("n_short", c_int64), ("n_mid", c_int64),
+                ("short_rows", c_void_p), ("mid_rows", c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/han_hip.h one to one
@@ -33,6 +34,7 @@ SIGNATURES = {
     "han_abi_version": (c_int, []),
     "han_error_string": (c_char_p, [c_int]),
     "han_project_fwd_workspace": (c_size_t, [I64, c_int, c_int, c_int]),
+    "han_project_fwd_multi_workspace": (c_size_t, [I64, c_int, c_int, c_int, c_int]),
     "han_project_keep_bytes": (c_size_t, [I64, c_int, I64, c_int, c_int]),
     "han_project_fwd": (c_int, [P, c_int, I64, P, P, P, P, P, P, c_int, P, P, P, c_size_t, I64, c_int, c_int, c_int,
                                 c_float, c_float, c_uint64, P, I64, P, c_int, P]),
@@ -70,7 +72,7 @@ SIGNATURES = {
     "han_bias_fill_csr": (c_int, [P, I64, I64, P, P, P]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

@@ -458,7 +458,8 @@ __global__ __launch_bounds__(256) void cls_gen_kernel(const ClsGenArgs a) {
         float mx = HAN_NEG_BIG, se = 0.f, llab = 0.f;
         int am = 0;
         const int lab = a.labels[row];
-        const float wgt = a.mask[row] ? a.row_weight : 0.f;
+        const bool live = a.mask[row] != 0;      // the predicate cls_dw_kernel skips rows by: a live row ALWAYS gets its dL row
+        const float wgt = live ? a.row_weight : 0.f;
         for (int c = 0; c < C; ++c) {
             const float *wr = a.WmT + (int64_t)c * D + lane;
             float part = 0.f;
@@ -487,7 +488,8 @@ __global__ __launch_bounds__(256) void cls_gen_kernel(const ClsGenArgs a) {
             float dz[NR];
 #pragma unroll
             for (int v = 0; v < NR; ++v) dz[v] = 0.f;
-            if (wgt != 0.f) {        // wave-uniform: rows outside the mask have dl == 0 exactly
+            if (live) {              // wave-uniform: rows outside the mask have dl == 0 exactly (a live row with
+                                     // row_weight == 0 writes zeros: cls_dw_kernel reads the dL row of every live row)
                 const float inv = 1.f / se;
                 if (NV == 0)
                     for (int v = 0; v < nv; ++v) a.dZ[row * D + 64 * v + lane] = 0.f;
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(256) void cls_gen_kernel(const ClsGenArgs a) {
                     }
                 }
             }
-            if (NV > 0 || wgt == 0.f) {
+            if (NV > 0 || !live) {
                 if (NV > 0) {
 #pragma unroll
                     for (int v = 0; v < NR; ++v)

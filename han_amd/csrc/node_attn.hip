@@ -78,6 +78,10 @@ struct FwdArgs {
     int64_t out_stride;
     float *pre, *lse, *aggp, *tsum;
     int64_t N;
+    // degree-binned launches (han_row_split_t: short_rows / mid_rows): this launch covers the n_work rows listed in
+    // `rows` (null: the rows 0 .. n_work-1 themselves)
+    const int32_t *rows;
+    int64_t n_work;
     float slope;
     uint32_t seed_lo, seed_hi, thr_coef;
     const uint64_t *seed_dev;
@@ -290,12 +294,13 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) 
     const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
     const float b2h = a.b2[head];
     const bool drop_c = TRAIN && a.thr_coef < HAN_KEEP_ALL;
-    const int64_t nunits = (a.N + RPW - 1) / RPW;   // wave-sized work units
+    const int64_t nunits = (a.n_work + RPW - 1) / RPW;   // wave-sized work units
 
     for (int64_t unit = wave0; unit < nunits; unit += nwaves) {
-        const int64_t row_raw = (RPW == 1) ? unit : unit * 4 + g;
-        const bool row_ok = row_raw < a.N;
-        const int64_t row = row_ok ? row_raw : a.N - 1;
+        const int64_t idx_raw = (RPW == 1) ? unit : unit * 4 + g;
+        const bool row_ok = idx_raw < a.n_work;
+        const int64_t widx = row_ok ? idx_raw : a.n_work - 1;
+        const int64_t row = a.rows ? (int64_t)a.rows[widx] : widx;
         const int64_t s = a.rowptr[row];
         const int64_t e_raw = row_ok ? a.rowptr[row + 1] : s;
         const bool is_long = e_raw - s > a.split_deg;      // handled by the chunk kernels
@@ -368,7 +373,9 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) 
             st.merge(16);
             st.merge(32);
         } else {
-            // each 16-lane group walks its own row; the wave loops to the longest
+            // each 16-lane group walks its own row; the wave loops to the longest.  The ids of up to 16 entries of a
+            // row are ONE coalesced load of its group (lane q: entry base + q) handed out by shuffle, so a short row
+            // (the degree-binned launch sends rows below 16 entries here) has a single index load in front of its gathers
             const int64_t len = e - s;
             int64_t maxlen = len;
             {
@@ -377,17 +384,24 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) 
                 o = __shfl_xor(maxlen, 32, 64);
                 maxlen = o > maxlen ? o : maxlen;
             }
-            for (int64_t it = 0; it < maxlen; it += U) {
-                int j[U];
-                float w[U];
-                bool valid[U];
+            for (int64_t base = 0; base < maxlen; base += 16) {
+                const int64_t left = len - base;                      // entries of THIS group's row from base on (may be <= 0)
+                const int64_t at = s + base + (q < left ? q : (left > 0 ? left - 1 : 0));
+                const int mycol = (left > 0) ? a.colidx[at] : 0;
+                const float myval = (VAL && left > 0) ? a.edge_val[at] : 1.f;
+                const int steps = (int)((maxlen - base) < 16 ? (maxlen - base) : 16);
+                for (int it = 0; it < steps; it += U) {
+                    int j[U];
+                    float w[U];
+                    bool valid[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    valid[u] = it + u < len;
-                    j[u] = (len > 0) ? a.colidx[valid[u] ? s + it + u : s] : 0;
-                    w[u] = (VAL && len > 0) ? a.edge_val[valid[u] ? s + it + u : s] : 1.f;
+                    for (int u = 0; u < U; ++u) {
+                        valid[u] = it + u < left;
+                        j[u] = __shfl(mycol, (lane & 48) + ((it + u) & 15), 64);
+                        w[u] = VAL ? __shfl(myval, (lane & 48) + ((it + u) & 15), 64) : 1.f;
+                    }
+                    consume_edges<FP, TRAIN, U, BF, VAL, FAST, false>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
                 }
-                consume_edges<FP, TRAIN, U, BF, VAL, FAST, false>(a, j, w, valid, f1h, gi, q, head, a24, b2h, drop_c, st);
             }
         }
 
@@ -933,6 +947,8 @@ struct BwdColsArgs {
     int lsb_mask;
     float *dH, *df2;
     int64_t NS;
+    const int32_t *rows;     // degree-binned launches: the n_work source rows of this launch (null: 0 .. n_work-1)
+    int64_t n_work;
     float slope;
     uint32_t seed_lo, seed_hi, thr_coef;
     const uint64_t *seed_dev;
@@ -1067,12 +1083,13 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
     const bool drop_c = a.thr_coef < HAN_KEEP_ALL;
     const float4_t a14 = *reinterpret_cast<const float4_t *>(a.a1 + 4 * q);
     const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
-    const int64_t nunits = (a.NS + RPW - 1) / RPW;
+    const int64_t nunits = (a.n_work + RPW - 1) / RPW;
 
     for (int64_t unit = wave0; unit < nunits; unit += nwaves) {
-        const int64_t src_raw = (RPW == 1) ? unit : unit * 4 + g;
-        const bool src_ok = src_raw < a.NS;
-        const int64_t src = src_ok ? src_raw : a.NS - 1;
+        const int64_t idx_raw = (RPW == 1) ? unit : unit * 4 + g;
+        const bool src_ok = idx_raw < a.n_work;
+        const int64_t widx = src_ok ? idx_raw : a.n_work - 1;
+        const int64_t src = a.rows ? (int64_t)a.rows[widx] : widx;
         const int64_t s = a.colptr[src];
         const int64_t e_raw = src_ok ? a.colptr[src + 1] : s;
         const bool is_long = e_raw - s > a.split_deg;
@@ -1091,7 +1108,6 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
             o = __shfl_xor(trips, 32, 64);
             trips = o > trips ? o : trips;
         }
-        int64_t it = 0;
         if (RPW == 1) {
             // as in the forward: the destination ids of 64 transposed edges are loaded coalesced
             // and handed out by shuffle, so no step (least of all a tail step) waits on an index load
@@ -1136,19 +1152,29 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
                 }
             }
         }
-        for (; RPW != 1 && it < trips; it += U) {
-            int i[U];
-            float ew[U];
-            bool valid[U];
+        if (RPW != 1) {
+            // one 16-lane group per source row: up to 16 destination ids per group in ONE coalesced load, handed
+            // out by shuffle (as the forward)
+            for (int64_t base = 0; base < trips; base += 16) {
+                const int64_t left = len - base;
+                const int64_t at = s + base + (q < left ? q : (left > 0 ? left - 1 : 0));
+                const int myrow = (left > 0) ? a.rowidx[at] : 0;
+                const float myval = (VAL && left > 0) ? a.edge_val[at] : 1.f;
+                const int steps = (int)((trips - base) < 16 ? (trips - base) : 16);
+                for (int st = 0; st < steps; st += U) {
+                    int i[U];
+                    float ew[U];
+                    bool valid[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t k = it + u;
-                valid[u] = k < len;
-                i[u] = len > 0 ? a.rowidx[valid[u] ? s + k : s] : 0;
-                if (MASKED) valid[u] = valid[u] && i[u] >= 0;
-                ew[u] = (VAL && len > 0) ? a.edge_val[valid[u] ? s + k : s] : 1.f;
+                    for (int u = 0; u < U; ++u) {
+                        valid[u] = st + u < left;
+                        i[u] = __shfl(myrow, (lane & 48) + ((st + u) & 15), 64);
+                        if (MASKED) valid[u] = valid[u] && i[u] >= 0;
+                        ew[u] = VAL ? __shfl(myval, (lane & 48) + ((st + u) & 15), 64) : 1.f;
+                    }
+                    bwd_consume<FP, U, BF, VAL, FAST, false, MASKED>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
+                }
             }
-            bwd_consume<FP, U, BF, VAL, FAST, false, MASKED>(a, i, ew, valid, sr, q, head, drop_c, acc, dfacc);
         }
         if (RPW == 1) {
 #pragma unroll
@@ -1513,8 +1539,13 @@ int attn_grid(int64_t units) { return han_grid_for(units, 4, 256 * 8 * 4); }
 // mean degree (E / N) below which a 16-lane group per row beats a wave per row
 constexpr double kLowDegree = 12.0;
 
-bool split_ok(const han_row_split_t *sp) {
-    if (!sp || sp->n_long == 0) return true;
+bool split_ok(const han_row_split_t *sp, int64_t n_rows) {
+    if (!sp) return true;
+    // bins: a listed bin needs its list unless it is every row of the launch (identity)
+    if (sp->n_short < 0 || sp->n_mid < 0 || sp->n_short + sp->n_mid > n_rows) return false;
+    if (sp->n_short > 0 && !sp->short_rows && sp->n_short != n_rows) return false;
+    if (sp->n_mid > 0 && !sp->mid_rows && sp->n_mid != n_rows) return false;
+    if (sp->n_long == 0) return true;
     return sp->n_long > 0 && sp->n_chunks >= sp->n_long && sp->split_deg > 0 && sp->long_rows && sp->long_ptr &&
            sp->chunk_long && sp->chunk_start && sp->chunk_end && sp->workspace &&
            sp->workspace_bytes >= (size_t)sp->n_chunks * kFwdChunkStride * sizeof(float);
@@ -1534,17 +1565,19 @@ bool split_ok(const han_row_split_t *sp) {
 // bf16 tables: every head shape (the configs[4] shape 8 x 8 is the tuned one)
 #define HAN_BF16_OK(FPV) (true)
 
+// One launch over the rows `a.rows[0 .. a.n_work)` (or 0 .. n_work-1): a 16-lane group per row (short) or a wave per row.
 template <int FPC, bool BF, bool VAL>
-static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split, hipStream_t st) {
+static void launch_fwd_rows(const FwdArgs &a, bool train, bool short_rows, hipStream_t st) {
     // FAST: the training configuration every shipped script uses (both dropouts on, table
     // index == global id) gets an edge loop without uniform branches
     const bool fast = train && a.thr_coef < HAN_KEEP_ALL && a.lsb_mask && !a.gid && !a.f2g;
-    if (low) {
-        const int grid = attn_grid((a.N + 3) / 4);
-        if (train) node_attn_fwd_kernel<FPC, true, 4, 2, BF, VAL, false, false><<<grid, 256, 0, st>>>(a);
-        else node_attn_fwd_kernel<FPC, false, 4, 2, BF, VAL, false, false><<<grid, 256, 0, st>>>(a);
+    if (short_rows) {
+        const int grid = attn_grid((a.n_work + 3) / 4);
+        if (train && fast) node_attn_fwd_kernel<FPC, true, 4, 4, BF, VAL, true, false><<<grid, 256, 0, st>>>(a);
+        else if (train) node_attn_fwd_kernel<FPC, true, 4, 4, BF, VAL, false, false><<<grid, 256, 0, st>>>(a);
+        else node_attn_fwd_kernel<FPC, false, 4, 4, BF, VAL, false, false><<<grid, 256, 0, st>>>(a);
     } else {
-        const int grid = attn_grid(a.N);
+        const int grid = attn_grid(a.n_work);
         // bf16 rows are 128 B: the eval forward (and the backward gather) keep 8 steps in flight
         // to cover the HBM latency (measured -6..-12 %); the training forward is VALU-bound
         // (RNG + masks per edge) and gets slower with the longer unroll
@@ -1552,6 +1585,42 @@ static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split,
         if (train && fast) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, true, true><<<grid, 256, 0, st>>>(a);
         else if (train) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, false, true><<<grid, 256, 0, st>>>(a);
         else node_attn_fwd_kernel<FPC, false, 1, UE, BF, VAL, false, BF><<<grid, 256, 0, st>>>(a);
+    }
+}
+
+// Degree bins of a launch (han_row_split_t): rows below HAN_SHORT_DEG entries, rows up to split_deg, rows beyond.
+struct RowBins {
+    bool binned;
+    int64_t n_short, n_mid;
+    const int32_t *short_rows, *mid_rows;
+};
+
+static RowBins bins_of(const han_row_split_t *sp) {
+    RowBins b = {false, 0, 0, nullptr, nullptr};
+    if (sp && (sp->n_short > 0 || sp->n_mid > 0)) {
+        b.binned = true;
+        b.n_short = sp->n_short; b.n_mid = sp->n_mid;
+        b.short_rows = sp->short_rows; b.mid_rows = sp->mid_rows;
+    }
+    return b;
+}
+
+template <int FPC, bool BF, bool VAL>
+static void launch_fwd_v(const FwdArgs &a_in, bool train, bool low, bool has_split, const RowBins &bins, hipStream_t st) {
+    FwdArgs a = a_in;
+    if (bins.binned) {
+        // degree-binned: rows below 16 entries four to a wave, the others a wave each (rows beyond split_deg: chunks)
+        if (bins.n_short > 0) {
+            a.rows = bins.short_rows; a.n_work = bins.n_short;
+            launch_fwd_rows<FPC, BF, VAL>(a, train, true, st);
+        }
+        if (bins.n_mid > 0) {
+            a.rows = bins.mid_rows; a.n_work = bins.n_mid;
+            launch_fwd_rows<FPC, BF, VAL>(a, train, false, st);
+        }
+    } else {
+        a.rows = nullptr; a.n_work = a.N;
+        launch_fwd_rows<FPC, BF, VAL>(a, train, low, st);
     }
     if (has_split) {
         const int cgrid = attn_grid(a.n_chunks);
@@ -1567,18 +1636,38 @@ static void launch_fwd_v(const FwdArgs &a, bool train, bool low, bool has_split,
 }
 
 template <int FPC, bool BF, bool VAL>
-static void launch_bwd_cols_v(const BwdColsArgs &a, bool low, bool has_split, hipStream_t st) {
+static void launch_bwd_rows(const BwdColsArgs &a, bool short_rows, hipStream_t st) {
     const bool fast = a.thr_coef < HAN_KEEP_ALL && !a.gid;
+    if (a.masked) {      // opt-in masked backward: the general instantiations, dead entries skipped in place
+        if (short_rows) node_attn_bwd_cols_kernel<FPC, 4, 4, BF, VAL, false, true><<<attn_grid((a.n_work + 3) / 4), 256, 0, st>>>(a);
+        else node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL, false, true><<<attn_grid(a.n_work), 256, 0, st>>>(a);
+    } else if (short_rows) {
+        if (fast) node_attn_bwd_cols_kernel<FPC, 4, 4, BF, VAL, true><<<attn_grid((a.n_work + 3) / 4), 256, 0, st>>>(a);
+        else node_attn_bwd_cols_kernel<FPC, 4, 4, BF, VAL, false><<<attn_grid((a.n_work + 3) / 4), 256, 0, st>>>(a);
+    } else if (fast) node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL, true><<<attn_grid(a.n_work), 256, 0, st>>>(a);
+    else node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL, false><<<attn_grid(a.n_work), 256, 0, st>>>(a);
+}
+
+template <int FPC, bool BF, bool VAL>
+static void launch_bwd_cols_v(const BwdColsArgs &a_in, bool low, bool has_split, const RowBins &bins, hipStream_t st) {
+    BwdColsArgs a = a_in;
+    a.rows = nullptr; a.n_work = a.NS;
     if (a.lean && !a.masked && !low && !BF && FPC == 8 && !a.gid) {      // small graphs, 8 x 8: one lane per head
         node_attn_bwd_cols_h8_kernel<VAL><<<attn_grid(a.NS), 256, 0, st>>>(a);
     } else if (a.lean && !a.masked && !low && !BF) {      // small graphs (HAN_FLAG_LEAN): VALU-bound, one hash per (edge, four heads)
         node_attn_bwd_cols_kernel<FPC, 1, 4, false, VAL, false, false, true><<<attn_grid(a.NS), 256, 0, st>>>(a);
-    } else if (a.masked) {      // opt-in masked backward: the general instantiations, dead entries skipped in place
-        if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF, VAL, false, true><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
-        else node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL, false, true><<<attn_grid(a.NS), 256, 0, st>>>(a);
-    } else if (low) node_attn_bwd_cols_kernel<FPC, 4, 2, BF, VAL, false><<<attn_grid((a.NS + 3) / 4), 256, 0, st>>>(a);
-    else if (fast) node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL, true><<<attn_grid(a.NS), 256, 0, st>>>(a);
-    else node_attn_bwd_cols_kernel<FPC, 1, 4, BF, VAL, false><<<attn_grid(a.NS), 256, 0, st>>>(a);
+    } else if (bins.binned) {
+        if (bins.n_short > 0) {
+            a.rows = bins.short_rows; a.n_work = bins.n_short;
+            launch_bwd_rows<FPC, BF, VAL>(a, true, st);
+        }
+        if (bins.n_mid > 0) {
+            a.rows = bins.mid_rows; a.n_work = bins.n_mid;
+            launch_bwd_rows<FPC, BF, VAL>(a, false, st);
+        }
+    } else {
+        launch_bwd_rows<FPC, BF, VAL>(a, low, st);
+    }
     if (has_split) {
         node_attn_bwd_chunk_kernel<FPC, 4, BF, VAL><<<attn_grid(a.n_chunks), 256, 0, st>>>(a);
         node_attn_bwd_finish_kernel<FPC, BF><<<(int)((a.n_long + 15) / 16), 256, 0, st>>>(a);
@@ -1597,14 +1686,14 @@ static void launch_fwd_lean_v(const FwdArgs &a, bool train, hipStream_t st) {
 
 // the binary-adjacency instantiation (every shipped config) carries no edge-value registers
 template <int FPC, bool BF>
-static void launch_fwd(const FwdArgs &a, bool train, bool low, bool has_split, hipStream_t st) {
-    if (a.edge_val) launch_fwd_v<FPC, BF, true>(a, train, low, has_split, st);
-    else launch_fwd_v<FPC, BF, false>(a, train, low, has_split, st);
+static void launch_fwd(const FwdArgs &a, bool train, bool low, bool has_split, const RowBins &bins, hipStream_t st) {
+    if (a.edge_val) launch_fwd_v<FPC, BF, true>(a, train, low, has_split, bins, st);
+    else launch_fwd_v<FPC, BF, false>(a, train, low, has_split, bins, st);
 }
 template <int FPC, bool BF>
-static void launch_bwd_cols(const BwdColsArgs &a, bool low, bool has_split, hipStream_t st) {
-    if (a.edge_val) launch_bwd_cols_v<FPC, BF, true>(a, low, has_split, st);
-    else launch_bwd_cols_v<FPC, BF, false>(a, low, has_split, st);
+static void launch_bwd_cols(const BwdColsArgs &a, bool low, bool has_split, const RowBins &bins, hipStream_t st) {
+    if (a.edge_val) launch_bwd_cols_v<FPC, BF, true>(a, low, has_split, bins, st);
+    else launch_bwd_cols_v<FPC, BF, false>(a, low, has_split, bins, st);
 }
 
 static bool dtype_ok(int dt, int FP) {
@@ -1624,7 +1713,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     if (N == 0) return 0;   // nothing to do; row pointers of empty tensors may be null
     if (!rowptr || (!colidx && E > 0) || !H || !f1 || !a2 || !b2 || !c || !out || N < 0 || E < 0 || out_stride < HAN_D)
         return HAN_E_BADARG;
-    if (!split_ok(split)) return HAN_E_BADARG;
+    if (!split_ok(split, N)) return HAN_E_BADARG;
     if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
     if ((flags & HAN_FLAG_LEAN) && !f2_src) return HAN_E_BADARG;      // the lean kernels read the scores from the table
     const bool train = pre || lse || aggp || tsum;
@@ -1635,7 +1724,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     FwdArgs a;
     a.rowptr = rowptr; a.colidx = colidx; a.edge_val = edge_val; a.H = H; a.gid = table_gid; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.f2g = f2_src; a.a2 = a2; a.b2 = b2; a.c = c; a.res = res;
     a.out = out; a.out_stride = out_stride; a.pre = pre; a.lse = lse; a.aggp = aggp; a.tsum = tsum;
-    a.N = N; a.slope = slope;
+    a.N = N; a.rows = nullptr; a.n_work = N; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
@@ -1660,10 +1749,11 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
         HAN_CHECK_LAUNCH();
         return 0;
     }
+    const RowBins bins = bins_of(split);
     if (table_dtype == HAN_DTYPE_BF16) {
-        HAN_DISPATCH_FP(FP, { launch_fwd<FPC, true>(a, train, low, has_split, st); })
+        HAN_DISPATCH_FP(FP, { launch_fwd<FPC, true>(a, train, low, has_split, bins, st); })
     } else {
-        HAN_DISPATCH_FP(FP, { launch_fwd<FPC, false>(a, train, low, has_split, st); })
+        HAN_DISPATCH_FP(FP, { launch_fwd<FPC, false>(a, train, low, has_split, bins, st); })
     }
     HAN_CHECK_LAUNCH();
     return 0;
@@ -1722,13 +1812,13 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
                                       const han_row_split_t *split, void *stream) {
     if (!colptr || (!rowidx && E > 0) || !gs || !H || !f2 || !df1 || !a1 || !a2 || !dH || !df2 || NS < 0 || E < 0)
         return HAN_E_BADARG;
-    if (!split_ok(split)) return HAN_E_BADARG;
+    if (!split_ok(split, NS)) return HAN_E_BADARG;
     if (!fp_supported(K, FP) || !dtype_ok(table_dtype, FP)) return HAN_E_UNSUPPORTED;
     if (coef_drop < 0.f || coef_drop >= 1.f || fts_drop < 0.f || fts_drop >= 1.f) return HAN_E_BADARG;
     if (NS == 0) return 0;
     BwdColsArgs a;
     a.colptr = colptr; a.rowidx = rowidx; a.edge_val = edge_val; a.gs = gs; a.gid = table_gid; a.H = H; a.lsb_mask = fts_drop > 0.f; a.f2 = f2;
-    a.df1 = df1; a.a1 = a1; a.a2 = a2; a.dH = dH; a.df2 = df2; a.NS = NS; a.slope = slope;
+    a.df1 = df1; a.a1 = a1; a.a2 = a2; a.dH = dH; a.df2 = df2; a.NS = NS; a.rows = nullptr; a.n_work = NS; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
@@ -1748,10 +1838,11 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
     a.split_ws = has_split ? (float *)split->workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool low = (double)E < kLowDegree * (double)NS;
+    const RowBins bins = bins_of(split);
     if (table_dtype == HAN_DTYPE_BF16) {
-        HAN_DISPATCH_FP(FP, { launch_bwd_cols<FPC, true>(a, low, has_split, st); })
+        HAN_DISPATCH_FP(FP, { launch_bwd_cols<FPC, true>(a, low, has_split, bins, st); })
     } else {
-        HAN_DISPATCH_FP(FP, { launch_bwd_cols<FPC, false>(a, low, has_split, st); })
+        HAN_DISPATCH_FP(FP, { launch_bwd_cols<FPC, false>(a, low, has_split, bins, st); })
     }
     HAN_CHECK_LAUNCH();
     return 0;

@@ -24,6 +24,7 @@ constexpr int XS_LD = 34;   // LDS leading dims chosen conflict-free for the MFM
 constexpr int WS_LD = 80;
 
 struct ProjFwdArgs {
+    const unsigned char *wimg;   // bf16 x 6 kernels: the pre-split, LDS-ready image of W (project_wimage_kernel), in the workspace
     const void *X;      // fp32 or bf16 (x_bf16), row stride ldx ELEMENTS
     int64_t ldx;
     const float *W;
@@ -346,11 +347,23 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int B6_ROWS = 128;             // rows per block
-constexpr int B6_LDB = 96;               // bytes per LDS row: 32 bf16 + 32 B pad (24 dwords: the 16-lane groups of a
-                                         // ds_read_b128 then start on 16 distinct multiples of 4 dwords -- conflict-free;
-                                         // 80-B rows measured 45 % conflict cycles)
+constexpr int B6_LDB = 64;               // bytes per LDS row: 32 bf16, NO padding, 16-byte slots XOR-swizzled (b6_swz)
 constexpr int B6_XBYTES = B6_ROWS * B6_LDB;
 constexpr int B6_WBYTES = HAN_D * B6_LDB;
+constexpr int B6_WTILE = 3 * B6_WBYTES;  // bytes of one K-step of the pre-split W image (3 terms x 64 columns x 64 B)
+
+// LDS layout of the X / W tiles (round 4; round 3 used 96-B padded rows, conflict-free for the fragment READS but
+// 4-way conflicting on the W staging stores and 2-way on the X stores -- ds_write banks are (a/4) % 32 --, and the
+// keep-word collection was 16-way: profiles/r03_pmc_k1.json, 43 % of the LDS cycles were conflict cycles).
+// A row is 64 B = four 16-byte slots; slot sl of row r sits at slot sl ^ b6_swz(r).  ds_read_b128 is served in the
+// lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, {32-35,44-47,52-59}, {36-43,48-51,60-63} (MI355X_MICROARCH.md,
+// LDS) over 64 banks = four rows: a fragment read (lane: row l15, slot l4) conflicts only among rows equal mod 4,
+// and within a group those rows carry l4 in {0,1,1,0} / {1,0,0,1} / {2,3,3,2} / {3,2,2,3} for (r >> 2) = 0..3 -- the
+// table 0,2,3,1 makes the four slots distinct in every group.  The X staging store (8 B per lane, 16 contiguous
+// lanes = two whole rows) then covers 128 contiguous bytes: conflict-free too.
+__device__ __forceinline__ int b6_swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+// byte offset of 16-byte slot `sl` of row `row` inside a tile
+__device__ __forceinline__ int b6_off(int row, int sl) { return row * B6_LDB + ((sl ^ b6_swz(row)) << 4); }
 
 // x == h + m + l exactly; each term has <= 8 significand bits (its low 16 bits are zero)
 __device__ __forceinline__ void b6_split(float x, uint32_t &h, uint32_t &m, uint32_t &l) {
@@ -379,6 +392,31 @@ __device__ __forceinline__ uint32_t b6_keep_masks(uint32_t w, uint32_t thr2, uin
     return s;
 }
 
+// W (P x F x 64 fp32) -> the LDS-ready image the bf16 x 6 kernels copy per K-step: [K-step kt][meta-path P][term 3][column 64][64 B],
+// the 32 k-values of a column as bf16 in four 16-byte slots, swizzled as in LDS (b6_off); k >= F is zero.  Every block
+// of the forward used to split the same W tiles again (7813 blocks x 8 K-steps at SYN-1M) and store them transposed
+// with 4-way bank conflicts; now a block copies 8-byte pieces straight through (16 contiguous lanes = 128 contiguous
+// bytes: conflict-free).  One thread per (K-step, column, 4 consecutive k).
+__global__ __launch_bounds__(256) void project_wimage_kernel(const float *W, unsigned char *img, int F, int ktiles, int P) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per_p = (int64_t)ktiles * 64 * 8;
+    if (t >= per_p * P) return;
+    const int p = (int)(t / per_p);
+    const int r = (int)(t % per_p);
+    const int kt = r / 512, col = r & 63, kq = (r >> 6) & 7;      // 64 consecutive threads: 64 consecutive columns of one k row
+    const float *Wp = W + (int64_t)p * F * HAN_D;
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = kt * 32 + kq * 4 + j;
+        b6_split(k < F ? Wp[(int64_t)k * HAN_D + col] : 0.f, h[j], m[j], l[j]);
+    }
+    unsigned char *dst = img + ((int64_t)kt * P + p) * B6_WTILE + b6_off(col, kq >> 1) + (kq & 1) * 8;
+    *reinterpret_cast<uint2 *>(dst) = make_uint2(b6_pack(h[0], h[1]), b6_pack(h[2], h[3]));
+    *reinterpret_cast<uint2 *>(dst + B6_WBYTES) = make_uint2(b6_pack(m[0], m[1]), b6_pack(m[2], m[3]));
+    *reinterpret_cast<uint2 *>(dst + 2 * B6_WBYTES) = make_uint2(b6_pack(l[0], l[1]), b6_pack(l[2], l[3]));
+}
+
 // NW = waves per block (the block always owns 128 rows): 8 waves of one 16-row tile each keep the kernel
 // within 128 registers, i.e. FOUR waves per SIMD -- measured round 3: the 4-wave form (248 registers, two
 // waves per SIMD) spends 55 % of its wave cycles waiting (profiles/r02_pmc_k1_b6.json: each wave alone
@@ -393,10 +431,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
     constexpr int MT = 8 / NW;            // 16-row tiles per wave
     constexpr int NT = 64 * NW;           // threads
     constexpr int XV = 1024 / NT;         // float4 loads of X per thread per tile (128 rows x 32 k)
-    constexpr int WV = 2048 / NT;         // W elements per thread per tile (32 k x 64 columns): WV consecutive k of one column
+    constexpr int WU = (B6_WTILE / 8) / NT;   // 8-byte pieces of the W image per thread per K-step
     __shared__ __attribute__((aligned(16))) unsigned char lds[NX * B6_XBYTES + 3 * B6_WBYTES + (KEEP ? B6_ROWS * 128 : 0)];
-    unsigned char *Xs = lds;                          // [NX][128][96 B]
-    unsigned char *Ws = lds + NX * B6_XBYTES;         // [3][64][96 B]   (transposed: [col][k])
+    unsigned char *Xs = lds;                          // [NX][128][64 B, slots swizzled]
+    unsigned char *Ws = lds + NX * B6_XBYTES;         // [3][64][64 B]   (transposed: [col][k]; a copy of the image's K-step)
     // KEEP: the keep words of four K-steps (128 features = one 128-B line per row) are collected here and leave
     // as whole lines; 8-byte stores per lane and K-step (32-B pieces, queued in front of the next tile's loads)
     // cost the training forward 0.12 ms
@@ -412,7 +450,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
             const int r = c >> 3, sg = c & 7;
             const int64_t krow = row0 + r;
             if (krow < a.N && kbase + 16 * sg < a.F) {      // F % 8 == 0: a 16-B piece may end 8 B past the row
-                const uint4 v = *reinterpret_cast<const uint4 *>(Kacc + r * 128 + 16 * sg);
+                // the 8-byte pieces of a row are XOR-swizzled by the row (conflict-free collection, see below): the pair
+                // (2 sg, 2 sg + 1) sits in the 16-byte slot sg ^ (r >> 1 & 7), its halves exchanged when r is odd
+                const uint4 raw = *reinterpret_cast<const uint4 *>(Kacc + r * 128 + 16 * (sg ^ ((r >> 1) & 7)));
+                const uint4 v = (r & 1) ? make_uint4(raw.z, raw.w, raw.x, raw.y) : raw;
                 uint8_t *dst = a.keep + krow * (int64_t)a.F + kbase + 16 * sg;
                 if (kbase + 16 * sg + 8 < a.F) *reinterpret_cast<uint4 *>(dst) = v;
                 else *reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
@@ -428,10 +469,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
 #pragma unroll
             for (int hh = 0; hh < HPT; ++hh) acc[m][t][hh] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // staging registers: X XV x float4 (row = idx >> 3, k4 = (idx & 7) * 4), W WV floats (col = tid & 63,
-    // k = (tid >> 6) * WV + j: 64 lanes read 64 consecutive columns per load)
+    // staging registers: X XV x float4 (row = idx >> 3, k4 = (idx & 7) * 4), W WU 8-byte pieces of the image
     float4_t xr[XV];
-    float wr[WV];
+    uint2 wq[WU];
+    const int ktiles = (a.F + 31) >> 5;
     auto load_tile = [&](int k0) {
         // unconditional loads from clamped addresses + selects: a predicated load becomes a branch
         // around it with its own s_waitcnt, which serialises the tile's loads
@@ -444,11 +485,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
             const int kc = k0 + c4 < a.F ? k0 + c4 : a.F - 4;       // F % 4 == 0 (vec path)
             xr[i] = load_x4(a.X, XBF, rc * a.ldx + kc);             // RAW: out-of-range elements are zeroed when the
         }                                                           // tile is staged -- a select here makes the wave
-#pragma unroll                                                      // wait for the load BEFORE its MFMA phase (round 3:
-        for (int j = 0; j < WV; ++j) {                              // that was the case, every K-step paid the HBM latency)
-            const int kw = k0 + (tid >> 6) * WV + j;
-            wr[j] = a.W[(int64_t)(kw < a.F ? kw : a.F - 1) * HAN_D + (tid & 63)];
-        }
+        const int kt = (k0 >> 5) < ktiles ? (k0 >> 5) : ktiles - 1; // wait for the load BEFORE its MFMA phase (round 3:
+        const unsigned char *src = a.wimg + (int64_t)kt * B6_WTILE; // that was the case, every K-step paid the HBM latency)
+#pragma unroll
+        for (int i = 0; i < WU; ++i) wq[i] = *reinterpret_cast<const uint2 *>(src + 8 * (tid + NT * i));
     };
     const uint32_t thr2 = (a.thr_in & 0xFFFFu) * 0x00010001u, one2 = 0x00010001u;   // keep iff field < thr_in
     load_tile(0);
@@ -460,7 +500,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int idx = tid + NT * i;
-            const int off = (idx >> 3) * B6_LDB + (idx & 7) * 8;
+            const int off = b6_off(idx >> 3, (idx & 7) >> 1) + (idx & 1) * 8;
             const bool ok = row0 + (idx >> 3) < a.N && k0 + (idx & 7) * 4 < a.F;
             uint32_t h[4], m[4], l[4];
 #pragma unroll
@@ -471,34 +511,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
                 *reinterpret_cast<uint2 *>(Xs + 2 * B6_XBYTES + off) = make_uint2(b6_pack(l[0], l[1]), b6_pack(l[2], l[3]));
             }
         }
-        {
-            uint32_t h[WV], m[WV], l[WV];
 #pragma unroll
-            for (int j = 0; j < WV; ++j) b6_split(k0 + (tid >> 6) * WV + j < a.F ? wr[j] : 0.f, h[j], m[j], l[j]);
-            const int off = (tid & 63) * B6_LDB + (tid >> 6) * (2 * WV);
-            uint32_t ph[WV / 2], pm[WV / 2], pl[WV / 2];
-#pragma unroll
-            for (int i = 0; i < WV / 2; ++i) {
-                ph[i] = b6_pack(h[2 * i], h[2 * i + 1]);
-                pm[i] = b6_pack(m[2 * i], m[2 * i + 1]);
-                pl[i] = b6_pack(l[2 * i], l[2 * i + 1]);
-            }
-            if (WV == 8) {
-                *reinterpret_cast<uint4 *>(Ws + off) = make_uint4(ph[0], ph[1], ph[WV / 2 - 2], ph[WV / 2 - 1]);
-                *reinterpret_cast<uint4 *>(Ws + B6_WBYTES + off) = make_uint4(pm[0], pm[1], pm[WV / 2 - 2], pm[WV / 2 - 1]);
-                *reinterpret_cast<uint4 *>(Ws + 2 * B6_WBYTES + off) = make_uint4(pl[0], pl[1], pl[WV / 2 - 2], pl[WV / 2 - 1]);
-            } else {
-                *reinterpret_cast<uint2 *>(Ws + off) = make_uint2(ph[0], ph[1]);
-                *reinterpret_cast<uint2 *>(Ws + B6_WBYTES + off) = make_uint2(pm[0], pm[1]);
-                *reinterpret_cast<uint2 *>(Ws + 2 * B6_WBYTES + off) = make_uint2(pl[0], pl[1]);
-            }
-        }
+        for (int i = 0; i < WU; ++i) *reinterpret_cast<uint2 *>(Ws + 8 * (tid + NT * i)) = wq[i];      // straight copy
         __syncthreads();
         // UNCONDITIONAL (clamped addresses): under an `if` the loaded registers meet the not-loaded path in a phi, whose
         // copies make the wave wait for the loads right here instead of after the MFMA phase
         load_tile(k0 + 32);   // in flight under the MFMAs
+        const int fro = l15 * B6_LDB + ((l4 ^ b6_swz(l15)) << 4);      // this lane's fragment inside a 16-row tile
         auto bfrag = [&](int t, int s3) {        // B[k = 8*l4 + j][col = 16t + l15]
-            return *reinterpret_cast<const i32x4 *>(Ws + s3 * B6_WBYTES + (16 * t + l15) * B6_LDB + 16 * l4);
+            return *reinterpret_cast<const i32x4 *>(Ws + s3 * B6_WBYTES + 16 * t * B6_LDB + fro);
         };
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -506,7 +527,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
             i32x4 af[NX];
 #pragma unroll
             for (int s3 = 0; s3 < NX; ++s3)
-                af[s3] = *reinterpret_cast<const i32x4 *>(Xs + s3 * B6_XBYTES + lr * B6_LDB + 16 * l4);
+                af[s3] = *reinterpret_cast<const i32x4 *>(Xs + s3 * B6_XBYTES + 16 * (w * MT + m) * B6_LDB + fro);
             if (!DROP) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -571,8 +592,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void project_fwd_b6_kerne
                         acc[m][t][hh] = cc;
                     }
                 }
+                // 16 contiguous lanes hold the same 8-byte piece (k0 & 96) / 8 + l4 of 16 consecutive rows: XOR-ing the
+                // piece index with the row spreads them over 16 different pieces = 32 banks (un-swizzled: 16-way)
                 if constexpr (KEEP)
-                    *reinterpret_cast<uint2 *>(Kacc + lr * 128 + (k0 & 96) + 8 * l4) = make_uint2(kw[0], kw[1]);
+                    *reinterpret_cast<uint2 *>(Kacc + lr * 128 + 8 * ((((k0 & 96) >> 3) + l4) ^ (lr & 15))) = make_uint2(kw[0], kw[1]);
             }
         }
     }
@@ -637,11 +660,13 @@ struct ProjMultiArgs {
     const void *X;
     int64_t ldx;
     const float *W;          // (P, F, 64)
+    const unsigned char *wimg;   // (P, ktiles, B6_WTILE): the pre-split LDS-ready images (project_wimage_kernel)
     void *H;                 // (P, N, 64) fp32 or bf16
     int h_bf16;
     int64_t N;
     int F;
     int p_first;             // first meta-path of this launch
+    int P;                   // meta-paths in the image (its layout is [K-step][meta-path])
     const float *a1, *a2, *b1, *b2;     // (P, K, FP), (P, K)
     float *f1, *f2;          // (P, N, K)
     int K;
@@ -654,18 +679,21 @@ template <bool XBF, int NP, int MT>
 __global__ __launch_bounds__(512) void project_fwd_b6_multi_kernel(const ProjMultiArgs a) {
     constexpr int NX = XBF ? 1 : 3;
     constexpr int NT = 512;
-    constexpr int WB = NP * B6_WBYTES;           // bytes of one term's W image: NP x 64 columns x 96 B
+    constexpr int WU = NP * (B6_WTILE / 8) / NT; // 8-byte pieces of the W images per thread per K-step
     constexpr int ROWS = 128 * MT;               // rows per block
     constexpr int XB = ROWS * B6_LDB;            // bytes of one term's X image
     extern __shared__ __attribute__((aligned(16))) unsigned char mlds[];
-    unsigned char *Xs = mlds;                    // [NX][ROWS][96 B]
-    unsigned char *Ws = mlds + NX * XB;          // [3][NP * 64][96 B]
+    unsigned char *Xs = mlds;                    // [NX][ROWS][64 B, slots swizzled: b6_off]
+    unsigned char *Ws = mlds + NX * XB;          // [NP][3][64][64 B]
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * ROWS;
     const int p0 = a.p_first + (int)blockIdx.y * NP;
-    const float *Wp = a.W + (int64_t)p0 * a.F * HAN_D;
+    const int ktiles = (a.F + 31) >> 5;
+    // the block's W tile of a K-step = the NP consecutive images (p0 .. p0 + NP - 1) of that K-step: the image is laid out
+    // [K-step][meta-path], and the LDS copy keeps that order ([pi][term][column][64 B]) -- one contiguous run of 8-byte pieces
+    const unsigned char *wsrc = a.wimg + (int64_t)p0 * B6_WTILE + 8 * tid;
 
     f32x4 acc[MT][NP * 4];
 #pragma unroll
@@ -674,7 +702,7 @@ __global__ __launch_bounds__(512) void project_fwd_b6_multi_kernel(const ProjMul
         for (int t = 0; t < NP * 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4_t xr[2 * MT];
-    float wr[NP][4];
+    uint2 wq[WU];
     auto load_tile = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
@@ -685,13 +713,10 @@ __global__ __launch_bounds__(512) void project_fwd_b6_multi_kernel(const ProjMul
             const int kc = k0 + c4 < a.F ? k0 + c4 : a.F - 4;
             xr[i] = load_x4(a.X, XBF, rc * a.ldx + kc);      // raw; zeroed when staged (no use before the MFMA phase)
         }
+        const int kt = (k0 >> 5) < ktiles ? (k0 >> 5) : ktiles - 1;
 #pragma unroll
-        for (int pi = 0; pi < NP; ++pi)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kw = k0 + (tid >> 6) * 4 + j;
-                wr[pi][j] = Wp[((int64_t)pi * a.F + (kw < a.F ? kw : a.F - 1)) * HAN_D + (tid & 63)];
-            }
+        for (int i = 0; i < WU; ++i)
+            wq[i] = *reinterpret_cast<const uint2 *>(wsrc + (int64_t)kt * a.P * B6_WTILE + 8 * NT * i);
     };
     load_tile(0);
     for (int k0 = 0; k0 < a.F; k0 += 32) {
@@ -699,7 +724,7 @@ __global__ __launch_bounds__(512) void project_fwd_b6_multi_kernel(const ProjMul
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             const int idx = tid + NT * i;
-            const int off = (idx >> 3) * B6_LDB + (idx & 7) * 8;
+            const int off = b6_off(idx >> 3, (idx & 7) >> 1) + (idx & 1) * 8;
             const bool ok = row0 + (idx >> 3) < a.N && k0 + (idx & 7) * 4 < a.F;
             uint32_t h[4], m[4], l[4];
 #pragma unroll
@@ -711,29 +736,22 @@ __global__ __launch_bounds__(512) void project_fwd_b6_multi_kernel(const ProjMul
             }
         }
 #pragma unroll
-        for (int pi = 0; pi < NP; ++pi) {
-            uint32_t h[4], m[4], l[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b6_split(k0 + (tid >> 6) * 4 + j < a.F ? wr[pi][j] : 0.f, h[j], m[j], l[j]);
-            const int off = (pi * 64 + (tid & 63)) * B6_LDB + (tid >> 6) * 8;
-            *reinterpret_cast<uint2 *>(Ws + off) = make_uint2(b6_pack(h[0], h[1]), b6_pack(h[2], h[3]));
-            *reinterpret_cast<uint2 *>(Ws + WB + off) = make_uint2(b6_pack(m[0], m[1]), b6_pack(m[2], m[3]));
-            *reinterpret_cast<uint2 *>(Ws + 2 * WB + off) = make_uint2(b6_pack(l[0], l[1]), b6_pack(l[2], l[3]));
-        }
+        for (int i = 0; i < WU; ++i) *reinterpret_cast<uint2 *>(Ws + 8 * (tid + NT * i)) = wq[i];      // straight copy of the images' K-step
         __syncthreads();
         load_tile(k0 + 32);      // unconditional, clamped: see project_fwd_b6_kernel
+        const int fro = l15 * B6_LDB + ((l4 ^ b6_swz(l15)) << 4);      // this lane's fragment inside a 16-row tile
         i32x4 af[MT][NX];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int s3 = 0; s3 < NX; ++s3)
-                af[m][s3] = *reinterpret_cast<const i32x4 *>(Xs + s3 * XB + (16 * (w * MT + m) + l15) * B6_LDB + 16 * l4);
+                af[m][s3] = *reinterpret_cast<const i32x4 *>(Xs + s3 * XB + 16 * (w * MT + m) * B6_LDB + fro);
 #pragma unroll
         for (int t = 0; t < NP * 4; ++t) {
-            const unsigned char *bp = Ws + (16 * t + l15) * B6_LDB + 16 * l4;
+            const unsigned char *bp = Ws + (t >> 2) * B6_WTILE + 16 * (t & 3) * B6_LDB + fro;
             const i32x4 b0 = *reinterpret_cast<const i32x4 *>(bp);
-            const i32x4 b1 = *reinterpret_cast<const i32x4 *>(bp + WB);
-            const i32x4 b2 = *reinterpret_cast<const i32x4 *>(bp + 2 * WB);
+            const i32x4 b1 = *reinterpret_cast<const i32x4 *>(bp + B6_WBYTES);
+            const i32x4 b2 = *reinterpret_cast<const i32x4 *>(bp + 2 * B6_WBYTES);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 f32x4 c = acc[m][t];
@@ -1359,11 +1377,21 @@ static void fwd_geometry(int64_t N, int F, int *mt, int *nsplit, int *f_chunk) {
     *nsplit = (F + chunk - 1) / chunk;
 }
 
-extern "C" size_t han_project_fwd_workspace(int64_t N, int F, int K, int FP) {
+// bytes of the pre-split W image of P meta-paths (project_wimage_kernel)
+static size_t wimage_bytes(int F, int P) { return (size_t)((F + 31) / 32) * (size_t)P * B6_WTILE; }
+// shapes the bf16 x 6 matrix-pipe kernels may run on (whole-F blocks of 128 rows)
+static bool b6_shape(int64_t N, int nsplit) { return nsplit == 1 && N >= 64 * 256; }
+
+extern "C" size_t han_project_fwd_multi_workspace(int64_t N, int F, int K, int FP, int P) {
     (void)K; (void)FP;
     int mt, nsplit, f_chunk;
     fwd_geometry(N > 0 ? N : 0, F, &mt, &nsplit, &f_chunk);
-    return nsplit > 1 ? (size_t)nsplit * (size_t)N * HAN_D * sizeof(float) : 0;
+    if (nsplit > 1) return (size_t)nsplit * (size_t)N * HAN_D * sizeof(float);      // split-F partial tiles (one meta-path at a time)
+    return b6_shape(N, nsplit) ? wimage_bytes(F, P > 0 ? P : 1) : 0;
+}
+
+extern "C" size_t han_project_fwd_workspace(int64_t N, int F, int K, int FP) {
+    return han_project_fwd_multi_workspace(N, F, K, FP, 1);
 }
 
 // the shapes for which the training forward writes (and dW reads) the keep table: the reference head shape on the
@@ -1424,9 +1452,16 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
     // bf16 features are their own high term (no split, three products instead of six): there the matrix-pipe
     // kernel is also the faster eval forward
     const bool b6_want = (in_drop > 0.f || a.x_bf16) ? !(flags & HAN_FLAG_K1_EXACT_PIPE) : (flags & HAN_FLAG_K1_MATRIX_PIPE) != 0;
-    const bool b6 = vec && nsplit == 1 && N >= 64 * 256 && (in_drop == 0.f || (K == 8 && FP == 8)) && b6_want;
+    const bool b6 = vec && b6_shape(N, nsplit) && (in_drop == 0.f || (K == 8 && FP == 8)) && b6_want;
     if (a.keep && !(b6 && keep_table_shape(N, F, ldx, K, FP))) return HAN_E_BADARG;   // no kernel writes a table here
+    a.wimg = nullptr;
     if (b6) {
+        // W is split into its three bf16 terms ONCE, into the LDS-ready image every block copies per K-step
+        if (!workspace || workspace_bytes < wimage_bytes(F, 1)) return HAN_E_WORKSPACE;
+        const int ktiles = (F + 31) / 32;
+        project_wimage_kernel<<<(ktiles * 512 + 255) / 256, 256, 0, st>>>(W, (unsigned char *)workspace, F, ktiles, 1);
+        HAN_CHECK_LAUNCH();
+        a.wimg = (const unsigned char *)workspace;
         const dim3 g6((unsigned)((N + B6_ROWS - 1) / B6_ROWS));
 #define HAN_LAUNCH_B6(D_, X_, K_)                                                               \
     do {                                                                                        \
@@ -1488,7 +1523,8 @@ extern "C" int han_project_fwd(const void *X, int x_dtype, int64_t ldx, const fl
 
 // multi-meta-path eval forward on the fused kernel: groups of 4, then 2 meta-paths per block
 template <bool XBF>
-static int launch_multi(ProjMultiArgs m, int P, int np_max, hipStream_t st) {
+static int launch_multi(ProjMultiArgs m, int P, int np_max, hipStream_t st, int *done) {
+    *done = 0;      // returns 0 or an error code (HIP errors are small POSITIVE ints: never to be read as a count)
     constexpr int MT = 2;
     const unsigned tiles = (unsigned)((m.N + 128 * MT - 1) / (128 * MT));
     const size_t xb = (size_t)(XBF ? 1 : 3) * 128 * MT * B6_LDB;
@@ -1510,8 +1546,9 @@ static int launch_multi(ProjMultiArgs m, int P, int np_max, hipStream_t st) {
         }
         HAN_CHECK_LAUNCH();
         p += groups * np;
+        *done = p;      // meta-paths done; a last odd one is left to the caller
     }
-    return p;      // meta-paths done (>= 0); a last odd one is left to the caller
+    return 0;
 }
 
 extern "C" int han_project_fwd_multi(const void *X, int x_dtype, int64_t ldx, const float *W, const float *a1,
@@ -1534,12 +1571,17 @@ extern "C" int han_project_fwd_multi(const void *X, int x_dtype, int64_t ldx, co
         !(flags & HAN_FLAG_K1_EXACT_PIPE) && (x_dtype == HAN_DTYPE_F32 || x_dtype == HAN_DTYPE_BF16) &&
         (table_dtype == HAN_DTYPE_F32 || h_bf16)) {
         hipStream_t st = (hipStream_t)stream;
+        if (!workspace || workspace_bytes < wimage_bytes(F, P)) return HAN_E_WORKSPACE;
+        const int ktiles = (F + 31) / 32;
+        project_wimage_kernel<<<(int)(((int64_t)ktiles * 512 * P + 255) / 256), 256, 0, st>>>(W, (unsigned char *)workspace, F, ktiles, P);
+        HAN_CHECK_LAUNCH();
         ProjMultiArgs m;
+        m.wimg = (const unsigned char *)workspace; m.P = P;
         m.X = X; m.ldx = ldx; m.W = W; m.H = H; m.h_bf16 = h_bf16; m.N = N; m.F = F; m.p_first = 0;
         m.a1 = a1; m.a2 = a2; m.b1 = b1; m.b2 = b2; m.f1 = f1; m.f2 = f2; m.K = K; m.fuse_scores = FP == 8;
         const int np_max = (flags & HAN_FLAG_K1_PAIRS) ? 2 : 4;
-        done = x_bf16 ? launch_multi<true>(m, P, np_max, st) : launch_multi<false>(m, P, np_max, st);
-        if (done < 0 || done > P) return done;      // an error code
+        const int rc = x_bf16 ? launch_multi<true>(m, P, np_max, st, &done) : launch_multi<false>(m, P, np_max, st, &done);
+        if (rc != 0) return rc;
         if (FP != 8) {                               // other head widths: scores from the stored rows
             for (int p = 0; p < done; ++p) {
                 ScoreArgs s;

@@ -143,6 +143,28 @@ class CSRGraph:
                                         chunk_start=chunk_start, chunk_end=chunk_end)
         return self._split[key]
 
+    def row_bins(self, short_deg: int = 16, split_deg: int = 8192):
+        """Degree bins of the rows (han_row_split_t: short_rows / mid_rows): rows with fewer than `short_deg` entries
+        (incl. empty rows), ordered by ceil(deg / 4) and then id -- four of them share a wave, one 16-lane group
+        each, and should need the same number of 4-entry steps --, rows of short_deg .. split_deg entries in id order
+        (a wave each), rows beyond split_deg (row_split's chunks).  Returns dict(n_short, short_rows, n_mid, mid_rows)
+        with int32 device tensors; a list is None when its bin holds EVERY row (identity).  Cached."""
+        key = ("bins", int(short_deg), int(split_deg))
+        if key not in self._split:
+            deg = self.degrees()
+            is_short = deg < short_deg
+            is_mid = (~is_short) & (deg <= split_deg)
+            n_short, n_mid = int(is_short.sum()), int(is_mid.sum())
+            short_rows = mid_rows = None
+            if 0 < n_short < self.n_rows:
+                ids = torch.nonzero(is_short).flatten()
+                order = torch.sort((deg[ids] + 3) // 4, stable=True).indices
+                short_rows = ids[order].to(torch.int32).contiguous()
+            if 0 < n_mid < self.n_rows:
+                mid_rows = torch.nonzero(is_mid).flatten().to(torch.int32).contiguous()
+            self._split[key] = dict(n_short=n_short, short_rows=short_rows, n_mid=n_mid, mid_rows=mid_rows)
+        return self._split[key]
+
     # ---- transposition (CSC) ------------------------------------------------
     def transpose(self) -> "CSRGraph":
         """The transposed graph: for every source j the destinations i, in

@@ -217,7 +217,9 @@ class NodeLevelAttention(torch.autograd.Function):
                                       table_gid=plan.gid if plan is not None else None, res=R,
                                       seed_dev=seed_dev, f2=None if multi else f2)
             if train:
-                saved.append((H, f1, f2) + sv + (R, proj_keep[p]))
+                # sv[0] is the OUTPUT view M[:, p, :] the backward inverts the activation on: it is kept through
+                # ctx.save_for_backward(M) below (version-checked by autograd, no reference cycle), not here
+                saved.append((H, f1, f2, None) + sv[1:] + (R, proj_keep[p]))
 
         for p in range(P):
             with _on_path(streams, p):
@@ -230,6 +232,9 @@ class NodeLevelAttention(torch.autograd.Function):
         ctx.cfg, ctx.xs, ctx.graphs = cfg, xs, graphs
         ctx.xin_shape = tuple(Xin.shape) if Xin is not None else None
         ctx.saved_per_p = saved
+        # the per-meta-path tensors above were allocated on these streams: the backward must run each meta-path on
+        # the SAME stream (the caching allocator ties a block to its allocation stream), whatever cfg holds by then
+        ctx.streams = streams
         ctx.in_drop, ctx.coef_drop = in_drop, coef_drop
         ctx.has_res = Wr is not None
         # direct-gradient mode (HANTrainer): every parameter carries a pre-bound .grad slice of
@@ -237,13 +242,18 @@ class NodeLevelAttention(torch.autograd.Function):
         # their results there and autograd gets None (no copy / accumulate launches)
         plist = (W, a1, b1, a2, b2, c) + ((Wr, br) if Wr is not None else ())
         ctx.direct = tuple(p.grad for p in plist) if all(_direct(p) for p in plist) else None
-        ctx.save_for_backward(W, a1, b1, a2, b2, c, *((Wr,) if Wr is not None else ()))
+        # M, the output, is backward state too (the pre-activation is recovered from it): saved through autograd, so
+        # that an in-place change of M between forward and backward raises instead of giving wrong gradients
+        ctx.save_for_backward(W, a1, b1, a2, b2, c, *((Wr,) if Wr is not None else ()), *((M,) if train else ()))
         return M
 
     @staticmethod
     def backward(ctx, dM):
         W, a1, b1, a2, b2, c = ctx.saved_tensors[:6]
         Wr = ctx.saved_tensors[6] if ctx.has_res else None
+        if not ctx.cfg["train"]:
+            raise RuntimeError("NodeLevelAttention was run with train=False; no backward state")
+        Mout = ctx.saved_tensors[-1]
         dWr = torch.empty_like(Wr) if Wr is not None else None
         dbr = torch.empty_like(c) if Wr is not None else None
         cfg, xs, graphs = ctx.cfg, ctx.xs, ctx.graphs
@@ -273,12 +283,12 @@ class NodeLevelAttention(torch.autograd.Function):
         masked = cfg.get("masked_bwd")        # per meta-path MaskedBackwardPlan, or None (the full pass)
         rows = [None] * P
         dres_in = []
-        streams = cfg.get("streams") if (not multi and cfg.get("streams") is not None and len(cfg["streams"]) >= P) else None
+        streams = ctx.streams       # the streams the forward ran (and allocated) on
         _fork(streams)
 
         def rows_path(p):      # row-local halves first; their tables go out while we continue
-            H, f1, f2, pre, lse, aggp, tsum, R, _keep = ctx.saved_per_p[p]
-            gs, df1, dcp = ops.node_attn_bwd_rows(dM[:, p, :], pre, aggp, tsum, f1, lse, c[p],
+            H, f1, f2, _, lse, aggp, tsum, R, _keep = ctx.saved_per_p[p]
+            gs, df1, dcp = ops.node_attn_bwd_rows(dM[:, p, :], Mout[:, p, :], aggp, tsum, f1, lse, c[p],
                                                   activation=cfg["act"], K=K, FP=FP,
                                                   table_dtype=H.dtype, res=R, dc_out=dc[p])
             if Wr is not None:      # residual: d(pre) = g flows into Wr, br and the input
@@ -415,7 +425,7 @@ class WideHeadAttention(torch.autograd.Function):
                                           table_gid=plan.gid if plan is not None else None, res=Rs[s_],
                                           seed_dev=seed_dev, f2_src=f2_tab)
                 if train:
-                    per_s.append((Hs[s_],) + sv + (Rs[s_],))
+                    per_s.append((Hs[s_], None) + sv[1:] + (Rs[s_],))      # the output slice: ctx.save_for_backward(M)
             if train:
                 saved.append((f1, f2, per_s))
         ctx.cfg, ctx.xs, ctx.graphs, ctx.S = cfg, xs, graphs, S
@@ -423,7 +433,7 @@ class WideHeadAttention(torch.autograd.Function):
         ctx.saved_per_p = saved
         ctx.in_drop, ctx.coef_drop = in_drop, coef_drop
         ctx.has_res = Wr is not None
-        ctx.save_for_backward(W, a1, a2, c, *((Wr,) if Wr is not None else ()))
+        ctx.save_for_backward(W, a1, a2, c, *((Wr,) if Wr is not None else ()), *((M,) if train else ()))
         return M
 
     @staticmethod
@@ -433,6 +443,7 @@ class WideHeadAttention(torch.autograd.Function):
         cfg, xs, graphs, S = ctx.cfg, ctx.xs, ctx.graphs, ctx.S
         if not cfg["train"]:
             raise RuntimeError("WideHeadAttention was run with train=False; no backward state")
+        Mout = ctx.saved_tensors[-1]
         P, dev = len(graphs), W.device
         Fw = W.shape[1]
         dM = dM.contiguous()
@@ -459,8 +470,9 @@ class WideHeadAttention(torch.autograd.Function):
             exchange = (plan.exchange_async if plan is not None else part.all_gather_rows_async) if multi else None
             rows, df1 = [], None
             for s_ in range(S):       # row-local halves: g, the slice's share of df1
-                H, pre, lse, aggp, tsum, R = per_s[s_]
-                gs, df1s, _ = ops.node_attn_bwd_rows(dM[:, p, s_ * D:(s_ + 1) * D], pre, aggp, tsum, f1, lse, cs[s_],
+                H, _, lse, aggp, tsum, R = per_s[s_]
+                gs, df1s, _ = ops.node_attn_bwd_rows(dM[:, p, s_ * D:(s_ + 1) * D], Mout[:, p, s_ * D:(s_ + 1) * D], aggp,
+                                                     tsum, f1, lse, cs[s_],
                                                      activation=cfg["act"], K=1, FP=D, table_dtype=H.dtype, res=R,
                                                      dc_out=dc[p, s_ * D:(s_ + 1) * D])
                 rows.append(exchange(gs, ("wb", lay, grp, p, s_)) if multi else _Ready(gs))      # one [g | stats] table per slice

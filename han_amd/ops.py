@@ -125,19 +125,33 @@ SPLIT_DEG = 8192       # rows longer than this are split into chunks of SPLIT_CH
 SPLIT_CHUNK = 4096
 
 
-def _row_split_arg(graph: CSRGraph, tag: str):
-    """ctypes han_row_split_t for `graph` (None when no row needs splitting).
-    Returns (byref-able struct or None, keepalive tuple)."""
+SHORT_DEG = 16         # HAN_SHORT_DEG: rows below this many entries run four to a wave in a degree-binned launch
+BINNED = True          # tests / measurements: False = one row shape per launch, chosen from E / N (rounds 1-3)
+
+
+def _row_split_arg(graph: CSRGraph, tag: str, bins: bool = True):
+    """ctypes han_row_split_t for `graph`: its degree bins (short / mid row lists) and the chunks of its rows beyond
+    SPLIT_DEG (None when the graph has neither: every row in one bin and no long row still passes the bin counts,
+    so that the library uses that bin's row shape).  Returns (byref-able struct or None, keepalive tuple)."""
     sp = graph.row_split(SPLIT_DEG, SPLIT_CHUNK)
-    if sp is None:
+    rb = graph.row_bins(SHORT_DEG, SPLIT_DEG) if (bins and BINNED and graph.n_rows > 0) else None
+    if sp is None and rb is None:
         return None, None
     lib = _lib.load()
-    ws = _ws(lib.han_row_split_workspace(sp["n_chunks"]), graph.device, "split" + tag)
-    st = _lib.HanRowSplit(sp["split_deg"], sp["n_long"], sp["n_chunks"], sp["long_rows"].data_ptr(),
-                          sp["long_ptr"].data_ptr(), sp["chunk_long"].data_ptr(),
-                          sp["chunk_start"].data_ptr(), sp["chunk_end"].data_ptr(), ws.data_ptr(),
-                          ws.numel())
-    return st, (sp, ws)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    if sp is not None:
+        ws = _ws(lib.han_row_split_workspace(sp["n_chunks"]), graph.device, "split" + tag)
+        st = _lib.HanRowSplit(sp["split_deg"], sp["n_long"], sp["n_chunks"], sp["long_rows"].data_ptr(),
+                              sp["long_ptr"].data_ptr(), sp["chunk_long"].data_ptr(),
+                              sp["chunk_start"].data_ptr(), sp["chunk_end"].data_ptr(), ws.data_ptr(),
+                              ws.numel(), 0, 0, None, None)
+    else:
+        ws = None
+        st = _lib.HanRowSplit(SPLIT_DEG, 0, 0, None, None, None, None, None, None, 0, 0, 0, None, None)
+    if rb is not None:
+        st.n_short, st.n_mid = rb["n_short"], rb["n_mid"]
+        st.short_rows, st.mid_rows = ptr(rb["short_rows"]), ptr(rb["mid_rows"])
+    return st, (sp, rb, ws)
 
 
 LEAN = True                # tests / measurements: False keeps the classic gather kernels
@@ -255,7 +269,7 @@ def project_fwd_multi(X, W, a1, a2, b1, b2, in_drop=0.0, fts_drop=0.0, seeds=Non
     H = torch.empty((P, N, D), dtype=table_dtype, device=dev)
     f1 = torch.empty((P, N, K), dtype=torch.float32, device=dev)
     f2 = torch.empty((P, N, K), dtype=torch.float32, device=dev)
-    nbytes = lib.han_project_fwd_workspace(N, F, K, FP)
+    nbytes = lib.han_project_fwd_multi_workspace(N, F, K, FP, P)
     ws = _ws(nbytes, dev, "projf") if nbytes else None
     ldx = X.stride(0) if N > 1 else max(F, X.stride(0))
     keep, kb = None, 0
@@ -382,7 +396,7 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         tsum = torch.empty((N, K), dtype=torch.float32, device=dev)
         saved = (out, lse, aggp, tsum)
         ptrs = [None, lse.data_ptr(), aggp.data_ptr(), tsum.data_ptr()]
-    split, _keep = _row_split_arg(graph, "f")
+    split, _keep = _row_split_arg(graph, "f", bins=not lean)
     timing = K2_TIMING
     if timing is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -506,7 +520,8 @@ def node_attn_bwd_cols(graph_t: CSRGraph, gs_tab, H, f2, df1, a1, a2, coef_drop=
     fts_drop = _check_drop(fts_drop, "fts_drop")
     dH = torch.empty((NS, D), dtype=torch.float32, device=dev)
     df2 = torch.empty((NS, K), dtype=torch.float32, device=dev)
-    split, _keep = _row_split_arg(graph_t, "b")
+    lean_b = not graph_t.masked and _use_lean(graph_t, H)
+    split, _keep = _row_split_arg(graph_t, "b", bins=not lean_b)
     timing = K2_TIMING
     if timing is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -519,7 +534,7 @@ def node_attn_bwd_cols(graph_t: CSRGraph, gs_tab, H, f2, df1, a1, a2, coef_drop=
         NS, graph_t.nnz, K, FP, LEAKY_SLOPE, _check_drop(coef_drop, "coef_drop"), fts_drop,
         int(seed), _dev_word(seed_dev), int(src_offset), int(dst_offset),
         (FLAG_XCD_ORDER if graph_t.has_locality() else 0) | (FLAG_MASKED_EDGES if graph_t.masked else 0)
-        | (FLAG_LEAN if (not graph_t.masked and _use_lean(graph_t, H)) else 0),
+        | (FLAG_LEAN if lean_b else 0),
         ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_bwd_cols")
     if timing is not None:
         ev1.record()

@@ -108,12 +108,30 @@ def powerlaw_graph(n: int, nnz: int, alpha: float, seed: int, device="cpu", rows
     return CSRGraph(rp, cols.contiguous(), n, validate=False)
 
 
-def bernoulli_graph(n: int, density: float, seed: int, device="cpu") -> CSRGraph:
-    """ACM/DBLP-like: symmetric Bernoulli(density) edges + I (dense generation,
-    n <= ~10k)."""
+def _symmetric_pairs(rng, n: int, density: float | None, nnz: int | None):
+    """Strict-upper-triangle pairs (i < j) of a symmetric graph on n nodes: Bernoulli(density) per pair, or --
+    nnz given -- EXACTLY (nnz - n) / 2 pairs drawn without replacement, so that the mirrored graph plus the n
+    self-loops has exactly nnz entries (the data sets' edge counts, SURVEY.md section 8, include the self-loops)."""
+    iu, ju = np.triu_indices(n, 1)
+    if nnz is not None:
+        if (nnz - n) % 2 or not (0 <= (nnz - n) // 2 <= iu.size):
+            raise ValueError(f"a symmetric graph with self-loops on {n} nodes cannot have {nnz} entries")
+        sel = rng.choice(iu.size, size=(nnz - n) // 2, replace=False)
+    else:
+        sel = np.nonzero(rng.random(iu.size) < density)[0]
+    return iu[sel], ju[sel]
+
+
+def bernoulli_graph(n: int, density: float | None, seed: int, device="cpu", nnz: int | None = None) -> CSRGraph:
+    """ACM/DBLP-like: symmetric random edges + I (dense generation, n <= ~10k).  The strict upper triangle is
+    drawn at `density` (every off-diagonal pair is an edge with that probability -- round 3 drew BOTH triangles at
+    density/2 and OR-ed them, which gives d - d^2/4, 16 % short on a 78 % dense graph) or, with `nnz`, at exactly
+    (nnz - n)/2 pairs; then mirrored, then the self-loops (utils/process.py:18-20)."""
     rng = np.random.default_rng(seed)
-    a = rng.random((n, n)) < density / 2
-    a = a | a.T
+    i, j = _symmetric_pairs(rng, n, density, nnz)
+    a = np.zeros((n, n), dtype=bool)
+    a[i, j] = True
+    a[j, i] = True
     np.fill_diagonal(a, True)
     rowptr = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(a.sum(1), out=rowptr[1:])
@@ -152,11 +170,10 @@ def planted_partition(n: int, c: int, p_metapaths: int, f: int, deg_in: int, deg
 
 CONFIGS = {
     # name: (N, P, F, C, per-meta-path graph spec)
-    "acm-like": dict(n=3025, f=1870, c=3, graphs=[("bernoulli", 29281 / 3025 ** 2),
-                                                  ("bernoulli", 2210761 / 3025 ** 2)]),
-    "dblp-like": dict(n=4057, f=334, c=4, graphs=[("bernoulli", 11113 / 4057 ** 2),
-                                                  ("bernoulli", 5000495 / 4057 ** 2),
-                                                  ("bernoulli", 12924399 / 4057 ** 2)]),
+    # the data sets' entry counts incl. self-loops (PAP / PSP; APA / APCPA / APTPA), exactly
+    "acm-like": dict(n=3025, f=1870, c=3, graphs=[("symmetric_nnz", 29281), ("symmetric_nnz", 2210761)]),
+    "dblp-like": dict(n=4057, f=334, c=4, graphs=[("symmetric_nnz", 11113), ("symmetric_nnz", 5000495),
+                                                  ("symmetric_nnz", 12924399)]),
     "syn-1m": dict(n=1_000_000, f=256, c=4, graphs=[("regular", 50)] * 4),
     "syn-1m-skew": dict(n=1_000_000, f=256, c=4, graphs=[("powerlaw", 50_000_000, 2.1)] * 4),
     # locality: neighbours within +-20000 of the row id -> halo exchange under a node partition
@@ -190,8 +207,13 @@ def make_graph(spec, n, seed, device, rows=None):
         gen = torch.Generator(device=device)
         gen.manual_seed(424242 + n)                  # one relabelling for all meta-paths of a workload
         return permute_graph(g, torch.randperm(n, generator=gen, device=device))
-    if kind == "bernoulli":
-        g = bernoulli_graph(n, spec[1], seed, device)
+    if kind in ("bernoulli", "symmetric_nnz"):
+        if kind == "bernoulli":
+            g = bernoulli_graph(n, spec[1], seed, device)
+        else:      # a sample of the data set at another n (n_override) keeps the density
+            cfg_n = next(c["n"] for c in CONFIGS.values() if spec in c["graphs"])
+            nnz = spec[1] if n == cfg_n else n + 2 * int(round((spec[1] - cfg_n) / (cfg_n * (cfg_n - 1)) * n * (n - 1) / 2))
+            g = bernoulli_graph(n, None, seed, device, nnz=nnz)
         if rows is None:
             return g
         from .dist import _row_block

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HAN_ABI_VERSION 5
+#define HAN_ABI_VERSION 6
 
 #define HAN_E_BADARG   (-1)   /* null pointer, negative size, inconsistent shape.  The forward
                               * entry points return 0 at once for N == 0 (empty tensors may
@@ -100,10 +100,16 @@ const char *han_error_string(int code);
  * X (N,F) ldx>=F (elements; x_dtype fp32 or bf16); W (F,D); a1,a2 (K,FP); b1,b2 (K);
  * H (N,D) in table_dtype (f1/f2 are taken from the rows as stored); f1,f2 (N,K).
  * in_drop == 0 -> no input dropout.  row_offset = global id of row 0 (RNG key).
- * workspace: han_project_fwd_workspace() bytes (0 for long inputs; short inputs --
- * fewer 128-row tiles than CUs -- split the reduction over F and sum partial tiles
- * from it in a fixed order); may be NULL when that is 0.                            */
+ * workspace: han_project_fwd_workspace() bytes (short inputs -- fewer 128-row tiles than CUs -- split the
+ * reduction over F and sum partial tiles from it in a fixed order; long inputs keep the pre-split image of W
+ * there, see below); may be NULL when that is 0.                            */
 size_t han_project_fwd_workspace(int64_t N, int F, int K, int FP);
+/* Round 4: long inputs (at least 16 384 rows, no split over F) may run on the bf16 x 6 matrix-pipe kernels, which
+ * read W from a pre-split, LDS-ready image built in the workspace by a small launch in front of the projection
+ * (every block used to split the same W tiles again and store them through 4-way bank conflicts):
+ * han_project_fwd_workspace() then returns the image size, ceil(F / 32) * 12 288 bytes -- no longer 0 --, and
+ * han_project_fwd_multi_workspace() the size for the P meta-paths of one han_project_fwd_multi call.        */
+size_t han_project_fwd_multi_workspace(int64_t N, int F, int K, int FP, int P);
 /* Keep table of the per-head input dropout (layers.py:18-19), written by the training forward and
  * read by han_project_bwd so that dW does not regenerate the draws: N rows of F bytes (F % 8 == 0);
  * the 8 bytes of features 8o .. 8o+7 of row n form one little-endian 64-bit word whose bit
@@ -150,12 +156,24 @@ int han_project_bwd_input(const float *dH, const float *W, float *dX, int64_t ld
                           int F, int K, int FP, float in_drop, uint64_t seed, const uint64_t *seed_dev,
                           int64_t row_offset, void *stream);
 
-/* Row splitting for skewed graphs (optional; pass NULL for none).  Rows (sources, in
- * the backward) with more than split_deg stored entries are skipped by the main
+/* Degree bins and row splitting for skewed graphs (optional; pass NULL for none: the library then picks ONE row
+ * shape for the whole launch from E / N).
+ * Bins (round 4): real meta-path graphs mix rows of a few entries with rows of thousands (DBLP APA: mean 2.7, max
+ * 46; the power-law workload of SURVEY.md section 8d).  With n_short + n_mid > 0 the launch is degree-binned:
+ *   short_rows (n_short, int32 row ids): rows with fewer than HAN_SHORT_DEG entries (incl. empty rows) -- one 16-lane
+ *       group per row, four rows per wave, the row's ids one coalesced load; best ordered by ceil(deg / 4), then id,
+ *       so that the four rows of a wave need the same number of steps;
+ *   mid_rows (n_mid): rows of HAN_SHORT_DEG .. split_deg entries -- a wave per row;
+ *   rows beyond split_deg: the chunks below.
+ * A list pointer may be NULL when its bin holds every row of the launch (n == N: identity).  Every row must be in
+ * exactly one of the three sets; each row is processed by one fixed kernel in a fixed order (bitwise reproducible).
+ * Splitting: rows (sources, in the backward) with more than split_deg stored entries are skipped by the main
  * launch; each is cut into chunks of consecutive edges [chunk_start, chunk_end),
  * one wave per chunk produces a partial state in `workspace`, and a finishing
  * launch merges a row's chunks in order (deterministic).  chunk_long[c] indexes
- * long_rows; long_ptr (n_long+1) gives each long row's chunk range.            */
+ * long_rows; long_ptr (n_long+1) gives each long row's chunk range.  n_long == 0: no row is split (the chunk
+ * fields are then not read; split_deg must still bound the rows listed in mid_rows).            */
+#define HAN_SHORT_DEG 16
 typedef struct han_row_split {
     int64_t split_deg, n_long, n_chunks;
     const int64_t *long_rows, *long_ptr;
@@ -163,6 +181,8 @@ typedef struct han_row_split {
     const int64_t *chunk_start, *chunk_end;
     void *workspace;
     size_t workspace_bytes;       /* >= han_row_split_workspace(n_chunks) */
+    int64_t n_short, n_mid;       /* degree bins; both 0: not binned */
+    const int32_t *short_rows, *mid_rows;
 } han_row_split_t;
 size_t han_row_split_workspace(int64_t n_chunks);
 

@@ -6,14 +6,27 @@ from oracle import han_oracle as ho
 from oracle import han_oracle_torch as ht
 
 
-def random_adj(rng, n, density, symmetric=True, special_rows=True):
+def random_adj(rng, n, density, symmetric=True, special_rows=True, nnz=None):
     """Binary adjacency WITHOUT self-loops (adj_to_bias re-adds I, as
-    ex_acm3025.py:61 / utils/process.py:18-20).  special_rows plants the edge
+    ex_acm3025.py:61 / utils/process.py:18-20).  `density` = the probability of every off-diagonal pair
+    (the strict upper triangle is drawn and mirrored; round 3 drew the full matrix and took max(a, a^T), i.e.
+    2d - d^2); nnz = EXACT number of entries the graph has after +I (the data sets' counts include the
+    self-loops), in which case no special rows are planted.  special_rows plants the edge
     cases of SURVEY.md section 4: an isolated node (degree 1 after +I: the
     self-loop only) and a node adjacent to everybody (degree N)."""
-    a = (rng.random((n, n)) < density).astype(np.float64)
     if symmetric:
-        a = np.maximum(a, a.T)
+        iu, ju = np.triu_indices(n, 1)
+        if nnz is not None:
+            assert (nnz - n) % 2 == 0
+            sel = rng.choice(iu.size, size=(nnz - n) // 2, replace=False)
+            special_rows = False
+        else:
+            sel = np.nonzero(rng.random(iu.size) < density)[0]
+        a = np.zeros((n, n), dtype=np.float64)
+        a[iu[sel], ju[sel]] = 1.0
+        a[ju[sel], iu[sel]] = 1.0
+    else:
+        a = (rng.random((n, n)) < density).astype(np.float64)
     np.fill_diagonal(a, 0.0)
     if special_rows and n >= 4:
         a[1, :] = 0.0
@@ -26,10 +39,14 @@ def random_adj(rng, n, density, symmetric=True, special_rows=True):
 
 
 def make_problem(seed, n, f, p, c, densities, dtype=np.float64, nonzero_biases=True, hid_units=None,
-                 n_heads=(8, 1), residual=False, mp_att_size=128):
+                 n_heads=(8, 1), residual=False, mp_att_size=128, nnz=None):
+    """nnz: per meta-path the exact entry count incl. self-loops (a data set's figure) instead of a density."""
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((1, n, f)).astype(dtype)
-    adjs = [random_adj(rng, n, densities[i % len(densities)])[None] for i in range(p)]
+    if nnz is not None:
+        adjs = [random_adj(rng, n, None, nnz=nnz[i % len(nnz)])[None] for i in range(p)]
+    else:
+        adjs = [random_adj(rng, n, densities[i % len(densities)])[None] for i in range(p)]
     biases = [ho.adj_to_bias(a, [n], 1) for a in adjs]
     params = ho.init_params(rng, p, f, c, nonzero_biases=nonzero_biases, hid_units=hid_units,
                             n_heads=n_heads, residual=residual, mp_att_size=mp_att_size)

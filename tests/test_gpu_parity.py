@@ -1232,6 +1232,31 @@ def test_captured_epoch_replay_matches_eager_and_oracle(dev):
         assert np.abs(getattr(trainers[0].model, k).detach().cpu().numpy() - bpo[k].numpy()).max() < 2e-4, k
 
 
+def test_path_streams_do_not_change_the_numbers(dev, monkeypatch):
+    """a captured epoch forks one stream per meta-path (HAN_PATH_STREAMS, default on).  The same epochs on
+    the single chain (HAN_PATH_STREAMS=0) must give bit-equal parameters and losses: the streams only reorder
+    independent launches; forward and backward of a meta-path use the stream recorded at forward time."""
+    from han_amd import rng as hrng
+    from han_amd.trainer import HANTrainer
+    prob = make_problem(53, 90, 14, 3, 3, [0.05, 0.3, 0.6])
+    x, graphs = gpu_inputs(prob, dev)
+    labels = _t(prob["labels"], dev, torch.int32)
+    tm = _t(prob["mask"].astype(np.uint8), dev, torch.uint8)
+    flats, hist = [], []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("HAN_PATH_STREAMS", flag)
+        model, _ = build_model(prob, dev)
+        tr = HANTrainer(model, [x] * 3, graphs, labels, tm, attn_drop=0.6, ffd_drop=0.6, use_graph=True)
+        assert (model.path_streams is not None) == (flag == "1")
+        hrng.manual_seed(31)
+        hist.append([[float(v) for v in tr.epoch()] for _ in range(5)])
+        torch.cuda.synchronize()
+        assert tr._graph is not None
+        flats.append(model.flat.detach().clone())
+    assert hist[0] == hist[1]
+    assert torch.equal(flats[0], flats[1])
+
+
 def test_workspace_growth_between_graph_replays(dev):
     """The process-global scratch buffers are grow-only and a captured epoch replays with the raw
     pointers it saw: a LARGER request for the same buffers between two replays (another model, a
@@ -1379,14 +1404,113 @@ def test_row_split_for_long_rows_matches_oracle(dev, monkeypatch, drop):
             assert rel_err(grads[k], gref[k]) < GTOL, k
 
 
+def _mixed_degree_graph(n, transpose, seed=5):
+    """Rows of 1, 3, 15, 16, 17, 64 and 500 distinct neighbours mixed at random + three rows of 20 000 (beyond
+    SPLIT_DEG): every bin of the degree-binned launch (short: 16-lane group per row; mid: wave per row; long:
+    chunks) and the boundaries 15 / 16 / 17 between the first two.  Distinct ids per row by construction (an
+    arithmetic progression with a stride coprime to n), ascending.  transpose: the same edges with the roles
+    swapped, so that the BACKWARD's graph (the transposed one) has this degree mix."""
+    rng = np.random.default_rng(seed)
+    assert n % 2 == 0 and n % 5 == 0 and n > 20000
+    degs = rng.choice([1, 3, 15, 16, 17, 64, 500], size=n, p=[0.2, 0.2, 0.15, 0.15, 0.15, 0.1, 0.05])
+    degs[[7, n // 3, n - 2]] = 20000
+    rows, cols = [], []
+    for i, d in enumerate(degs):
+        step = int(rng.choice([1, 3, 7, 9, 11, 13]))                # odd, not a multiple of 5: coprime to n = 2^a 5 b...
+        start = int(rng.integers(0, n))
+        cc = (start + step * np.arange(d, dtype=np.int64)) % n
+        rows.append(np.full(d, i, dtype=np.int64))
+        cols.append(np.sort(cc))
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    if transpose:
+        order = np.lexsort((rows, cols))
+        rows, cols = cols[order], rows[order]
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=n), out=rp[1:])
+    return rp, cols.astype(np.int32), degs
+
+
+@pytest.mark.parametrize("transpose", [False, True])
+@pytest.mark.parametrize("drop", [0.0, 0.6])
+def test_degree_binned_launch_on_mixed_rows(dev, drop, transpose, monkeypatch):
+    """K2 launches are degree-binned per (graph, direction).  A graph mixing rows of 1, 3, 15, 16,
+    17, 64, 500 and 20 000 entries: loss, logits and every gradient against the oracle (fed the kernels' own dropout
+    masks), against the un-binned launch, and bitwise determinism of the binned one (forward outputs and gradients)."""
+    import math
+    from han_amd import ops, rng as hrng
+    from han_amd.graph import CSRGraph
+    from han_amd.gat import HeteGAT_multi
+    n, f, c = 20480, 12, 3
+    assert math.gcd(n, 3 * 7 * 9 * 11 * 13) == 1
+    rp, ci, degs = _mixed_degree_graph(n, transpose)
+    rng = np.random.default_rng(11)
+    prob = dict(n=n, f=f, p=1, c=c, x=0.5 * rng.standard_normal((1, n, f)),
+                params=ho.init_params(rng, 1, f, c, nonzero_biases=True))
+    labels = rng.integers(0, c, size=n)
+    mask = rng.random(n) < 0.3
+    model, bp = build_model(prob, dev)
+    g = CSRGraph.from_arrays(rp, ci, n, device=dev)
+    for gg in (g, g.transpose()):                      # both directions carry bins; the mixed one has all three
+        rb, sp = gg.row_bins(ops.SHORT_DEG, ops.SPLIT_DEG), gg.row_split(ops.SPLIT_DEG, ops.SPLIT_CHUNK)
+        assert rb["n_short"] + rb["n_mid"] + (sp["n_long"] if sp else 0) == n
+    mixed = g.transpose() if transpose else g
+    rb, sp = mixed.row_bins(ops.SHORT_DEG, ops.SPLIT_DEG), mixed.row_split(ops.SPLIT_DEG, ops.SPLIT_CHUNK)
+    assert sp["n_long"] == 3 and rb["n_short"] == int((degs < 16).sum()) and rb["n_mid"] == int((degs >= 16).sum()) - 3
+    short = rb["short_rows"].cpu().numpy()
+    assert (np.diff((degs[short] + 3) // 4) >= 0).all()            # ordered by the number of 4-entry steps
+    x = _t(prob["x"][0], dev)
+    lab_t, mask_t = _t(labels, dev, torch.int32), _t(mask.astype(np.uint8), dev, torch.uint8)
+
+    def run():
+        hrng.manual_seed(4242)
+        model.zero_grad_flat()
+        M = model.node_level([x], [g], drop, drop, True, ops.ACT_ELU)
+        Z, _ = model.semantic(M)
+        loss, _, logits = model.classifier_loss(Z, lab_t, mask_t, 1.0 / int(mask.sum()))
+        loss.backward()
+        return (float(loss), logits.detach().cpu().numpy(), M.detach().clone(),
+                {k: getattr(model, k).grad.detach().clone() for k in ht.PARAM_ORDER})
+
+    loss, lg, M1, g1 = run()
+    loss2, lg2, M2, g2 = run()
+    assert torch.equal(M1, M2) and all(torch.equal(g1[k], g2[k]) for k in ht.PARAM_ORDER)      # bitwise reproducible
+    monkeypatch.setattr(ops, "BINNED", False)
+    loss_u, lg_u, M_u, g_u = run()
+    monkeypatch.setattr(ops, "BINNED", True)
+    assert np.abs(lg - lg_u).max() < 2e-5 and abs(loss - loss_u) < 2e-5
+    for k in ht.PARAM_ORDER:
+        assert rel_err(g1[k].cpu().numpy(), g_u[k].cpu().numpy()) < 2e-4, k
+    # the oracle, fed the masks the kernels drew
+    masks, keep = None, 1.0
+    if drop > 0:
+        hrng.manual_seed(4242)
+        seed = hrng.next_seed()
+        keep = rng_ref.keep_prob32(drop)
+        masks = [{"seq": torch.tensor(rng_ref.seq_mask(seed, n, f, 8, drop)),
+                  "coef": torch.tensor(rng_ref.coef_mask_csr(seed, rp, ci, 8, drop)),
+                  "fts": torch.tensor(rng_ref.fts_mask(seed, n, 64, drop))}]
+    bpo = {k: v.clone().requires_grad_(True) for k, v in bp.items()}
+    logits_o, _, _ = ht.hetegat_forward([torch.tensor(prob["x"][0])], [(torch.tensor(rp), torch.tensor(ci))], bpo,
+                                        keep_in=keep, keep_coef=keep, masks=masks, dense=False)
+    loss_o = ht.masked_softmax_cross_entropy(logits_o, torch.tensor(np.eye(c)[labels]), torch.tensor(mask))
+    loss_o.backward()
+    assert np.abs(lg - logits_o.detach().numpy()).max() < (5 * TOL if drop else TOL)
+    assert abs(loss - float(loss_o)) < 5e-4
+    for k in ht.PARAM_ORDER:
+        assert rel_err(g1[k].cpu().numpy(), bpo[k].grad.numpy()) < GTOL, k
+
+
 # ------------------------------------------------- BASELINE.json configs at full size
+ACM_NNZ = (29281, 2210761)                  # SURVEY.md section 8: entries incl. self-loops of PAP / PSP
+DBLP_NNZ = (11113, 5000495, 12924399)       # APA / APCPA / APTPA
 def test_acm_like_config_logits_parity(dev):
     """configs[1]: ACM3025 shape (N=3025, P=2, F=1870, 8 heads x 8, C=3), DENSE
     bias_mat path, fp32, logits within 1e-4 of the float64 oracle (synthetic data
     with the measured PAP/PSP densities: ACM3025.mat is not available offline)."""
     from han_amd import synth
     n, f, p = 3025, 1870, 2
-    prob = make_problem(3025, n, f, p, 3, [29281 / n ** 2, 2210761 / n ** 2])
+    prob = make_problem(3025, n, f, p, 3, None, nnz=ACM_NNZ)        # PAP / PSP entry counts, exactly
+    assert [int((b > -1e8).sum()) for b in prob["biases"]] == list(ACM_NNZ)
     prob["x"] *= 0.2                        # bag-of-words-like magnitudes keep |logits| O(1)
     lg, fe, att = ho.hetegat_multi_inference([prob["x"]] * p, 3, n, False, 0.0, 0.0, prob["biases"],
                                              [8], [8, 1], prob["params"])
@@ -1405,7 +1529,8 @@ def test_dblp_like_config_sparse_path_parity(dev):
     measured APA / APCPA / APTPA degree mix (mean 2.7 / 1233 / 3186)."""
     from han_amd import layers
     n, f, p = 4057, 334, 3
-    prob = make_problem(4057, n, f, p, 4, [11113 / n ** 2, 5000495 / n ** 2, 12924399 / n ** 2])
+    prob = make_problem(4057, n, f, p, 4, None, nnz=DBLP_NNZ)       # APA / APCPA / APTPA entry counts, exactly
+    assert [int((b > -1e8).sum()) for b in prob["biases"]] == list(DBLP_NNZ)
     prob["x"] *= 0.3
     bp = ht.to_batched(prob["params"])
     graphs_o = [tuple(torch.tensor(t) for t in ho.bias_to_csr(b)) for b in prob["biases"]]

@@ -793,3 +793,47 @@ def test_locality_pass_is_a_pure_relabelling_on_cpu_backend(cpu_ops):
     assert abs(l0 - l1) < 1e-6 and abs(a0 - a1) < 1e-7
     assert float((lg0 - lg1).abs().max()) < 1e-5 and float((at0 - at1).abs().max()) < 1e-6
     assert float((g0 - g1).abs().max()) < 1e-6 * max(1.0, float(g0.abs().max()))
+
+
+def test_row_bins_partition_the_rows():
+    """CSRGraph.row_bins (the degree bins of a K2 launch): every row in exactly one of short / mid / long, the short
+    rows ordered by their number of 4-entry steps, a bin that holds every row is the identity (no list)."""
+    from han_amd.graph import CSRGraph
+    rng = np.random.default_rng(3)
+    deg = rng.choice([0, 1, 3, 15, 16, 17, 40, 9000], size=400, p=[0.05, 0.2, 0.2, 0.15, 0.15, 0.1, 0.14, 0.01])
+    deg[5] = 9000
+    rp = np.zeros(401, dtype=np.int64)
+    np.cumsum(deg, out=rp[1:])
+    g = CSRGraph(torch.tensor(rp), torch.zeros(int(rp[-1]), dtype=torch.int32), 400, validate=False)
+    rb, sp = g.row_bins(16, 8192), g.row_split(8192, 4096)
+    short, mid, long_ = rb["short_rows"].numpy(), rb["mid_rows"].numpy(), sp["long_rows"].numpy()
+    assert sorted(np.concatenate([short, mid, long_]).tolist()) == list(range(400))
+    assert (deg[short] < 16).all() and ((deg[mid] >= 16) & (deg[mid] <= 8192)).all() and (deg[long_] > 8192).all()
+    assert rb["n_short"] == len(short) and rb["n_mid"] == len(mid)
+    steps = (deg[short] + 3) // 4
+    assert (np.diff(steps) >= 0).all()
+    for s_ in np.unique(steps):                      # ids ascending inside a step class
+        assert (np.diff(short[steps == s_]) > 0).all()
+    assert (np.diff(mid) > 0).all()
+    # one bin holds everything: identity, no list
+    g2 = CSRGraph(torch.arange(0, 50 * 11, 50, dtype=torch.int64), torch.zeros(500, dtype=torch.int32), 10, validate=False)
+    rb2 = g2.row_bins(16, 8192)
+    assert rb2 == dict(n_short=0, short_rows=None, n_mid=10, mid_rows=None)
+    g3 = CSRGraph(torch.arange(0, 3 * 11, 3, dtype=torch.int64), torch.zeros(30, dtype=torch.int32), 10, validate=False)
+    assert g3.row_bins(16, 8192) == dict(n_short=10, short_rows=None, n_mid=0, mid_rows=None)
+
+
+def test_inplace_change_of_the_node_level_output_raises(cpu_ops):
+    """the K2 backward recovers the pre-activation from the forward's OUTPUT M; M is saved through
+    ctx.save_for_backward, so an in-place op on it (or on a slice) between forward and backward is caught by autograd's
+    version check instead of silently giving wrong gradients."""
+    prob = make_problem(41, 30, 6, 2, 3, [0.2, 0.4])
+    model, _ = _cpu_model(prob)
+    graphs = _cpu_graphs(prob)
+    x = torch.tensor(prob["x"][0], dtype=torch.float32)
+    M = model.node_level([x, x], graphs, 0.0, 0.0, True, cpu_ops.ACT_ELU)
+    M.sum().backward()                                   # untouched: fine
+    M = model.node_level([x, x], graphs, 0.0, 0.0, True, cpu_ops.ACT_ELU)
+    M[:, 0, :].mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        M.sum().backward()

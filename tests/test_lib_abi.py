@@ -40,3 +40,23 @@ def test_library_loads_and_exports_every_symbol():
 def test_code_object_is_gfx950():
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"gfx950" in blob
+
+
+def test_row_split_struct_layout_matches_the_header(tmp_path):
+    """han_row_split_t (ABI 6: + the degree bins) as plain C sees it == the ctypes mirror, field by field."""
+    import subprocess
+    fields = [f for f, _ in _lib.HanRowSplit._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "han_hip.h"\nint main(void) {\n'
+                   '  printf("%zu\\n", sizeof(han_row_split_t));\n'
+                   + "".join(f'  printf("%zu\\n", offsetof(han_row_split_t, {f}));\n' for f in fields)
+                   + '  printf("%d %d\\n", HAN_ABI_VERSION, HAN_SHORT_DEG);\n  return 0;\n}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == ctypes.sizeof(_lib.HanRowSplit)
+    for f, off in zip(fields, out[1:]):
+        assert int(off) == getattr(_lib.HanRowSplit, f).offset, f
+    assert int(out[-2]) == _lib.ABI_VERSION
+    from han_amd import ops
+    assert int(out[-1]) == ops.SHORT_DEG
