@@ -311,7 +311,7 @@ def hbm_regime_probe(dev, n, table_dtype, steps, warmup=2, deg=50):
 
 def skew_variant(dev, args, tdt, esz, warmup=2):
     """SURVEY.md 8d's second line: the same model on the power-law variant of the workload (alpha = 2.1, the same
-    N, E, F, P; rows far longer than 8192 edges are cut into chunks) -- graph generation + `warmup` + --skew-steps
+    N, E, F, P; rows longer than 1024 edges are cut into chunks) -- graph generation + `warmup` + --skew-steps
     epochs in this process, after the headline's timed region.  Hub rows stay in the L2s, so a K2 rate above the
     HBM peak is labelled a cache rate (k2_rooflines)."""
     from han_amd import ops, rng, synth

@@ -817,35 +817,67 @@ __global__ __launch_bounds__(256) void node_attn_fwd_chunk_kernel(const FwdArgs 
     }
 }
 
-// Split rows, step 2: one 16-lane group per long row merges its chunks in order.
+// Split rows, step 2: one BLOCK per long row merges its chunks.  (Rounds 1-3: one 16-lane group per row walked the
+// row's chunks one after the other -- a chain of dependent loads: 100 us for the 245 chunks of a 10^6-edge row, 0.8 ms
+// once rows are cut at 1024 entries, profiles/r04_k2_skew_split_sweep.jsonl.)  The 16 groups of the block take the
+// chunks c = first + grp, + 16, ... (their loads do not depend on the running state, four are in flight), then group 0
+// merges the 16 partial states in group order: a fixed order, bitwise reproducible.
 template <int FP, bool TRAIN>
 __global__ __launch_bounds__(256) void node_attn_fwd_finish_kernel(const FwdArgs a) {
     constexpr int K = HAN_D / FP;
-    const int q = threadIdx.x & 15;
+    __shared__ float part[16][16][12];      // [group][lane q]: acc 4 | accp 4 | m | l | tl
+    const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int head = (4 * q) / FP;
-    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t r = blockIdx.x;
     if (r >= a.n_long) return;
     const float4_t c4 = *reinterpret_cast<const float4_t *>(a.c + 4 * q);
     RowState<TRAIN> st;
     st.init();
-    for (int64_t ch = a.long_ptr[r]; ch < a.long_ptr[r + 1]; ++ch) {
-        const float *w = a.split_ws + ch * kFwdChunkStride;
-        const float4_t v = *reinterpret_cast<const float4_t *>(w + 4 * q);
-        const float m_o = w[128 + head], l_o = w[128 + K + head];
+    auto fold = [&](const float4_t &v, const float4_t &vp, const float m_o, const float l_o, const float tl_o) {
         const float M = fmaxf(st.m, m_o);
         const float sa = __expf(st.m - M), sb = __expf(m_o - M);
         st.l = st.l * sa + l_o * sb;
 #pragma unroll
         for (int t = 0; t < 4; ++t) st.acc[t] = st.acc[t] * sa + v[t] * sb;
         if (TRAIN) {
-            const float4_t vp = *reinterpret_cast<const float4_t *>(w + 64 + 4 * q);
-            st.tl = st.tl * sa + w[128 + 2 * K + head] * sb;
+            st.tl = st.tl * sa + tl_o * sb;
 #pragma unroll
             for (int t = 0; t < 4; ++t) st.accp[t] = st.accp[t] * sa + vp[t] * sb;
         }
         st.m = M;
+    };
+    const int64_t c_end = a.long_ptr[r + 1];
+    for (int64_t ch = a.long_ptr[r] + grp; ch < c_end; ch += 64) {
+        float4_t v[4], vp[4];
+        float mo[4], lo[4], to[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {        // four chunk states in flight
+            const bool ok = ch + 16 * u < c_end;
+            const float *w = a.split_ws + (ok ? ch + 16 * u : ch) * kFwdChunkStride;
+            v[u] = *reinterpret_cast<const float4_t *>(w + 4 * q);
+            vp[u] = TRAIN ? *reinterpret_cast<const float4_t *>(w + 64 + 4 * q) : v[u];
+            mo[u] = ok ? w[128 + head] : HAN_NEG_BIG;
+            lo[u] = ok ? w[128 + K + head] : 0.f;
+            to[u] = (TRAIN && ok) ? w[128 + 2 * K + head] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ch + 16 * u < c_end) fold(v[u], vp[u], mo[u], lo[u], to[u]);      // uniform per 16-lane group
     }
-    write_row<FP, TRAIN>(a, a.long_rows[r], st, q, head, c4, true);
+    float *pp = part[grp][q];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { pp[t] = st.acc[t]; pp[4 + t] = TRAIN ? st.accp[t] : 0.f; }
+    pp[8] = st.m; pp[9] = st.l; pp[10] = TRAIN ? st.tl : 0.f;
+    __syncthreads();
+    if (grp == 0) {
+        st.init();
+        for (int g = 0; g < 16; ++g) {
+            const float *o = part[g][q];
+            const float4_t v = {o[0], o[1], o[2], o[3]}, vp = {o[4], o[5], o[6], o[7]};
+            fold(v, vp, o[8], o[9], o[10]);
+        }
+        write_row<FP, TRAIN>(a, a.long_rows[r], st, q, head, c4, true);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1375,26 +1407,54 @@ __global__ __launch_bounds__(256) void node_attn_bwd_chunk_kernel(const BwdColsA
     }
 }
 
+// one BLOCK per long source row: the 16 groups sum the chunks c = first + grp, + 16, ... (four loads in flight), group 0
+// adds the 16 partial sums in group order (fixed order: bitwise reproducible) -- see node_attn_fwd_finish_kernel
 template <int FP, bool BF>
 __global__ __launch_bounds__(256) void node_attn_bwd_finish_kernel(const BwdColsArgs a) {
-    const int q = threadIdx.x & 15;
+    __shared__ float part[16][16][5];
+    const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int head = (4 * q) / FP;
-    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t r = blockIdx.x;
     if (r >= a.n_long) return;
-    const float4_t a14 = *reinterpret_cast<const float4_t *>(a.a1 + 4 * q);
-    const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
-    const int64_t src = a.long_rows[r];
-    const SrcRow sr = load_src<FP, BF>(a, src, q, head);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     float dfacc = 0.f;
-    for (int64_t ch = a.long_ptr[r]; ch < a.long_ptr[r + 1]; ++ch) {
-        const float *w = a.split_ws + ch * kBwdChunkStride;
-        const float4_t v = *reinterpret_cast<const float4_t *>(w + 4 * q);
+    const int64_t c_end = a.long_ptr[r + 1];
+    for (int64_t ch = a.long_ptr[r] + grp; ch < c_end; ch += 64) {
+        float4_t v[4];
+        float d[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] += v[t];
-        dfacc += w[64 + head];
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = ch + 16 * u < c_end;
+            const float *w = a.split_ws + (ok ? ch + 16 * u : ch) * kBwdChunkStride;
+            v[u] = *reinterpret_cast<const float4_t *>(w + 4 * q);
+            d[u] = w[64 + head];
+            if (!ok) { v[u] = (float4_t){0.f, 0.f, 0.f, 0.f}; d[u] = 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += v[u][t];
+            dfacc += d[u];
+        }
     }
-    write_src<FP>(a, src, sr, acc, dfacc, q, head, a14, a24);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) part[grp][q][t] = acc[t];
+    part[grp][q][4] = dfacc;
+    __syncthreads();
+    if (grp == 0) {
+        const float4_t a14 = *reinterpret_cast<const float4_t *>(a.a1 + 4 * q);
+        const float4_t a24 = *reinterpret_cast<const float4_t *>(a.a2 + 4 * q);
+        const int64_t src = a.long_rows[r];
+        const SrcRow sr = load_src<FP, BF>(a, src, q, head);
+        float tot[4] = {0.f, 0.f, 0.f, 0.f};
+        float dtot = 0.f;
+        for (int g = 0; g < 16; ++g) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) tot[t] += part[g][q][t];
+            dtot += part[g][q][4];
+        }
+        write_src<FP>(a, src, sr, tot, dtot, q, head, a14, a24);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1624,7 +1684,7 @@ static void launch_fwd_v(const FwdArgs &a_in, bool train, bool low, bool has_spl
     }
     if (has_split) {
         const int cgrid = attn_grid(a.n_chunks);
-        const int fgrid = (int)((a.n_long + 15) / 16);
+        const int fgrid = (int)a.n_long;      // one block per long row
         if (train) {
             node_attn_fwd_chunk_kernel<FPC, true, 4, BF, VAL><<<cgrid, 256, 0, st>>>(a);
             node_attn_fwd_finish_kernel<FPC, true><<<fgrid, 256, 0, st>>>(a);
@@ -1670,7 +1730,7 @@ static void launch_bwd_cols_v(const BwdColsArgs &a_in, bool low, bool has_split,
     }
     if (has_split) {
         node_attn_bwd_chunk_kernel<FPC, 4, BF, VAL><<<attn_grid(a.n_chunks), 256, 0, st>>>(a);
-        node_attn_bwd_finish_kernel<FPC, BF><<<(int)((a.n_long + 15) / 16), 256, 0, st>>>(a);
+        node_attn_bwd_finish_kernel<FPC, BF><<<(int)a.n_long, 256, 0, st>>>(a);
     }
 }
 

@@ -121,8 +121,11 @@ def _dtype_code(t: torch.Tensor, name: str) -> int:
     return DTYPE_CODE[t.dtype]
 
 
-SPLIT_DEG = 8192       # rows longer than this are split into chunks of SPLIT_CHUNK edges
-SPLIT_CHUNK = 4096
+# rows longer than SPLIT_DEG are cut into chunks of SPLIT_CHUNK edges, a wave per chunk (round 4: 1024 / 512, from 8192 /
+# 4096 -- a wave walking an 8192-entry row alone was the tail of the whole launch on power-law graphs; the finishing
+# launch now merges a row's chunks with a block instead of one lane group: profiles/r04_k2_skew_split_sweep.jsonl)
+SPLIT_DEG = 1024
+SPLIT_CHUNK = 512
 
 
 SHORT_DEG = 16         # HAN_SHORT_DEG: rows below this many entries run four to a wave in a degree-binned launch
