@@ -103,7 +103,7 @@ int main(int argc, char **argv) {
                            N, F, K, FP, 0.f, 0.f, 0, nullptr, 0, /*keep*/ nullptr, /*flags*/ 0, st));
     HAN_OK(han_node_attn_fwd(drp, dci, nullptr, dH, HAN_DTYPE_F32, nullptr, df1, nullptr, da2, db2, dc, nullptr, dM, D,
                              nullptr, nullptr, nullptr, nullptr, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0,
-                             HAN_ACT_ELU, /*flags*/ 0, nullptr, st));
+                             HAN_ACT_ELU, /*flags*/ 0, /*split*/ nullptr, /*dense*/ nullptr, st));
     HAN_OK(han_sem_attn_fwd(dM, dwo, dbo, duo, dZ, dbeta, N, 1, D, A, /*flags*/ 0, st));
     HIP_OK(hipStreamSynchronize(st));
 
@@ -155,11 +155,11 @@ int main(int argc, char **argv) {
     if (wb_pb) HIP_OK(hipMalloc(&ws_pb, wb_pb));
     HAN_OK(han_node_attn_fwd(drp, dci, nullptr, dH, HAN_DTYPE_F32, nullptr, df1, nullptr, da2, db2, dc, nullptr, dM, D,
                              nullptr, dlse, daggp, dtsum, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0,
-                             HAN_ACT_ELU, 0, nullptr, st));
+                             HAN_ACT_ELU, 0, nullptr, nullptr, st));
     HAN_OK(han_node_attn_bwd_rows(ddOut, D, dM, D, daggp, dtsum, df1, dlse, dc, nullptr, dgs, HAN_DTYPE_F32, ddf1,
                                   ddc, ws_rows, wb_rows, N, K, FP, HAN_ACT_ELU, st));
     HAN_OK(han_node_attn_bwd_cols(dcp, dri, nullptr, dgs, nullptr, dH, HAN_DTYPE_F32, df2, ddf1, da1, da2, ddH,
-                                  ddf2, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0, 0, 0, nullptr, st));
+                                  ddf2, N, N * DEG, K, FP, 0.2f, 0.f, 0.f, 0, nullptr, 0, 0, 0, /*split*/ nullptr, /*dense*/ nullptr, st));
     HAN_OK(han_score_param_bwd(dH, HAN_DTYPE_F32, ddf1, ddf2, dda1, dda2, ddb1, ddb2, ws_sp, wb_sp, N, K, FP, st));
     HAN_OK(han_project_bwd(dX, HAN_DTYPE_F32, F, ddH, ddW, ws_pb, wb_pb, N, F, K, FP, 0.f, 0, nullptr, 0, /*keep*/ nullptr, st));
     HIP_OK(hipStreamSynchronize(st));

@@ -15,6 +15,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhan_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ("node_attn.hip", "project.hip", "sem_attn.hip", "loss_opt.hip")
+# node_attn.hip: the dense K2 kernels (node_attn_dense.h) keep 8-16 fp32 MFMA accumulators in a rolled loop; with the
+# default AGPR form hipcc shuffles them through v_accvgpr_read / _mov / _write every iteration (each a wait for the
+# matrix pipe); the VGPR form of the MFMA destination has no such traffic
+EXTRA_FLAGS = {"node_attn.hip": ("-mllvm", "-amdgpu-mfma-vgpr-form")}
 
 P = c_void_p
 I64 = c_int64
@@ -27,6 +31,12 @@ class HanRowSplit(ctypes.Structure):
                 ("chunk_start", c_void_p), ("chunk_end", c_void_p), ("workspace", c_void_p),
                 ("workspace_bytes", c_size_t), ("n_short", c_int64), ("n_mid", c_int64),
                 ("short_rows", c_void_p), ("mid_rows", c_void_p)]
+
+
+class HanDense(ctypes.Structure):
+    """han_dense_t of include/han_hip.h."""
+    _fields_ = [("bits", c_void_p), ("ld_words", c_int64), ("n_table", c_int64), ("workspace", c_void_p),
+                ("workspace_bytes", c_size_t)]
 
 
 # name -> (restype, argtypes); mirrors include/han_hip.h one to one
@@ -46,7 +56,9 @@ SIGNATURES = {
     "han_project_bwd_input": (c_int, [P, P, P, I64, I64, c_int, c_int, c_int, c_float, c_uint64, P, I64, P]),
     "han_row_split_workspace": (c_size_t, [I64]),
     "han_node_attn_fwd": (c_int, [P, P, P, P, c_int, P, P, P, P, P, P, P, P, I64, P, P, P, P, I64, I64, c_int,
-                                  c_int, c_float, c_float, c_float, c_uint64, P, I64, c_int, c_int, P, P]),
+                                  c_int, c_float, c_float, c_float, c_uint64, P, I64, c_int, c_int, P, P, P]),
+    "han_node_attn_dense_workspace": (c_size_t, [I64, I64, c_int]),
+    "han_csr_to_bitmask": (c_int, [P, P, I64, I64, P, I64, P, P]),
     "han_node_attn_coefs": (c_int, [P, P, P, P, P, P, P, c_int, I64, I64, c_int, c_int, c_float, c_float,
                                     c_uint64, P, I64, P]),
     "han_node_attn_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
@@ -54,7 +66,7 @@ SIGNATURES = {
     "han_node_attn_bwd_rows": (c_int, [P, I64, P, I64, P, P, P, P, P, P, P, c_int, P, P, P, c_size_t, I64,
                                        c_int, c_int, c_int, P]),
     "han_node_attn_bwd_cols": (c_int, [P, P, P, P, P, P, c_int, P, P, P, P, P, P, I64, I64, c_int, c_int,
-                                       c_float, c_float, c_float, c_uint64, P, I64, I64, c_int, P, P]),
+                                       c_float, c_float, c_float, c_uint64, P, I64, I64, c_int, P, P, P]),
     "han_score_param_bwd_workspace": (c_size_t, [I64, c_int, c_int]),
     "han_score_param_bwd": (c_int, [P, c_int, P, P, P, P, P, P, P, c_size_t, I64, c_int, c_int, P]),
     "han_sem_attn_fwd": (c_int, [P, P, P, P, P, P, I64, c_int, c_int, c_int, c_int, P]),
@@ -84,7 +96,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into ``han_amd/libhan_hip.so``: one object per source
     (compiled in parallel, re-compiled only when the source or a header changed), then one link."""
     from concurrent.futures import ThreadPoolExecutor
-    hdrs = [os.path.join(CSRC, "han_common.h"), os.path.join(_HERE, "..", "include", "han_hip.h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(_HERE, "..", "include", "han_hip.h")]
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -93,7 +106,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
-            jobs.append(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj])
+            jobs.append(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + list(EXTRA_FLAGS.get(s, ())) +
+                        ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

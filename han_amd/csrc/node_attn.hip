@@ -82,6 +82,7 @@ struct FwdArgs {
     // `rows` (null: the rows 0 .. n_work-1 themselves)
     const int32_t *rows;
     int64_t n_work;
+    const int *only_if;      // lean kernels behind the dense path: run only when this device word is non-zero (null: always)
     float slope;
     uint32_t seed_lo, seed_hi, thr_coef;
     const uint64_t *seed_dev;
@@ -520,6 +521,7 @@ __device__ __forceinline__ void lean_fwd_step(const FwdArgs &a, const float *til
 // steps of 16 edges, ids one piece ahead; whole rows of any length, any id order.
 template <int FP, bool TRAIN, bool VAL>
 __global__ __launch_bounds__(256) void node_attn_fwd_lean_kernel(const FwdArgs a_in) {
+    if (a_in.only_if && *a_in.only_if == 0) return;      // the dense path did the work
     FwdArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     constexpr int K = HAN_D / FP;
@@ -600,6 +602,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_lean_kernel(const FwdArgs a
 // ---------------------------------------------------------------------------------------------
 template <bool TRAIN, bool VAL>
 __global__ __launch_bounds__(256) void node_attn_fwd_h8_kernel(const FwdArgs a_in) {
+    if (a_in.only_if && *a_in.only_if == 0) return;      // the dense path did the work
     FwdArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     __shared__ __attribute__((aligned(16))) int colw_all[4 * 64];
@@ -989,6 +992,7 @@ struct BwdColsArgs {
     int xcd_order;
     int masked;          // HAN_FLAG_MASKED_EDGES
     int lean;            // HAN_FLAG_LEAN
+    const int *only_if;  // lean kernel behind the dense path: run only when this device word is non-zero (null: always)
     int64_t split_deg;
     int64_t n_long, n_chunks;
     const int64_t *long_rows, *long_ptr, *chunk_start, *chunk_end;
@@ -1231,6 +1235,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_kernel(const BwdColsAr
 // ---------------------------------------------------------------------------------------------
 template <bool VAL>
 __global__ __launch_bounds__(256) void node_attn_bwd_cols_h8_kernel(const BwdColsArgs a_in) {
+    if (a_in.only_if && *a_in.only_if == 0) return;      // the dense path did the work
     BwdColsArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     constexpr int RB = GsRow<8, false>::bytes;
@@ -1587,6 +1592,59 @@ __global__ __launch_bounds__(256) void node_attn_coef_kernel(const CoefArgs a_in
     }
 }
 
+#include "node_attn_dense.h"
+
+// segments of the column tiles so that a launch has ~1024 blocks (4 per CU, one wave of each per SIMD; measured at the
+// DBLP APTPA shape: 256 / 768 / 1024 blocks = 82 / 64 / 62 us for the eval launch)
+static void dense_split(int64_t rows, int64_t n_table, int *S, int *tps, int *tiles) {
+    const int64_t bx = (rows + kDenseRowsPerBlock - 1) / kDenseRowsPerBlock;
+    const int t = (int)((n_table + kDenseTile - 1) / kDenseTile);
+    int64_t want = (1024 + bx - 1) / (bx > 0 ? bx : 1);
+    if (want < 1) want = 1;
+    if (want > t) want = t > 0 ? t : 1;
+    *tps = (int)((t + want - 1) / want);
+    if (*tps < 1) *tps = 1;
+    *S = (t + *tps - 1) / *tps;
+    if (*S < 1) *S = 1;
+    *tiles = t;
+}
+
+static size_t dense_workspace_bytes(int64_t rows, int64_t n_table, int row_width) {
+    int S, tps, tiles;
+    dense_split(rows, n_table, &S, &tps, &tiles);
+    return (size_t)kDenseHdrFloats * sizeof(float) + (size_t)S * (size_t)rows * (size_t)row_width * sizeof(float);
+}
+
+static bool dense_geometry(int64_t rows, int64_t n_table, bool train, const han_dense_t *dn, DenseArgs *d) {
+    const int rw = train ? DenseRowWidth<true>::value : DenseRowWidth<false>::value;
+    if (!dn->workspace || dn->workspace_bytes < dense_workspace_bytes(rows, n_table, rw) || n_table <= 0 ||
+
+        dn->ld_words < (n_table + 31) / 32 || ((uintptr_t)dn->workspace & 15))
+        return false;
+    dense_split(rows, n_table, &d->S, &d->tiles_per_seg, &d->tiles);
+    d->bits = dn->bits; d->ldw = dn->ld_words; d->NT = n_table;
+    d->hdr = (float *)dn->workspace;
+    d->slab = (float *)dn->workspace + kDenseHdrFloats;
+    return true;
+}
+
+// CSR -> adjacency bit mask (rows must be zero-filled by the caller's memset in front of it); a bit that is already
+// set is a repeated entry: counted, because the bit-mask form cannot hold a multigraph term
+__global__ __launch_bounds__(256) void csr_to_bitmask_kernel(const int64_t *rowptr, const int32_t *colidx, int64_t N,
+                                                             uint32_t *bits, int64_t ldw, int *dups) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave0; row < N; row += nwaves) {
+        const int64_t e = rowptr[row + 1];
+        for (int64_t p = rowptr[row] + lane; p < e; p += 64) {
+            const int c = colidx[p];
+            const uint32_t bit = 1u << (c & 31);
+            const uint32_t old = atomicOr(bits + row * ldw + (c >> 5), bit);
+            if ((old & bit) && dups) atomicAdd(dups, 1);
+        }
+    }
+}
+
 constexpr int kReduceBlocks = 1024;
 
 bool fp_supported(int K, int FP) {
@@ -1714,8 +1772,11 @@ static void launch_bwd_cols_v(const BwdColsArgs &a_in, bool low, bool has_split,
     a.rows = nullptr; a.n_work = a.NS;
     if (a.lean && !a.masked && !low && !BF && FPC == 8 && !a.gid) {      // small graphs, 8 x 8: one lane per head
         node_attn_bwd_cols_h8_kernel<VAL><<<attn_grid(a.NS), 256, 0, st>>>(a);
+        return;      // whole rows of any length: no chunk / finish launches behind it
     } else if (a.lean && !a.masked && !low && !BF) {      // small graphs (HAN_FLAG_LEAN): VALU-bound, one hash per (edge, four heads)
+        a.split_deg = INT64_MAX;
         node_attn_bwd_cols_kernel<FPC, 1, 4, false, VAL, false, false, true><<<attn_grid(a.NS), 256, 0, st>>>(a);
+        return;
     } else if (bins.binned) {
         if (bins.n_short > 0) {
             a.rows = bins.short_rows; a.n_work = bins.n_short;
@@ -1769,7 +1830,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
                                  float *aggp, float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
                                  float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev,
                                  int64_t row_offset, int activation, int flags, const han_row_split_t *split,
-                                 void *stream) {
+                                 const han_dense_t *dense, void *stream) {
     if (N == 0) return 0;   // nothing to do; row pointers of empty tensors may be null
     if (!rowptr || (!colidx && E > 0) || !H || !f1 || !a2 || !b2 || !c || !out || N < 0 || E < 0 || out_stride < HAN_D)
         return HAN_E_BADARG;
@@ -1784,7 +1845,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     FwdArgs a;
     a.rowptr = rowptr; a.colidx = colidx; a.edge_val = edge_val; a.H = H; a.gid = table_gid; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.f2g = f2_src; a.a2 = a2; a.b2 = b2; a.c = c; a.res = res;
     a.out = out; a.out_stride = out_stride; a.pre = pre; a.lse = lse; a.aggp = aggp; a.tsum = tsum;
-    a.N = N; a.rows = nullptr; a.n_work = N; a.slope = slope;
+    a.N = N; a.rows = nullptr; a.n_work = N; a.only_if = nullptr; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);
@@ -1802,6 +1863,26 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     a.split_ws = has_split ? (float *)split->workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool low = (double)E < kLowDegree * (double)N;
+    if (dense && dense->bits) {
+        // small dense graph on the matrix pipe (node_attn_dense.h); the lean CSR kernel behind it runs only when the
+        // scores' range is too wide for the fixed-shift form (a device-side flag: no host round trip)
+        if (!(flags & HAN_FLAG_LEAN) || table_dtype != HAN_DTYPE_F32 || table_gid || !f2_src || edge_val || K != 8 || FP != 8)
+            return HAN_E_BADARG;
+        DenseArgs d;
+        if (!dense_geometry(N, dense->n_table, train, dense, &d)) return HAN_E_WORKSPACE;
+        dense_f2_range_kernel<<<1, 1024, 0, st>>>(f2_src, d.NT, d.hdr);
+        const dim3 dg((unsigned)((N + kDenseRowsPerBlock - 1) / kDenseRowsPerBlock), (unsigned)d.S);
+        const int fg = (int)((N + 15) / 16);
+        if (train) {
+            node_attn_fwd_dense_kernel<true><<<dg, 256, 0, st>>>(a, d);
+            node_attn_fwd_dense_finish_kernel<true><<<fg, 256, 0, st>>>(a, d);
+        } else {
+            node_attn_fwd_dense_kernel<false><<<dg, 256, 0, st>>>(a, d);
+            node_attn_fwd_dense_finish_kernel<false><<<fg, 256, 0, st>>>(a, d);
+        }
+        HAN_CHECK_LAUNCH();
+        a.only_if = reinterpret_cast<const int *>(d.hdr) + 16;
+    }
     if ((flags & HAN_FLAG_LEAN) && table_dtype == HAN_DTYPE_F32 && !table_gid && f2_src) {
         // small graph, table in the L2s: scores gathered, one hash per (edge, four heads); whole rows (no row split)
         if (edge_val) { HAN_DISPATCH_FP(FP, { launch_fwd_lean_v<FPC, true>(a, train, st); }) }
@@ -1869,7 +1950,7 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
                                       float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                                       float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev,
                                       int64_t src_offset, int64_t dst_offset, int flags,
-                                      const han_row_split_t *split, void *stream) {
+                                      const han_row_split_t *split, const han_dense_t *dense, void *stream) {
     if (!colptr || (!rowidx && E > 0) || !gs || !H || !f2 || !df1 || !a1 || !a2 || !dH || !df2 || NS < 0 || E < 0)
         return HAN_E_BADARG;
     if (!split_ok(split, NS)) return HAN_E_BADARG;
@@ -1886,6 +1967,7 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
     a.src_offset = src_offset; a.dst_offset = dst_offset; a.xcd_order = (flags & HAN_FLAG_XCD_ORDER) ? 1 : 0;
     a.masked = (flags & HAN_FLAG_MASKED_EDGES) ? 1 : 0;
     a.lean = (flags & HAN_FLAG_LEAN) ? 1 : 0;
+    a.only_if = nullptr;
     const bool has_split = split && split->n_long > 0;
     a.split_deg = has_split ? split->split_deg : INT64_MAX;
     a.n_long = has_split ? split->n_long : 0;
@@ -1898,6 +1980,20 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
     a.split_ws = has_split ? (float *)split->workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool low = (double)E < kLowDegree * (double)NS;
+    if (dense && dense->bits) {
+        // small dense graph: the transposed bit mask on the matrix pipe (node_attn_dense.h), the lean CSR kernel behind it
+        // predicated on the range flag
+        if (!a.lean || a.masked || low || table_dtype != HAN_DTYPE_F32 || table_gid || edge_val || K != 8 || FP != 8)
+            return HAN_E_BADARG;
+        DenseArgs d;
+        if (!dense_geometry(NS, dense->n_table, false, dense, &d)) return HAN_E_WORKSPACE;
+        dense_f2_range_kernel<<<1, 1024, 0, st>>>(f2, NS, d.hdr);
+        const dim3 dg((unsigned)((NS + kDenseRowsPerBlock - 1) / kDenseRowsPerBlock), (unsigned)d.S);
+        node_attn_bwd_dense_kernel<<<dg, 256, 0, st>>>(a, d);
+        node_attn_bwd_dense_finish_kernel<<<(int)((NS + 15) / 16), 256, 0, st>>>(a, d);
+        HAN_CHECK_LAUNCH();
+        a.only_if = reinterpret_cast<const int *>(d.hdr) + 16;
+    }
     const RowBins bins = bins_of(split);
     if (table_dtype == HAN_DTYPE_BF16) {
         HAN_DISPATCH_FP(FP, { launch_bwd_cols<FPC, true>(a, low, has_split, bins, st); })
@@ -1959,6 +2055,27 @@ extern "C" int han_node_attn_coefs(const int64_t *rowptr, const int32_t *colidx,
     const int grid = attn_grid(N);
     hipStream_t st = (hipStream_t)stream;
     HAN_DISPATCH_FP(FP, { node_attn_coef_kernel<HAN_D / FPC><<<grid, 256, 0, st>>>(a); })
+    HAN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t han_node_attn_dense_workspace(int64_t rows, int64_t n_table, int train) {
+    if (rows <= 0 || n_table <= 0) return 0;
+    return dense_workspace_bytes(rows, n_table, train ? DenseRowWidth<true>::value : DenseRowWidth<false>::value);
+}
+
+extern "C" int han_csr_to_bitmask(const int64_t *rowptr, const int32_t *colidx, int64_t N, int64_t n_table,
+                                  uint32_t *bits, int64_t ld_words, int *repeated, void *stream) {
+    if (!rowptr || !bits || N < 0 || n_table <= 0 || ld_words < (n_table + 31) / 32) return HAN_E_BADARG;
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(bits, 0, (size_t)N * (size_t)ld_words * sizeof(uint32_t), st);
+    if (e != hipSuccess) return (int)e;
+    if (repeated) {
+        e = hipMemsetAsync(repeated, 0, sizeof(int), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    csr_to_bitmask_kernel<<<attn_grid(N), 256, 0, st>>>(rowptr, colidx, N, bits, ld_words, repeated);
     HAN_CHECK_LAUNCH();
     return 0;
 }

@@ -165,6 +165,24 @@ class CSRGraph:
             self._split[key] = dict(n_short=n_short, short_rows=short_rows, n_mid=n_mid, mid_rows=mid_rows)
         return self._split[key]
 
+    def bitmask(self):
+        """Adjacency bit mask for the dense (matrix-pipe) K2 path: (n_rows, ceil(n_cols / 32)) int32 on the device, bit
+        (j & 31) of word (j >> 5) of row i set iff the graph stores (i, j) -- or None when the graph holds repeated
+        entries (a multigraph term has no bit-mask form) or lives on the host.  Built once by han_csr_to_bitmask, cached."""
+        if "bitmask" not in self._split:
+            bm = None
+            if self.rowptr.is_cuda and self.n_rows > 0 and self.n_cols > 0 and not self.masked:
+                lib = _lib.load()
+                ldw = (self.n_cols + 31) // 32
+                bits = torch.empty((self.n_rows, ldw), dtype=torch.int32, device=self.device)
+                rep = torch.zeros(1, dtype=torch.int32, device=self.device)
+                _lib.check(lib.han_csr_to_bitmask(self.rowptr.data_ptr(), self.colidx.data_ptr(), self.n_rows, self.n_cols,
+                                                  bits.data_ptr(), ldw, rep.data_ptr(), _stream()), "han_csr_to_bitmask")
+                if int(rep.item()) == 0:
+                    bm = bits
+            self._split["bitmask"] = bm
+        return self._split["bitmask"]
+
     # ---- transposition (CSC) ------------------------------------------------
     def transpose(self) -> "CSRGraph":
         """The transposed graph: for every source j the destinations i, in

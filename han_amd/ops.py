@@ -132,11 +132,11 @@ SHORT_DEG = 16         # HAN_SHORT_DEG: rows below this many entries run four to
 BINNED = True          # tests / measurements: False = one row shape per launch, chosen from E / N (rounds 1-3)
 
 
-def _row_split_arg(graph: CSRGraph, tag: str, bins: bool = True):
+def _row_split_arg(graph: CSRGraph, tag: str, bins: bool = True, split: bool = True):
     """ctypes han_row_split_t for `graph`: its degree bins (short / mid row lists) and the chunks of its rows beyond
     SPLIT_DEG (None when the graph has neither: every row in one bin and no long row still passes the bin counts,
     so that the library uses that bin's row shape).  Returns (byref-able struct or None, keepalive tuple)."""
-    sp = graph.row_split(SPLIT_DEG, SPLIT_CHUNK)
+    sp = graph.row_split(SPLIT_DEG, SPLIT_CHUNK) if split else None      # (the lean kernels walk whole rows)
     rb = graph.row_bins(SHORT_DEG, SPLIT_DEG) if (bins and BINNED and graph.n_rows > 0) else None
     if sp is None and rb is None:
         return None, None
@@ -165,6 +165,29 @@ def _use_lean(graph: CSRGraph, table) -> bool:
     degree >= 64), where the classic gather kernels are bound by vector-instruction issue, not by memory."""
     return (LEAN and table.dtype == torch.float32 and 0 < graph.n_cols <= 16384
             and graph.nnz >= 64 * graph.n_rows)
+
+
+DENSE = True               # tests / measurements: False keeps small dense graphs on the lean CSR kernels
+DENSE_MIN_DENSITY = 0.5    # stored entries / (rows x table rows) from which the matrix-pipe form wins (profiles/r04_k2_dense_vs_lean.jsonl)
+
+
+def _use_dense(graph: CSRGraph, table, K: int, FP: int) -> bool:
+    """The dense (bit mask + fp32 MFMA) K2 path: a lean-eligible graph (_use_lean) of the reference shape whose rows
+    are dense enough that computing every (i, j) pair beats walking the stored entries, binary, without repeated
+    entries."""
+    if not (DENSE and K == 8 and FP == 8 and graph.values is None and not graph.masked and _use_lean(graph, table)):
+        return False
+    if graph.nnz < DENSE_MIN_DENSITY * graph.n_rows * graph.n_cols:
+        return False
+    return graph.bitmask() is not None
+
+
+def _dense_arg(graph: CSRGraph, train: bool, tag: str):
+    """ctypes han_dense_t of `graph` (+ keepalive)."""
+    lib = _lib.load()
+    bits = graph.bitmask()
+    ws = _ws(lib.han_node_attn_dense_workspace(graph.n_rows, graph.n_cols, int(train)), graph.device, "dense" + tag)
+    return _lib.HanDense(bits.data_ptr(), bits.shape[1], graph.n_cols, ws.data_ptr(), ws.numel()), (bits, ws)
 
 
 def _check_heads(K: int, FP: int):
@@ -399,7 +422,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         tsum = torch.empty((N, K), dtype=torch.float32, device=dev)
         saved = (out, lse, aggp, tsum)
         ptrs = [None, lse.data_ptr(), aggp.data_ptr(), tsum.data_ptr()]
-    split, _keep = _row_split_arg(graph, "f", bins=not lean)
+    split, _keep = _row_split_arg(graph, "f", bins=not lean, split=not lean)
+    dense, _keep_d = _dense_arg(graph, train, "f") if (lean and f2_src is None and _use_dense(graph, H_tab, K, FP)) else (None, None)
     timing = K2_TIMING
     if timing is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -414,7 +438,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
         int(seed), _dev_word(seed_dev), int(row_offset), int(activation),
         (FLAG_XCD_ORDER if graph.has_locality() else 0) | (FLAG_LEAN if lean else 0),
-        ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_fwd")
+        ctypes.byref(split) if split is not None else None,
+        ctypes.byref(dense) if dense is not None else None, _stream()), "han_node_attn_fwd")
     if timing is not None:
         ev1.record()
         timing.append(("train" if train else "eval", ev0, ev1, N, graph.nnz))
@@ -524,7 +549,8 @@ def node_attn_bwd_cols(graph_t: CSRGraph, gs_tab, H, f2, df1, a1, a2, coef_drop=
     dH = torch.empty((NS, D), dtype=torch.float32, device=dev)
     df2 = torch.empty((NS, K), dtype=torch.float32, device=dev)
     lean_b = not graph_t.masked and _use_lean(graph_t, H)
-    split, _keep = _row_split_arg(graph_t, "b", bins=not lean_b)
+    split, _keep = _row_split_arg(graph_t, "b", bins=not lean_b, split=not lean_b)
+    dense, _keep_d = _dense_arg(graph_t, False, "b") if (lean_b and table_gid is None and _use_dense(graph_t, H, K, FP)) else (None, None)
     timing = K2_TIMING
     if timing is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -538,7 +564,8 @@ def node_attn_bwd_cols(graph_t: CSRGraph, gs_tab, H, f2, df1, a1, a2, coef_drop=
         int(seed), _dev_word(seed_dev), int(src_offset), int(dst_offset),
         (FLAG_XCD_ORDER if graph_t.has_locality() else 0) | (FLAG_MASKED_EDGES if graph_t.masked else 0)
         | (FLAG_LEAN if lean_b else 0),
-        ctypes.byref(split) if split is not None else None, _stream()), "han_node_attn_bwd_cols")
+        ctypes.byref(split) if split is not None else None,
+        ctypes.byref(dense) if dense is not None else None, _stream()), "han_node_attn_bwd_cols")
     if timing is not None:
         ev1.record()
         timing.append(("bwd_cols", ev0, ev1, NS, graph_t.nnz))

@@ -186,6 +186,28 @@ typedef struct han_row_split {
 } han_row_split_t;
 size_t han_row_split_workspace(int64_t n_chunks);
 
+/* Small dense graphs on the matrix pipe (round 4; optional, pass NULL for none).  The reference computes its heads
+ * densely -- N x N logits, an additive mask, matmul(coefs, seq_fts): utils/layers.py:26-34 -- and its own data sets ARE
+ * dense (ACM PSP 24 % of all pairs, DBLP APCPA / APTPA 30 % / 78 %).  With a han_dense_t the forward / the transposed-
+ * graph backward run as 16 x 16 x 4 fp32 MFMA tiles over an adjacency BIT MASK, with the exponential taken out of the
+ * inner loop (exp(LeakyReLU(x)) = max(e^x, e^0.2x): per-node factors).  Built for 8 heads x 8 columns, fp32 tables,
+ * table_gid NULL, edge_val NULL, graphs without repeated entries (han_csr_to_bitmask counts them), HAN_FLAG_LEAN set and
+ * f2_src given: when the per-head range of the scores exceeds 80 (checked on the device) the lean CSR kernel runs
+ * instead, in the same call.  bits: [rows][ld_words] 32-bit words, bit (j & 31) of word (j >> 5) of row i set iff the
+ * graph stores the entry (i, j); n_table = rows of the table the columns index.                                        */
+typedef struct han_dense {
+    const uint32_t *bits;
+    int64_t ld_words;             /* >= ceil(n_table / 32) */
+    int64_t n_table;
+    void *workspace;              /* 16-byte aligned */
+    size_t workspace_bytes;       /* >= han_node_attn_dense_workspace(rows, n_table, train) */
+} han_dense_t;
+size_t han_node_attn_dense_workspace(int64_t rows, int64_t n_table, int train);
+/* CSR -> bit mask.  *repeated (device int, or NULL) receives the number of entries that were already present.
+ * Launches a memset of bits (and of *repeated) and one kernel on `stream`.                                     */
+int han_csr_to_bitmask(const int64_t *rowptr, const int32_t *colidx, int64_t N, int64_t n_table,
+                       uint32_t *bits, int64_t ld_words, int *repeated, void *stream);
+
 /* ---- K2: node-level attention ---------------------------------------------
  * utils/layers.py:26-35,46 (dense mask form) == :95-118,127 (sparse form) over
  * the stored neighbours only:
@@ -221,7 +243,7 @@ int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, const float 
                       float *out, int64_t out_stride, float *pre, float *lse, float *aggp,
                       float *tsum, int64_t N, int64_t E, int K, int FP, float slope,
                       float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev, int64_t row_offset,
-                      int activation, int flags, const han_row_split_t *split, void *stream);
+                      int activation, int flags, const han_row_split_t *split, const han_dense_t *dense, void *stream);
 
 /* The attention coefficients themselves (attn_head(..., return_coef=True),
  * utils/layers.py:27-30,43-44; models/gat.py:143-172 averages them over the heads):
@@ -276,7 +298,7 @@ int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowidx, const f
                            float *dH, float *df2, int64_t NS, int64_t E, int K, int FP, float slope,
                            float coef_drop, float fts_drop, uint64_t seed, const uint64_t *seed_dev,
                            int64_t src_offset, int64_t dst_offset, int flags,
-                           const han_row_split_t *split, void *stream);
+                           const han_row_split_t *split, const han_dense_t *dense, void *stream);
 
 /* Backward, step 3: gradients of the score parameters
  *   da1[k,f] = sum_n df1[n,k] H[n,k,f]   da2 likewise with df2

@@ -857,25 +857,34 @@ def test_sp_attn_head_weighted_adjacency_values(dev, drop, monkeypatch):
 
 @pytest.mark.parametrize("K,FP", [(8, 8), (16, 4), (4, 16), (2, 32), (1, 64)])
 @pytest.mark.parametrize("drop", [0.0, 0.6])
-def test_lean_kernels_on_small_dense_graphs_match_oracle(dev, K, FP, drop, monkeypatch):
+@pytest.mark.parametrize("dense", [False, True])
+def test_lean_kernels_on_small_dense_graphs_match_oracle(dev, K, FP, drop, dense, monkeypatch):
     """HAN_FLAG_LEAN: small graphs with long rows (the reference's own data sets) run K2 on the lean kernels -- scores
     read from the K1 table, softmax in log2 units, one attention-dropout hash per (edge, four heads) handed out by
     ds_bpermute, and for 8 x 8 one lane per head (forward and backward gather).  n = 600, rows of several 64-entry
     pieces with partial last steps; every head shape; inference and loss + all gradients with both dropouts on the
     oracle's exact masks; and the same numbers (to the order of the sums) as the gather kernels."""
     from han_amd import ops, rng as hrng
+    if dense and (K, FP) != (8, 8):
+        pytest.skip("the matrix-pipe (bit mask) form is built for the reference shape, 8 heads x 8")
+    # dense=True: the same graphs through node_attn_dense.h (bit mask + fp32 MFMA tiles, exp-free scores) -- forward,
+    # training forward and the transposed-graph backward; dense=False keeps them on the lean CSR kernels
+    monkeypatch.setattr(ops, "DENSE", dense)
+    monkeypatch.setattr(ops, "DENSE_MIN_DENSITY", 0.1)      # both graphs (80 % and 25 % dense) through the dense form
     n, f, p = 600, 13, 2
     prob = make_problem(300 + K, n, f, p, 3, [0.8, 0.25], hid_units=[FP], n_heads=(K, 1))
     model, bp = build_model(prob, dev)
     x, graphs = gpu_inputs(prob, dev)
-    calls = []
-    real = ops._use_lean
+    calls, dcalls = [], []
+    real, real_d = ops._use_lean, ops._use_dense
     monkeypatch.setattr(ops, "_use_lean", lambda g, t: calls.append(real(g, t)) or calls[-1])
+    monkeypatch.setattr(ops, "_use_dense", lambda g, t, k_, fp_: dcalls.append(real_d(g, t, k_, fp_)) or dcalls[-1])
     lg, fe, att = ho.hetegat_multi_inference([prob["x"]] * p, 3, n, False, 0.0, 0.0, prob["biases"], [FP], [K, 1],
                                              prob["params"])
     with torch.no_grad():
         logits, final_embed, att_val = model.inference([x] * p, 3, n, False, 0.0, 0.0, graphs, [FP], [K, 1])
     assert calls and all(calls)                       # both meta-paths took the lean kernels
+    assert dcalls and all(d_ == dense for d_ in dcalls)     # ... or, with dense, the matrix-pipe form
     assert np.abs(logits[0].cpu().numpy() - lg[0]).max() < TOL
     assert np.abs(final_embed.cpu().numpy() - fe).max() < TOL
     monkeypatch.setattr(ops, "LEAN", False)
@@ -891,8 +900,10 @@ def test_lean_kernels_on_small_dense_graphs_match_oracle(dev, K, FP, drop, monke
         keep = rng_ref.keep_prob32(drop)
         masks = [group_masks(seeds[q], n, f, K, FP, *ho.bias_to_csr(prob["biases"][q]), drop) for q in range(p)]
     loss_ref, gref, lg_ref = _oracle_grads(prob, bp, masks=masks, keep=keep, dense=False)
+    n_d = len(dcalls)
     loss, grads, lgg, _ = _gpu_loss_and_grads(model, prob, dev, attn_drop=drop, ffd_drop=drop)
     assert calls[-1]
+    assert len(dcalls) == n_d + 2 * p and all(d_ == dense for d_ in dcalls[n_d:])      # forward and backward of both meta-paths
     assert np.abs(lgg - lg_ref).max() < 5 * TOL
     assert abs(loss - loss_ref) < 5e-4
     for k in ht.PARAM_ORDER:
@@ -925,6 +936,7 @@ def test_lean_kernels_edge_values_and_ragged_rows(dev):
             for values in (None, vals):
                 g = CSRGraph(rowptr, colidx, n, values=values)
                 gt = g.transpose()
+                assert g.bitmask() is None and gt.bitmask() is None      # a repeated entry has no bit-mask form: CSR kernels
                 a1, a2 = (torch.randn((K, FP), device=dev, generator=gen) * 0.3 for _ in range(2))
                 b1, b2 = (torch.randn(K, device=dev, generator=gen) * 0.1 for _ in range(2))
                 c = torch.randn(64, device=dev, generator=gen) * 0.1
@@ -976,21 +988,67 @@ def test_lean_kernels_row_length_edges(dev):
         W = torch.randn((12, 64), device=dev, generator=gen) * 0.3
         dOut = torch.randn((n, 64), device=dev, generator=gen)
         H, f1, f2 = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.3, fts_drop=0.3, seed=21)
-        res = []
-        for lean in (True, False):
-            ops.LEAN = lean
+        res = {}
+        for mode in ("lean", "gather") + (("dense",) if (K, FP) == (8, 8) else ()):
+            ops.LEAN, ops.DENSE = mode != "gather", mode == "dense"
+            min_density, ops.DENSE_MIN_DENSITY = ops.DENSE_MIN_DENSITY, 0.0      # (the graph is ~35 % dense)
             try:
-                assert ops._use_lean(g, H) == lean and ops._use_lean(gt, H) == lean
+                assert ops._use_lean(g, H) == ops.LEAN and ops._use_lean(gt, H) == ops.LEAN
+                assert ops._use_dense(g, H, K, FP) == ops.DENSE and ops._use_dense(gt, H, K, FP) == ops.DENSE
                 oe, _ = ops.node_attn_fwd(g, H, f1, a2, b2, c, f2=f2)
+                oe = oe.clone()
                 ot, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, train=True, coef_drop=0.3, fts_drop=0.3, seed=21, f2=f2)
                 gs, df1, dc = ops.node_attn_bwd_rows(dOut, ot, sv[2], sv[3], f1, sv[1], c, K=K, FP=FP)
                 dH, df2 = ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, coef_drop=0.3, fts_drop=0.3, seed=21)
             finally:
-                ops.LEAN = True
-            res.append((oe, ot.clone()) + sv[1:] + (dH, df2))
-        for name, a_, b_ in zip(("eval", "train", "lse", "aggp", "tsum", "dH", "df2"), *res):
-            scale = float(b_.abs().max()) + 1.0
-            assert float((a_ - b_).abs().max()) < 5e-5 * scale, (K, FP, name)
+                ops.LEAN = ops.DENSE = True
+                ops.DENSE_MIN_DENSITY = min_density
+            res[mode] = (oe, ot.clone()) + sv[1:] + (dH, df2)
+        for mode in res:      # (the dense form: rows of 0 .. 256 entries in a 256-column table, i.e. empty to full mask rows)
+            for name, a_, b_ in zip(("eval", "train", "lse", "aggp", "tsum", "dH", "df2"), res[mode], res["gather"]):
+                scale = float(b_.abs().max()) + 1.0
+                assert float((a_ - b_).abs().max()) < 5e-5 * scale, (K, FP, mode, name)
+
+
+def test_dense_form_falls_back_on_the_device_when_the_scores_range_is_wide(dev):
+    """The matrix-pipe K2 form shifts every row by a FIXED bound (max f2 of the table), which is exact only while the
+    per-head range of f2 stays below 80; beyond that dense_f2_range_kernel leaves a flag in the header and the lean CSR
+    kernel behind it -- launched in the same call, predicated on that flag -- produces the result.  Scores scaled so
+    that the range is ~400: outputs, saved statistics and gradients equal the gather kernels'; the same inputs at a
+    normal scale take the dense kernels (different rounding, same tolerance)."""
+    from han_amd import ops, synth
+    n = 512
+    gen = torch.Generator(device=dev).manual_seed(3)
+    g = synth.bernoulli_graph(n, 0.5, 5, dev)
+    gt = g.transpose()
+    a1, b1, b2 = torch.randn((8, 8), device=dev, generator=gen) * 0.3, torch.zeros(8, device=dev), torch.zeros(8, device=dev)
+    c = torch.randn(64, device=dev, generator=gen) * 0.1
+    X = torch.randn((n, 16), device=dev, generator=gen)
+    W = torch.randn((16, 64), device=dev, generator=gen) * 0.3
+    dOut = torch.randn((n, 64), device=dev, generator=gen)
+    for scale in (0.3, 60.0):
+        a2 = torch.randn((8, 8), device=dev, generator=torch.Generator(device=dev).manual_seed(4)) * scale
+        H, f1, f2 = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.3, fts_drop=0.3, seed=8)
+        rng_ = float((f2.max(0).values - f2.min(0).values).max())
+        assert (rng_ > 200) == (scale > 1)
+        res = {}
+        for mode in ("gather", "dense"):
+            ops.LEAN, ops.DENSE = mode != "gather", mode == "dense"
+            min_density, ops.DENSE_MIN_DENSITY = ops.DENSE_MIN_DENSITY, 0.0
+            try:
+                assert ops._use_dense(g, H, 8, 8) == ops.DENSE
+                oe = ops.node_attn_fwd(g, H, f1, a2, b2, c, f2=f2)[0].clone()
+                ot, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, train=True, coef_drop=0.3, fts_drop=0.3, seed=8, f2=f2)
+                gs, df1, _ = ops.node_attn_bwd_rows(dOut, ot, sv[2], sv[3], f1, sv[1], c)
+                dH, df2 = ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, coef_drop=0.3, fts_drop=0.3, seed=8)
+            finally:
+                ops.LEAN = ops.DENSE = True
+                ops.DENSE_MIN_DENSITY = min_density
+            res[mode] = (oe, ot.clone()) + sv[1:] + (dH, df2)
+        for name, a_, b_ in zip(("eval", "train", "lse", "aggp", "tsum", "dH", "df2"), res["dense"], res["gather"]):
+            assert torch.isfinite(a_).all(), (scale, name)
+            sc = float(b_.abs().max()) + 1.0
+            assert float((a_ - b_).abs().max()) < 1e-4 * sc, (scale, name)
 
 
 def test_return_coef_and_hetegat_class(dev):
