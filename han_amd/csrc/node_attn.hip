@@ -83,6 +83,7 @@ struct FwdArgs {
     const int32_t *rows;
     int64_t n_work;
     const int *only_if;      // lean kernels behind the dense path: run only when this device word is non-zero (null: always)
+    int deep;                // HAN_FLAG_K2_DEEP (measurements)
     float slope;
     uint32_t seed_lo, seed_hi, thr_coef;
     const uint64_t *seed_dev;
@@ -1696,12 +1697,15 @@ static void launch_fwd_rows(const FwdArgs &a, bool train, bool short_rows, hipSt
         else node_attn_fwd_kernel<FPC, false, 4, 4, BF, VAL, false, false><<<grid, 256, 0, st>>>(a);
     } else {
         const int grid = attn_grid(a.n_work);
-        // bf16 rows are 128 B: the eval forward (and the backward gather) keep 8 steps in flight
-        // to cover the HBM latency (measured -6..-12 %); the training forward is VALU-bound
-        // (RNG + masks per edge) and gets slower with the longer unroll
-        constexpr int UE = BF ? 8 : 4;
+        // steps of 4 x 4 rows for both table types.  (Rounds 2-3 ran the bf16 eval forward with 8 steps in flight, 114-125
+        // registers, four waves per SIMD; re-measured in round 4 at N = 10M, profiles/r04_k2_bf16_in_flight_sweep.jsonl:
+        // 4 steps / 76 registers / six waves 12.3 ms, 8 steps 13.3 ms, 16 steps 21.0 ms, 2 masked steps at eight waves
+        // 13.6 ms -- what a CU keeps in flight is waves x steps, and registers spent on deeper unrolls cost more waves
+        // than they add rows.)
+        constexpr int UE = 4;
         if (train && fast) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, true, true><<<grid, 256, 0, st>>>(a);
         else if (train) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, false, true><<<grid, 256, 0, st>>>(a);
+        else if (BF && a.deep) node_attn_fwd_kernel<FPC, false, 1, 8, BF, VAL, false, BF><<<grid, 256, 0, st>>>(a);      // HAN_FLAG_K2_DEEP
         else node_attn_fwd_kernel<FPC, false, 1, UE, BF, VAL, false, BF><<<grid, 256, 0, st>>>(a);
     }
 }
@@ -1845,7 +1849,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     FwdArgs a;
     a.rowptr = rowptr; a.colidx = colidx; a.edge_val = edge_val; a.H = H; a.gid = table_gid; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.f2g = f2_src; a.a2 = a2; a.b2 = b2; a.c = c; a.res = res;
     a.out = out; a.out_stride = out_stride; a.pre = pre; a.lse = lse; a.aggp = aggp; a.tsum = tsum;
-    a.N = N; a.rows = nullptr; a.n_work = N; a.only_if = nullptr; a.slope = slope;
+    a.N = N; a.rows = nullptr; a.n_work = N; a.only_if = nullptr; a.deep = (flags & HAN_FLAG_K2_DEEP) ? 1 : 0; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);

@@ -50,6 +50,8 @@ extern "C" {
                                   for 8 heads x 8 columns one lane owns a whole head of an edge.  han_node_attn_bwd_cols: the same
                                   hash sharing, and the one-lane-per-head map for 8 x 8.  fp32 tables, table_gid NULL.  Not for
                                   large tables: the score gather would cost a memory line per edge there.                      */
+#define HAN_FLAG_K2_DEEP 512    /* measurements only: the bf16 eval forward with 8 steps (32 rows) in flight per wave instead of 4
+                                  (rounds 2-3's form: more registers, fewer waves; tools/k2_regimes.py --deep)               */
 #define HAN_FLAG_MASKED_EDGES 64 /* han_node_attn_bwd_cols: entries of rowidx below 0 are skipped IN PLACE (their destination's
                                   g row is identically zero -- a destination outside the loss mask of a one-layer model);
                                   the remaining terms are summed in the positions and order of the full pass, so the

@@ -41,6 +41,13 @@ def train_variants(dev, sizes=(1_000_000, 4_000_000, 10_000_000)):
                     ts.append(e0.elapsed_time(e1))
                 return sorted(ts)[len(ts) // 2]
             te = timeit(lambda: ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out))
+            if "--deep" in sys.argv and tdt == torch.bfloat16:      # same process, same box: 4 against 8 steps in flight
+                ops.K2_DEEP = True
+                te8 = timeit(lambda: ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out))
+                ops.K2_DEEP = False
+                te4 = timeit(lambda: ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out))
+                print(json.dumps({"N": n, "tables": tag, "bf16_eval_forward_ms": {"4_steps_in_flight": [round(te, 3), round(te4, 3)],
+                                                                                   "8_steps_in_flight": round(te8, 3)}}), flush=True)
             tt = timeit(lambda: ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=0.6,
                                                   fts_drop=0.6, seed=3))
             _, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=0.6, fts_drop=0.6, seed=3)
