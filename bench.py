@@ -538,6 +538,8 @@ def main():
     ap.add_argument("--reorder", choices=("none", "bfs"), default="none",
                     help="locality pass (han_amd.reorder): breadth-first relabelling of the nodes before training "
                          "(single GPU; the pass itself is timed separately and reported)")
+    ap.add_argument("--no-dense", action="store_true",
+                    help="keep small dense graphs on the lean CSR kernels (measurements: the matrix-pipe K2 form off)")
     ap.add_argument("--table-dtype", choices=("f32", "bf16"), default="f32",
                     help="storage of X and of the H/g gather tables (bf16 = the 10M-node config's "
                          "'bf16 feats'); accumulation is fp32 either way")
@@ -583,6 +585,8 @@ def main():
     from han_amd.gat import HeteGAT_multi
     from han_amd.trainer import HANTrainer
 
+    if args.no_dense:
+        ops.DENSE = False
     rng.manual_seed(2024)
     cfg_n = args.nodes or synth.CONFIGS[args.workload]["n"]
     part = NodePartition(cfg_n, rank, world) if use_dist else None
@@ -641,6 +645,12 @@ def main():
               ("eval", "train"): "all-gather (backward only); H projected on every rank in both forwards"}[tuple(rep)]
         exchange = ["halo %.1f%% of the remote rows" % (100.0 * pl.halo_fraction) if pl is not None else ag
                     for pl in plans]
+    # which meta-paths run K2 in the dense (bit mask + fp32 MFMA) form: small graphs at least half full
+    dense_paths = None
+    if part is None and n <= 16384:
+        probe = torch.empty((n, 64), device=dev)
+        dense_paths = [bool(ops._use_dense(g, probe, 8, 8)) for g in trainer.graphs]
+        del probe
     trainer_replicate_info = trainer.replicate_info
     wl["graphs"] = None
     torch.cuda.synchronize()
@@ -787,8 +797,9 @@ def main():
                        "parallelism": f"node-partition x{world}" if world > 1 else
                        ("single GPU, epoch replayed from a hipGraph" if use_graph else "single GPU"),
                        **({"captured_epoch": {"c_abi_calls": getattr(trainer, "graph_abi_calls", None),
-                                              "kernel_nodes_per_epoch": "profiles/r03_*_like_graph_kernel_stats.csv "
+                                              "kernel_nodes_per_epoch": "profiles/r04_*_like_graph_kernel_stats.csv "
                                                                         "(calls / 53 epochs)"}} if use_graph else {}),
+                       **({"k2_dense_form": dense_paths} if dense_paths is not None else {}),
                        **({"exchange": exchange} if exchange is not None else {}),
                        **({"replication": trainer_replicate_info} if trainer_replicate_info else {}),
                        **({"reorder": reorder_info} if reorder_info is not None else {}),

@@ -1874,7 +1874,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
             return HAN_E_BADARG;
         DenseArgs d;
         if (!dense_geometry(N, dense->n_table, train, dense, &d)) return HAN_E_WORKSPACE;
-        dense_f2_range_kernel<<<1, 1024, 0, st>>>(f2_src, d.NT, d.hdr);
+        dense_f2_range_kernel<<<kDenseRangeBlocks, 256, 0, st>>>(f2_src, d.NT, d.hdr);
         const dim3 dg((unsigned)((N + kDenseRowsPerBlock - 1) / kDenseRowsPerBlock), (unsigned)d.S);
         const int fg = (int)((N + 15) / 16);
         if (train) {
@@ -1991,7 +1991,7 @@ extern "C" int han_node_attn_bwd_cols(const int64_t *colptr, const int32_t *rowi
             return HAN_E_BADARG;
         DenseArgs d;
         if (!dense_geometry(NS, dense->n_table, false, dense, &d)) return HAN_E_WORKSPACE;
-        dense_f2_range_kernel<<<1, 1024, 0, st>>>(f2, NS, d.hdr);
+        dense_f2_range_kernel<<<kDenseRangeBlocks, 256, 0, st>>>(f2, NS, d.hdr);
         const dim3 dg((unsigned)((NS + kDenseRowsPerBlock - 1) / kDenseRowsPerBlock), (unsigned)d.S);
         node_attn_bwd_dense_kernel<<<dg, 256, 0, st>>>(a, d);
         node_attn_bwd_dense_finish_kernel<<<(int)((NS + 15) / 16), 256, 0, st>>>(a, d);

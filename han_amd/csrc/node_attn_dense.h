@@ -40,35 +40,33 @@ struct DenseArgs {
     int64_t ldw;
     float *slab;             // [S][rows][row_width] partial sums per segment
     float *hdr;              // [0..7] F = max f2 per head, [8..15] min, [16] (int) 1 = range too wide: run the CSR kernel
+                             // (published by block (0, 0) of the dense launch); [32 ..) the range launch's partials
     int S, tiles_per_seg, tiles;
     int64_t NT;              // table rows
 };
 
-constexpr int kDenseHdrFloats = 32;
+constexpr int kDenseRangeBlocks = 32;
+constexpr int kDenseHdrFloats = 32 + 16 * kDenseRangeBlocks;      // [0..16] final (F, min, flag) | [32 ..) per-block partials
 
-// per head: max / min of f2 over the table, and the verdict.  One block of 1024
-// threads, every load independent of the others (the first build -- 256 threads, one row per thread and trip -- was
-// 8 us of dependent L2 round trips in front of a 60 us kernel).
-__global__ __launch_bounds__(1024) void dense_f2_range_kernel(const float *f2, int64_t NT, float *hdr) {
-    __shared__ float smx[16][8], smn[16][8];
+// per head: max / min of f2 over the table, in kDenseRangeBlocks slices (one block each; partial results at
+// hdr[32 + 16 b]: 8 max | 8 min).  The consumers fold the 32 partials themselves (dense_range below): as ONE block
+// this was 8 us alone and 30 us inside a captured epoch, where a single 1024-thread block waits for a free CU behind
+// the other meta-paths' kernels (profiles/r04_dblp_like_graph_kernel_stats.csv of the first build).
+__global__ __launch_bounds__(256) void dense_f2_range_kernel(const float *f2, int64_t NT, float *hdr) {
+    __shared__ float smx[4][8], smn[4][8];
+    const int64_t per = (NT + kDenseRangeBlocks - 1) / kDenseRangeBlocks;
+    const int64_t r0 = per * blockIdx.x, r1 = (r0 + per < NT) ? r0 + per : NT;
     float mx[8], mn[8];
 #pragma unroll
     for (int h = 0; h < 8; ++h) { mx[h] = -3.0e38f; mn[h] = 3.0e38f; }
-    for (int64_t r0 = threadIdx.x; r0 < NT; r0 += 4096) {
-        float4_t va[4], vb[4];
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        const float4_t a = *reinterpret_cast<const float4_t *>(f2 + r * 8);
+        const float4_t b = *reinterpret_cast<const float4_t *>(f2 + r * 8 + 4);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t r = (r0 + 1024 * u < NT) ? r0 + 1024 * u : r0;
-            va[u] = *reinterpret_cast<const float4_t *>(f2 + r * 8);
-            vb[u] = *reinterpret_cast<const float4_t *>(f2 + r * 8 + 4);
+        for (int t = 0; t < 4; ++t) {
+            mx[t] = fmaxf(mx[t], a[t]); mn[t] = fminf(mn[t], a[t]);
+            mx[4 + t] = fmaxf(mx[4 + t], b[t]); mn[4 + t] = fminf(mn[4 + t], b[t]);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                mx[t] = fmaxf(mx[t], va[u][t]); mn[t] = fminf(mn[t], va[u][t]);
-                mx[4 + t] = fmaxf(mx[4 + t], vb[u][t]); mn[4 + t] = fminf(mn[4 + t], vb[u][t]);
-            }
     }
 #pragma unroll
     for (int h = 0; h < 8; ++h)
@@ -85,15 +83,37 @@ __global__ __launch_bounds__(1024) void dense_f2_range_kernel(const float *f2, i
     __syncthreads();
     if (threadIdx.x < 8) {
         const int h = threadIdx.x;
-        float M = smx[0][h], m = smn[0][h];
-        for (int ww = 1; ww < 16; ++ww) { M = fmaxf(M, smx[ww][h]); m = fminf(m, smn[ww][h]); }
-        hdr[h] = M;
-        hdr[8 + h] = m;
-        // NaN / inf scores fail the comparison too: they go to the CSR kernels, which treat them as the reference does
-        const bool ok = (M - m) <= kDenseMaxRange && fabsf(M) < 1.0e30f;
-        const unsigned long long bad = __ballot(!ok) & 0xFFull;
-        if (h == 0) reinterpret_cast<int *>(hdr)[16] = bad ? 1 : 0;
+        float *part = hdr + 32 + 16 * blockIdx.x;
+        part[h] = fmaxf(fmaxf(smx[0][h], smx[1][h]), fmaxf(smx[2][h], smx[3][h]));
+        part[8 + h] = fminf(fminf(smn[0][h], smn[1][h]), fminf(smn[2][h], smn[3][h]));
     }
+}
+
+// Fold the partial ranges (every block of a dense launch does, identically): sF[0..7] = F = max f2 per head; returns
+// whether the fixed-shift form applies (every head's range within kDenseMaxRange; NaN / inf scores fail the comparison
+// too and go to the CSR kernels, which treat them as the reference does).  Block (0, 0) publishes F and the verdict in
+// hdr[0..16] for the launches behind this one (the finishing pass; the predicated CSR kernel).  Contains a barrier.
+__device__ __forceinline__ bool dense_range(float *hdr, float *sF) {
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int h = threadIdx.x;
+        float M = -3.0e38f, m = 3.0e38f;
+#pragma unroll 8
+        for (int b = 0; b < kDenseRangeBlocks; ++b) {
+            M = fmaxf(M, hdr[32 + 16 * b + h]);
+            m = fminf(m, hdr[32 + 16 * b + 8 + h]);
+        }
+        sF[h] = M;
+        const bool ok = (M - m) <= kDenseMaxRange && fabsf(M) < 1.0e30f;
+        if (!ok) atomicOr(&s_bad, 1);
+        if (blockIdx.x == 0 && blockIdx.y == 0) { hdr[h] = M; hdr[8 + h] = m; }
+    }
+    __syncthreads();
+    const bool bad = s_bad != 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) reinterpret_cast<int *>(hdr)[16] = bad ? 1 : 0;
+    return !bad;
 }
 
 // (Folding the finishing launch into the last segment to arrive for a row block -- a ticket per block, __threadfence()
@@ -137,7 +157,8 @@ __global__ __launch_bounds__(256) void node_attn_fwd_dense_finish_kernel(const F
 // grid (ceil(N / 64), S); block 256 = 4 waves x one 16-row tile each
 template <bool TRAIN>
 __global__ __launch_bounds__(256) void node_attn_fwd_dense_kernel(const FwdArgs a_in, const DenseArgs d) {
-    if (reinterpret_cast<const int *>(d.hdr)[16]) return;      // range too wide: the predicated CSR launch does the work
+    __shared__ float sF[8];
+    if (!dense_range(d.hdr, sF)) return;      // range too wide (every block agrees): the predicated CSR launch does the work
     FwdArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     constexpr int RW = DenseRowWidth<TRAIN>::value;
@@ -159,7 +180,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_dense_kernel(const FwdArgs 
 #pragma unroll
         for (int h = 0; h < 8; ++h) {
             f1i[h] = h < 4 ? fa[h & 3] : fb[h & 3];
-            const float x = f1i[h] + d.hdr[h];
+            const float x = f1i[h] + sF[h];
             const float m = han_lrelu(x, a.slope);
             Ai[h] = __expf(x - m);
             Ci[h] = __expf(a.slope * x - m);
@@ -196,7 +217,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_dense_kernel(const FwdArgs 
         f2reg = a.f2g[j * 8 + (tid & 7)];
         wreg = d.bits[irow * d.ldw + jc];
     };
-    const float fmax_h = d.hdr[tid & 7];
+    const float fmax_h = sF[tid & 7];
     load_tile(t0);
     for (int jt = t0; jt < t1; ++jt) {
         const int64_t j0 = (int64_t)jt * kDenseTile;
@@ -349,7 +370,8 @@ __global__ __launch_bounds__(256) void node_attn_bwd_dense_finish_kernel(const B
 }
 
 __global__ __launch_bounds__(256) void node_attn_bwd_dense_kernel(const BwdColsArgs a_in, const DenseArgs d) {
-    if (reinterpret_cast<const int *>(d.hdr)[16]) return;
+    __shared__ float sF[8];
+    if (!dense_range(d.hdr, sF)) return;
     BwdColsArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
     constexpr int RB = GsRow<8, false>::bytes;
@@ -372,7 +394,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_dense_kernel(const BwdColsA
 #pragma unroll
         for (int h = 0; h < 8; ++h) {
             f2j[h] = h < 4 ? fa[h & 3] : fb[h & 3];
-            const float y = f2j[h] - d.hdr[h];
+            const float y = f2j[h] - sF[h];
             Bj[h] = __expf(y);
             Dj[h] = __expf(a.slope * y);
 #pragma unroll
@@ -406,7 +428,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_dense_kernel(const BwdColsA
         sreg = *reinterpret_cast<const float4_t *>(gsb + i * RB + GB + 16 * (tid & 7));
         wreg = d.bits[jrow * d.ldw + ic];
     };
-    const float fmax_h = d.hdr[tid & 7];
+    const float fmax_h = sF[tid & 7];
     load_tile(t0);
     for (int it = t0; it < t1; ++it) {
         const int64_t i0 = (int64_t)it * kDenseTile;

@@ -85,14 +85,24 @@ def run(rank, world, device, epochs, drop, out_path, port, use_cpu_backend):
                     xs_full=[x] * p if (rep and part is not None) else None, replicate=rep or "auto",
                     max_halo_fraction=-1.0 if os.environ.get("HAN_TEST_ALLGATHER") == "1" else 0.6,
                     masked_backward=os.environ.get("HAN_TEST_MASKED_BWD") == "1")
+    comm = None
+    if part is not None and os.environ.get("HAN_TEST_COMM") == "1":      # what bench.py attaches for its N > 1 line
+        from han_amd.dist import CommStats
+        comm = part.comm = CommStats()
     hist = []
     for _ in range(epochs):
         hist.append(tr.reduce_metrics(*tr.epoch()))
     if rank == 0:
         pf, pb = model.halo_plans
         halo = 0 if pf is None else sum(x is not None for x in pf) + sum(x is not None for x in pb)
+        halo_rows = 0 if pf is None else sum(x.n_halo for x in list(pf) + list(pb) if x is not None)
+        extra = {}
+        if comm is not None:
+            extra = dict(comm_bytes=comm.bytes_received, comm_exchanges=comm.exchanges,
+                         comm_allreduce=comm.allreduce_bytes, comm_wait_ms=comm.wait_ms(),
+                         shard=part.shard, halo_rows=halo_rows, n_params=model.flat.numel())
         np.savez(out_path, flat=model.flat.detach().cpu().numpy(), hist=np.array(hist), halo_plans=halo,
-                 replicate=",".join(sorted(tr.replicate)))
+                 replicate=",".join(sorted(tr.replicate)), **extra)
     if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()

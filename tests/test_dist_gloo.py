@@ -177,3 +177,27 @@ def test_wide_heads_under_a_node_partition(tmp_path, graph, port):
         assert int(b["halo_plans"]) == 4
     assert np.abs(a["flat"] - b["flat"]).max() < 1e-5
     assert np.abs(a["hist"] - b["hist"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("mode,port", [("allgather", 29791), ("halo", 29795)])
+def test_comm_stats_count_what_a_rank_receives(tmp_path, mode, port):
+    """dist.CommStats (bench.py's N > 1 keys exchange_bytes_received / comm_wait_ms / grad_allreduce_bytes): per epoch and
+    meta-path a rank receives one forward table in the training step, one in the eval forward (256 B per row) and one
+    fused [g | stats] table in the backward (384 B per row) -- the other ranks' whole blocks in all-gather mode, its halo
+    rows in halo mode -- and all-reduces the flat gradient buffer once (reduce_metrics adds 16 B per epoch)."""
+    out = str(tmp_path / "two.npz")
+    env = {"HAN_TEST_COMM": "1"}
+    env.update({"HAN_TEST_ALLGATHER": "1"} if mode == "allgather" else {"HAN_TEST_GRAPH": "band"})
+    epochs, world, p = 2, 2, 2
+    _launch(world, epochs, 0.6, out, port, env)
+    z = np.load(out)
+    assert int(z["comm_exchanges"]) == epochs * p * 3
+    if mode == "allgather":
+        assert int(z["halo_plans"]) == 0
+        assert int(z["comm_bytes"]) == epochs * p * (world - 1) * int(z["shard"]) * (256 + 256 + 384)
+    else:
+        assert int(z["halo_plans"]) == 4
+        # forward plans serve two exchanges per epoch (train + eval), backward plans one; halo_rows sums both kinds
+        assert 0 < int(z["comm_bytes"]) < epochs * p * int(z["shard"]) * (256 + 256 + 384) // 4
+    assert int(z["comm_allreduce"]) == epochs * (int(z["n_params"]) * 4 + 4 * 4)
+    assert float(z["comm_wait_ms"]) > 0.0       # host-staged gloo collectives: wall time on the host
