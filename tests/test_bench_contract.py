@@ -180,3 +180,35 @@ def test_multi_rank_lines_carry_the_exchange_keys():
             assert MULTI_RANK_KEYS <= set(d), (name, MULTI_RANK_KEYS - set(d))
             assert d["rccl_ranks"] == d["n_gpus"] and d["exchange_bytes_received"] > 0 and d["comm_wait_ms"] >= 0
     assert seen >= 1
+
+
+def test_round4_lines_meet_what_they_claim():
+    """The committed round-4 lines: the default line with the power-law variant's K2 launches at the targets VERDICT r3
+    set (training forward <= 2.0 ms, eval <= 1.85 ms) and the uniform headline not slower than round 3; the small-graph
+    lines on graphs with EXACTLY the data sets' entry counts; the DBLP-like line says which meta-path ran K2 in the dense
+    form and beats the CSR-only run of the same build."""
+    lines = dict(_lines("r04"))
+    d = lines["r04_bench_syn1m_f32_1gpu.json"]
+    assert CONTRACT_KEYS <= set(d) and d["n_gpus"] == 1 and d["vs_baseline"] is None
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-3 and d["value"] >= 27.5
+    r = d["roofline"]
+    assert r["bound"] == "fabric / infinity cache" and 0.5 <= r["hbm_frac"] <= 1.0
+    assert abs(r["traffic"] / r["moved_bytes_per_launch"] - 1.0) < 0.03
+    assert all(v["frac"] >= 0.5 for v in d["roofline_hbm_regime"].values())          # BASELINE: >= 50 % of the HBM roofline
+    sk = d["skew"]["k2"]
+    assert sk["train"]["avg_launch_ms"] <= 2.0 and sk["eval"]["avg_launch_ms"] <= 1.85
+    assert d["skew"]["value"] >= 30.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["all_cores"]["sample_n"] == c["one_thread"]["sample_n"] >= 10_000
+    dblp, dblp_csr, acm = (lines[k] for k in ("r04_bench_dblp_like_graph.json", "r04_bench_dblp_like_graph_no_dense.json",
+                                              "r04_bench_acm_like_graph.json"))
+    assert "E=17936007 [11113, 5000495, 12924399]" in dblp["config"]["workload"]
+    assert "E=2240042 [29281, 2210761]" in acm["config"]["workload"]
+    assert dblp["config"]["k2_dense_form"] == [False, False, True] and dblp_csr["config"]["k2_dense_form"] == [False] * 3
+    assert dblp["ms_per_step"] <= 1.0 and dblp["value"] > 1.15 * dblp_csr["value"]
+    assert acm["config"]["k2_dense_form"] == [False, False]
+    b16 = lines["r04_bench_syn10m_bf16_1gpu.json"]
+    assert "syn-10m" in b16["config"]["workload"] and b16["dtype"].startswith("bf16") and b16["value"] > 1.5
+    for name, dd in lines.items():
+        assert CONTRACT_KEYS <= set(dd) | {"roofline"}, name
+        assert dd["unit"] == "epochs/s" and dd["data"] == "synthetic" and "workload" in dd["config"]

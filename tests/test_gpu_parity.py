@@ -229,6 +229,28 @@ def test_project_fwd_multi_matches_the_per_meta_path_kernel(dev, P, n, f, xbf, K
         assert np.abs(f2[p].cpu().numpy() - f2ref).max() < 1e-4 * max(1.0, np.abs(f2ref).max()), p
 
 
+def test_bf16_table_keeps_nan_and_inf(dev):
+    """han_f32_to_bf16_bits (VERDICT r3 hygiene): a NaN stays a NaN in a bf16 table -- the rounding add used to carry a
+    NaN whose upper mantissa bits were all ones into the sign / exponent (0x7FFFFFFF -> -0.0) -- and +-inf stay +-inf."""
+    from han_amd import ops
+    n, f = 300, 8
+    X = torch.zeros((n, f), device=dev)
+    X[:, 0] = 1.0
+    X[7, 0] = float("nan")
+    X[8, 0] = torch.tensor(0x7FFFFFFF, dtype=torch.int32).view(torch.float32)      # the NaN that used to turn into -0.0
+    X[9, 0] = float("inf")
+    X[10, 0] = -float("inf")
+    W = torch.zeros((f, 64), device=dev)
+    W[0, :] = 1.0                                  # H[n, :] = X[n, 0]
+    a = torch.zeros((8, 8), device=dev)
+    b = torch.zeros(8, device=dev)
+    H, f1, f2 = ops.project_fwd(X, W, a, a, b, b, table_dtype=torch.bfloat16)
+    H = H.float()
+    assert torch.isnan(H[7]).all() and torch.isnan(H[8]).all()
+    assert (H[9] == float("inf")).all() and (H[10] == -float("inf")).all()
+    assert (H[11] == 1.0).all()
+
+
 @pytest.mark.parametrize("K,FP", [(4, 16), (16, 4), (2, 32)])
 @pytest.mark.parametrize("n,f,xbf", [(3000, 256, False), (16500, 64, True)])
 def test_bf16_table_scores_follow_the_head_width(dev, K, FP, n, f, xbf):
