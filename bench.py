@@ -786,10 +786,10 @@ def main():
             "config": {"workload": f"{args.workload}: N={n} nodes, P={p} meta-paths, "
                                    f"E={e_global} " + (f"{e_per_path} " if len(set(e_per_path)) > 1 and world == 1 else "") +
                                    f"edges, F={wl['f']}, K=8 heads x F'=8, A=128, C={wl['c']}",
-                       "graph_recipe": ("per row the self-loop + (deg-1) uniform neighbours drawn with a torch "
-                                        "generator on the device, duplicates kept (multigraph terms), columns sorted "
-                                        "per row -- deviates from SURVEY.md 8d's distinct-neighbour / "
-                                        "numpy default_rng(1234+p) recipe; byte counts are identical")
+                       "graph_recipe": ("SURVEY.md 8d: per row the self-loop + (deg-1) DISTINCT uniformly random "
+                                        "off-diagonal neighbours, columns sorted per row; drawn with block-seeded torch "
+                                        "generators on the device (so that N ranks generate exactly their own rows) "
+                                        "instead of numpy default_rng(1234+p)")
                        if args.workload.startswith("syn-") else
                        "han_amd.synth: per meta-path a symmetric random graph + I with EXACTLY the data set's entry count "
                        "(SURVEY.md section 8; (nnz - N)/2 distinct pairs i < j drawn without replacement, mirrored; "

@@ -170,7 +170,7 @@ def _use_lean(graph: CSRGraph, table) -> bool:
 
 
 DENSE = True               # tests / measurements: False keeps small dense graphs on the lean CSR kernels
-DENSE_MIN_DENSITY = 0.5    # stored entries / (rows x table rows) from which the matrix-pipe form wins (profiles/r04_k2_dense_vs_lean.jsonl)
+DENSE_MIN_DENSITY = 0.65   # stored entries / (rows x table rows) from which the matrix-pipe form wins over a whole training step (eval + training forward + backward: 0.47 ms at any density against 0.59 ms for the lean CSR kernels at 78 %, ~0.40 ms at 50 %; profiles/r04_k2_dense_vs_lean.jsonl)
 
 
 def _use_dense(graph: CSRGraph, table, K: int, FP: int) -> bool:

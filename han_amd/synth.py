@@ -42,21 +42,41 @@ def _blocks(r0, r1):
 
 
 def random_regular_graph(n: int, deg: int, seed: int, device="cpu", symmetric=False, rows=None) -> CSRGraph:
-    """Each row: the self-loop + (deg-1) uniformly random neighbours (duplicates
-    of the self-loop or of each other are possible at rate ~deg^2/n and are kept:
-    the kernels treat a repeated neighbour as a repeated term, as a multigraph).
-    Generated on `device` with torch so that 5e7-edge graphs take seconds.
+    """Each row: the self-loop + (deg-1) DISTINCT uniformly random off-diagonal neighbours, columns sorted
+    (SURVEY.md section 8d's recipe; rounds 1-3 kept the ~deg^2/2n repeated draws as multigraph terms).  Generated on
+    `device` with torch so that 5e7-edge graphs take seconds: candidates are drawn from [0, n-1) and shifted past
+    the row's own id; the few rows that drew a neighbour twice (0.12 % at deg 50, n = 10^6) are re-drawn whole, from a
+    generator keyed by the attempt, until none is left -- all per 65 536-row block, so what a block holds does not
+    depend on which rows the caller asks for.
     rows = (r0, r1): only those destination rows (colidx stays global, n_cols = n)."""
     if symmetric:
         raise NotImplementedError
+    if deg - 1 > n - 1:
+        raise ValueError(f"{deg - 1} distinct off-diagonal neighbours do not exist among {n} nodes")
     r0, r1 = _row_range(n, rows)
     parts = []
     for b, lo, hi in _blocks(r0, r1):
         nb_rows = min(ROW_BLOCK, n - b * ROW_BLOCK)
-        nb = torch.randint(0, n, (nb_rows, deg - 1), generator=_block_generator(seed, 1, b, device), device=device,
-                           dtype=torch.int32)[lo:hi]
-        ids = torch.arange(b * ROW_BLOCK + lo, b * ROW_BLOCK + hi, device=device, dtype=torch.int32)[:, None]
-        parts.append(torch.sort(torch.cat([ids, nb], dim=1), dim=1).values.reshape(-1))
+        ids_all = torch.arange(b * ROW_BLOCK, b * ROW_BLOCK + nb_rows, device=device, dtype=torch.int32)[:, None]
+
+        def draw(gen, ids):
+            if (deg - 1) ** 2 > n - 1:     # small tables (a row repeats a draw with probability > 0.4): a random permutation's prefix
+                c = torch.rand((ids.shape[0], n - 1), generator=gen, device=device).argsort(1)[:, :deg - 1].to(torch.int32)
+            else:
+                c = torch.randint(0, n - 1, (ids.shape[0], deg - 1), generator=gen, device=device, dtype=torch.int32)
+            return torch.sort(c + (c >= ids).to(torch.int32), dim=1).values      # skip the row's own id
+
+        nb = draw(_block_generator(seed, 1, b, device), ids_all)
+        for attempt in range(64):
+            dup = (nb[:, 1:] == nb[:, :-1]).any(1) if deg > 2 else torch.zeros(nb_rows, dtype=torch.bool, device=device)
+            idx = torch.nonzero(dup).flatten()
+            if idx.numel() == 0:
+                break
+            nb[idx] = draw(_block_generator(seed, 101 + attempt, b, device), ids_all[idx])
+        else:
+            raise RuntimeError("could not draw distinct neighbours (deg too close to n)")
+        ids = ids_all[lo:hi]
+        parts.append(torch.sort(torch.cat([ids, nb[lo:hi]], dim=1), dim=1).values.reshape(-1))
         del nb
     cols = torch.cat(parts) if parts else torch.empty(0, dtype=torch.int32, device=device)
     rowptr = torch.arange(0, (r1 - r0) * deg + 1, deg, device=device, dtype=torch.int64)

@@ -2161,7 +2161,7 @@ def test_structural_properties_of_the_node_attention(dev):
     (1) the order of the stored neighbours inside a row does not matter;
     (2) K single-head calls of the reference-named attn_head, concatenated, equal the K-head model layer
         (models/gat.py:42-46 builds the layer exactly that way);
-    (3) a repeated neighbour is a repeated softmax term (the multigraph reading the synthetic graphs rely on):
+    (3) a repeated neighbour is a repeated softmax term (the multigraph reading of a CSR with repeated entries):
         doubling every edge of a row changes nothing, doubling ONE edge shifts weight to it;
     (4) rows are independent: changing the neighbour list of row r changes only output row r."""
     import torch.nn.functional as Fnn
