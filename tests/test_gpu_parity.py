@@ -1073,6 +1073,65 @@ def test_dense_form_falls_back_on_the_device_when_the_scores_range_is_wide(dev):
             assert float((a_ - b_).abs().max()) < 1e-4 * sc, (scale, name)
 
 
+def test_dense_form_with_residual_identity_activation_and_stored_pre(dev):
+    """The dense K2 form finishes its rows through the same write_row as the CSR kernels: residual term added before the
+    activation (layers.py:38-40), identity activation (the kernel then emits the pre-activation for a torch-side callable),
+    an output view with a row stride (M[:, p, :]), empty rows, and a table whose last 32-column tile is partial -- against the
+    gather kernels on the same inputs, forward and backward."""
+    from han_amd import ops, synth
+    n = 333                                   # 10 full tiles + one of 13 columns; 5 full 64-row blocks + one of 13 rows
+    gen = torch.Generator(device=dev).manual_seed(13)
+    g0 = synth.bernoulli_graph(n, 0.7, 9, dev)
+    # empty two rows (no self-loop either): their outputs are act(c + res)
+    deg = g0.degrees().clone()
+    keep = torch.ones(g0.nnz, dtype=torch.bool, device=dev)
+    for r in (5, 200):
+        keep[int(g0.rowptr[r]):int(g0.rowptr[r + 1])] = False
+        deg[r] = 0
+    from han_amd.graph import CSRGraph
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = deg.cumsum(0)
+    g = CSRGraph(rowptr, g0.colidx[keep].contiguous(), n)
+    gt = g.transpose()
+    a1, a2 = (torch.randn((8, 8), device=dev, generator=gen) * 0.3 for _ in range(2))
+    b1, b2 = (torch.randn(8, device=dev, generator=gen) * 0.1 for _ in range(2))
+    c = torch.randn(64, device=dev, generator=gen) * 0.1
+    X = torch.randn((n, 24), device=dev, generator=gen)
+    W = torch.randn((24, 64), device=dev, generator=gen) * 0.25
+    res = torch.randn((n, 64), device=dev, generator=gen) * 0.2
+    dOut = torch.randn((n, 64), device=dev, generator=gen)
+    H, f1, f2 = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.4, fts_drop=0.4, seed=17)
+    out = {}
+    for mode in ("gather", "dense"):
+        ops.LEAN, ops.DENSE = mode != "gather", mode == "dense"
+        min_density, ops.DENSE_MIN_DENSITY = ops.DENSE_MIN_DENSITY, 0.0
+        try:
+            assert ops._use_dense(g, H, 8, 8) == ops.DENSE and ops._use_dense(gt, H, 8, 8) == ops.DENSE
+            r = []
+            for act in (ops.ACT_ELU, ops.ACT_IDENTITY):
+                M = torch.zeros((n, 2, 64), device=dev)
+                ops.node_attn_fwd(g, H, f1, a2, b2, c, out=M[:, 1, :], activation=act, res=res, f2=f2)
+                assert float(M[:, 0, :].abs().max()) == 0.0            # the strided view: nothing written beside it
+                Mt = torch.zeros((n, 2, 64), device=dev)
+                _, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, out=Mt[:, 1, :], train=True, coef_drop=0.4, fts_drop=0.4,
+                                          seed=17, activation=act, res=res, f2=f2)
+                gs, df1, dc = ops.node_attn_bwd_rows(dOut, sv[0], sv[2], sv[3], f1, sv[1], c, activation=act, res=res)
+                dH, df2 = ops.node_attn_bwd_cols(gt, gs, H, f2, df1, a1, a2, coef_drop=0.4, fts_drop=0.4, seed=17)
+                r += [M[:, 1, :].clone(), Mt[:, 1, :].clone(), sv[1], sv[2], sv[3], dH, df2, dc]
+        finally:
+            ops.LEAN = ops.DENSE = True
+            ops.DENSE_MIN_DENSITY = min_density
+        out[mode] = r
+    for i, (a_, b_) in enumerate(zip(out["dense"], out["gather"])):
+        assert torch.isfinite(a_).all(), i
+        sc = float(b_.abs().max()) + 1.0
+        assert float((a_ - b_).abs().max()) < 5e-5 * sc, i
+    e = out["dense"][0]                        # ELU eval output of the empty rows: act(c + res)
+    for r_ in (5, 200):
+        want = torch.nn.functional.elu(c + res[r_])
+        assert float((e[r_] - want).abs().max()) < 1e-6
+
+
 def test_return_coef_and_hetegat_class(dev):
     """attn_head(..., return_coef=True) (layers.py:43-44) and HeteGAT.inference(...,
     return_coef=True) (models/gat.py:132-203: shared inputs, head-mean coefficients per
