@@ -114,7 +114,7 @@ class CSRGraph:
         return g
 
     # ---- row splitting for skewed degree distributions ---------------------------
-    def row_split(self, split_deg: int = 8192, chunk: int = 4096):
+    def row_split(self, split_deg: int = 1024, chunk: int = 512):
         """Rows longer than `split_deg` cut into chunks of `chunk` edges (the
         han_row_split_t description).  Returns None when no row is that long,
         else a dict of device tensors; cached per (split_deg, chunk)."""
@@ -143,7 +143,7 @@ class CSRGraph:
                                         chunk_start=chunk_start, chunk_end=chunk_end)
         return self._split[key]
 
-    def row_bins(self, short_deg: int = 16, split_deg: int = 8192):
+    def row_bins(self, short_deg: int = 16, split_deg: int = 1024):
         """Degree bins of the rows (han_row_split_t: short_rows / mid_rows): rows with fewer than `short_deg` entries
         (incl. empty rows), ordered by ceil(deg / 4) and then id -- four of them share a wave, one 16-lane group
         each, and should need the same number of 4-entry steps --, rows of short_deg .. split_deg entries in id order
