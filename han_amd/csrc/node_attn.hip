@@ -170,16 +170,39 @@ __device__ __forceinline__ int han_bit_mask(int x) {
     return r;
 }
 
+// the 16-bit field `head & 3` of the hash words (hx, hy) that the lane at byte address `src_addr` computed (ds_bpermute)
+__device__ __forceinline__ uint32_t shared_field(const uint32_t hx, const uint32_t hy, const int src_addr, const int head) {
+    const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)hx);
+    const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)hy);
+    const uint32_t wsel = (head & 2) ? y : x;
+    return (head & 1) ? (wsel >> 16) : (wsel & 0xFFFFu);
+}
+
 // Gather U neighbour rows and fold them into the running softmax state.
 // FAST (training launches with both dropouts on and table index == global id): no uniform
 // branch is left inside the edge loop.  ALLV: all U slots hold real edges (full steps), so
 // the validity selects vanish; the tail of a row runs with U = 1.
-template <int FP, bool TRAIN, int U, bool BF, bool VAL, bool FAST, bool ALLV>
+// DD (full 4-edge steps of the FAST training launch): the attention-dropout hash of an edge serves four heads, so ONE lane
+// of the 16-lane group computes it (lane q: edge q & 3, head quad (q >> 2) % KQ) and the others fetch their field with
+// ds_bpermute, instead of all 16 lanes hashing every edge.
+template <int FP, bool TRAIN, int U, bool BF, bool VAL, bool FAST, bool ALLV, bool DD = false>
 __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U], const float (&w)[U],
                                               const bool (&valid)[U], const float f1h, const uint32_t gi, const int q, const int head,
                                               const float4_t &a24, const float b2h, const bool drop_c,
                                               RowState<TRAIN> &st) {
     constexpr int KQ = (HAN_D / FP + 3) / 4;
+    static_assert(!DD || (U == 4 && TRAIN && FAST && ALLV), "the shared hash is built for full 4-edge training steps");
+    uint32_t dd_x = 0, dd_y = 0;
+    int dd_addr = 0;
+    if (DD) {
+        const int uu = q & 3;
+        const int ju = uu == 0 ? j[0] : (uu == 1 ? j[1] : (uu == 2 ? j[2] : j[U - 1]));
+        const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
+                                        (uint32_t)ju * (uint32_t)KQ + (uint32_t)((q >> 2) % KQ));
+        dd_x = rn.x;
+        dd_y = rn.y;
+        dd_addr = (int)(((__lane_id() & 48) + 4 * (head >> 2)) * 4);
+    }
     float4_t hv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) hv[u] = han_load_row4<BF>(a.H, (int64_t)j[u], q);
@@ -214,7 +237,9 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
         if (TRAIN) {
             // The 1/keep factors of both dropouts are applied once per row in write_row,
             // not per edge: here a dropped term is simply zeroed.
-            if (FAST || drop_c) {   // attention dropout, layers.py:29-30
+            if (DD) {               // attention dropout from the group's shared hash
+                pd = shared_field(dd_x, dd_y, dd_addr + 4 * u, head) < a.thr_coef ? p : 0.f;
+            } else if (FAST || drop_c) {   // attention dropout, layers.py:29-30
                 const uint32_t gj = (!FAST && a.gid) ? (uint32_t)a.gid[j[u]] : (uint32_t)j[u];
                 const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
                                                 gj * (uint32_t)KQ + (uint32_t)(head >> 2));
@@ -282,7 +307,7 @@ __device__ __forceinline__ void write_row(const FwdArgs &a, const int64_t row, c
 // SPLIT: a row's edges run as full U-steps + single steps for the tail (fewer VALU instructions;
 // what the VALU-bound instantiations want) instead of masked U-steps (fewer registers: the fp32
 // eval forward keeps 64 VGPRs = 8 waves/SIMD, which is what the HBM-bound regime wants)
-template <int FP, bool TRAIN, int RPW, int U, bool BF, bool VAL, bool FAST, bool SPLIT>
+template <int FP, bool TRAIN, int RPW, int U, bool BF, bool VAL, bool FAST, bool SPLIT, bool DD = false>
 __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) {
     FwdArgs a = a_in;
     han_resolve_seed(a.seed_lo, a.seed_hi, a.seed_dev);
@@ -345,8 +370,8 @@ __global__ __launch_bounds__(256) void node_attn_fwd_kernel(const FwdArgs a_in) 
                         j[u] = __shfl(mycol, idx, 64);
                         w[u] = VAL ? __shfl(myval, idx, 64) : 1.f;
                     }
-                    consume_edges<FP, TRAIN, U, BF, VAL, FAST, true>(a, j, w, valid, f1h, gi, q, head, a24, b2h,
-                                                                     drop_c, st);
+                    consume_edges<FP, TRAIN, U, BF, VAL, FAST, true, DD>(a, j, w, valid, f1h, gi, q, head, a24, b2h,
+                                                                         drop_c, st);
                 }
                 if (U > 4 && (it + 4) * 4 <= cnt) {          // long unrolls: one half step before the singles
                     int j[4];
@@ -1632,13 +1657,17 @@ static bool dense_geometry(int64_t rows, int64_t n_table, bool train, const han_
 // CSR -> adjacency bit mask (rows must be zero-filled by the caller's memset in front of it); a bit that is already
 // set is a repeated entry: counted, because the bit-mask form cannot hold a multigraph term
 __global__ __launch_bounds__(256) void csr_to_bitmask_kernel(const int64_t *rowptr, const int32_t *colidx, int64_t N,
-                                                             uint32_t *bits, int64_t ldw, int *dups) {
+                                                             int64_t n_table, uint32_t *bits, int64_t ldw, int *dups) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t row = wave0; row < N; row += nwaves) {
         const int64_t e = rowptr[row + 1];
         for (int64_t p = rowptr[row] + lane; p < e; p += 64) {
             const int c = colidx[p];
+            if (c < 0 || c >= n_table) {      // a masked (-1) or foreign id has no bit: reported like a repeated entry, so that
+                if (dups) atomicAdd(dups, 1);      // the caller keeps such a graph off the dense form
+                continue;
+            }
             const uint32_t bit = 1u << (c & 31);
             const uint32_t old = atomicOr(bits + row * ldw + (c >> 5), bit);
             if ((old & bit) && dups) atomicAdd(dups, 1);
@@ -1703,6 +1732,10 @@ static void launch_fwd_rows(const FwdArgs &a, bool train, bool short_rows, hipSt
         // 13.6 ms -- what a CU keeps in flight is waves x steps, and registers spent on deeper unrolls cost more waves
         // than they add rows.)
         constexpr int UE = 4;
+        // (one attention-dropout hash per (edge, four heads) shared by ds_bpermute -- consume_edges<..., DD> -- is bitwise the
+        // same and was measured in one process, profiles/r04_k2_bf16_in_flight_sweep.jsonl: fp32 25.4 -> 24.0 ms at N = 10M
+        // but bf16 18.0 -> 18.9 ms, and 1.84 / 1.56 -> 1.85 / 1.61 ms at N = 1M: the two ds_bpermute per edge cost what
+        // the 11 vector instructions save; not instantiated)
         if (train && fast) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, true, true><<<grid, 256, 0, st>>>(a);
         else if (train) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, false, true><<<grid, 256, 0, st>>>(a);
         else if (BF && a.deep) node_attn_fwd_kernel<FPC, false, 1, 8, BF, VAL, false, BF><<<grid, 256, 0, st>>>(a);      // HAN_FLAG_K2_DEEP
@@ -2079,7 +2112,7 @@ extern "C" int han_csr_to_bitmask(const int64_t *rowptr, const int32_t *colidx, 
         e = hipMemsetAsync(repeated, 0, sizeof(int), st);
         if (e != hipSuccess) return (int)e;
     }
-    csr_to_bitmask_kernel<<<attn_grid(N), 256, 0, st>>>(rowptr, colidx, N, bits, ld_words, repeated);
+    csr_to_bitmask_kernel<<<attn_grid(N), 256, 0, st>>>(rowptr, colidx, N, n_table, bits, ld_words, repeated);
     HAN_CHECK_LAUNCH();
     return 0;
 }

@@ -205,7 +205,8 @@ typedef struct han_dense {
     size_t workspace_bytes;       /* >= han_node_attn_dense_workspace(rows, n_table, train) */
 } han_dense_t;
 size_t han_node_attn_dense_workspace(int64_t rows, int64_t n_table, int train);
-/* CSR -> bit mask.  *repeated (device int, or NULL) receives the number of entries that were already present.
+/* CSR -> bit mask.  *repeated (device int, or NULL) receives the number of entries that were already present (entries outside
+ * [0, n_table) -- e.g. the -1 of HAN_FLAG_MASKED_EDGES graphs -- are skipped and counted too: such a graph has no dense form).
  * Launches a memset of bits (and of *repeated) and one kernel on `stream`.                                     */
 int han_csr_to_bitmask(const int64_t *rowptr, const int32_t *colidx, int64_t N, int64_t n_table,
                        uint32_t *bits, int64_t ld_words, int *repeated, void *stream);
