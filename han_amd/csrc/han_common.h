@@ -182,6 +182,16 @@ static __global__ __launch_bounds__(256) void han_reduce_slabs_kernel(const floa
     if (n < width) {
         const float *col = slab + n;
         int b = sl;
+        // (round 4) two steps = eight loads in flight before the first add: at the slab counts of the small graphs
+        // (100-300 rows) the loop used to be 2-4 dependent L2 round trips; the additions keep their order
+        for (; b + 112 < nblocks; b += 128) {
+            const float v0 = col[(int64_t)b * row_stride], v1 = col[(int64_t)(b + 16) * row_stride];
+            const float v2 = col[(int64_t)(b + 32) * row_stride], v3 = col[(int64_t)(b + 48) * row_stride];
+            const float v4 = col[(int64_t)(b + 64) * row_stride], v5 = col[(int64_t)(b + 80) * row_stride];
+            const float v6 = col[(int64_t)(b + 96) * row_stride], v7 = col[(int64_t)(b + 112) * row_stride];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+            s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+        }
         for (; b + 48 < nblocks; b += 64) {
             s0 += col[(int64_t)b * row_stride];
             s1 += col[(int64_t)(b + 16) * row_stride];
