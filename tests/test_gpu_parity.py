@@ -1132,6 +1132,37 @@ def test_dense_form_with_residual_identity_activation_and_stored_pre(dev):
         assert float((e[r_] - want).abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("residual", [False, True])
+def test_dense_form_in_a_two_layer_stack(dev, residual, monkeypatch):
+    """Two node-attention layers of 8 heads x 8 (models/gat.py:42-57) on 70 % / 90 % dense graphs: every K2 call of both
+    layers, forward and backward, takes the dense matrix-pipe form (with the residual term of layers.py:38-40 when asked);
+    loss, logits and gradients equal the lean CSR kernels' on the same dropout draws."""
+    from han_amd import ops, rng as hrng
+    prob = make_problem(5, 400, 11, 2, 3, [0.7, 0.9], hid_units=[8, 8], n_heads=(8, 8, 1), residual=residual)
+    model, _ = build_model(prob, dev)
+    x, graphs = gpu_inputs(prob, dev)
+    labels = _t(prob["labels"], dev, torch.int32)
+    mask = _t(prob["mask"].astype(np.uint8), dev, torch.uint8)
+    res = {}
+    for dense in (True, False):
+        monkeypatch.setattr(ops, "DENSE", dense)
+        calls = []
+        real = ops._use_dense
+        monkeypatch.setattr(ops, "_use_dense", lambda g, t, k_, fp_, real=real: calls.append(real(g, t, k_, fp_)) or calls[-1])
+        hrng.manual_seed(9)
+        model.zero_grad_flat()
+        M = model.node_level([x] * 2, graphs, 0.5, 0.5, True, ops.ACT_ELU)
+        Z, _ = model.semantic(M)
+        loss, _, logits = model.classifier_loss(Z, labels, mask, 1.0 / int(prob["mask"].sum()))
+        loss.backward()
+        monkeypatch.setattr(ops, "_use_dense", real)
+        assert len(calls) == 8 and all(c_ == dense for c_ in calls)      # 2 layers x 2 meta-paths x (forward, backward)
+        res[dense] = (float(loss.detach()), logits.detach().clone(), model.flat_grad.detach().clone())
+    a, b = res[True], res[False]
+    assert abs(a[0] - b[0]) < 2e-5 and float((a[1] - b[1]).abs().max()) < 1e-4
+    assert float((a[2] - b[2]).abs().max()) < 1e-4 * (float(b[2].abs().max()) + 1.0)
+
+
 def test_return_coef_and_hetegat_class(dev):
     """attn_head(..., return_coef=True) (layers.py:43-44) and HeteGAT.inference(...,
     return_coef=True) (models/gat.py:132-203: shared inputs, head-mean coefficients per
