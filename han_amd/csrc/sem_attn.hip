@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void sem_attn_fwd_wave_kernel(const float *__r
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 sa_bf16x8 __attribute__((ext_vector_type(8)));
 typedef int sa_i32x4 __attribute__((ext_vector_type(4)));
-constexpr int SA_WLDB = 144;     // bytes per LDS row of the transposed, split Womega: 64 bf16 + 16 B
+constexpr int SA_WLDB = 160;     // bytes per LDS row of the transposed, split Womega: 64 bf16 + 32 B -- with rows of
+                                 // 160 B a ds_read_b128 lane group (tools/lds_banks.py) lands on 64 different banks
 
 __device__ __forceinline__ void sa_split(float x, uint32_t &h, uint32_t &m, uint32_t &l) {
     h = __float_as_uint(x) & 0xFFFF0000u;             // x == h + m + l exactly (8 + 8 + 8 significand bits)
@@ -855,10 +856,24 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_kernel(const float *__r
     for (int i = threadIdx.x; i < 64 * A + 2 * A; i += 256) out[i] = red[i];
 }
 
+// First attention column of the eight a lane group l4 contributes to step s of G2's reduction (see the kernel's header).
+template <int CA>
+__device__ __forceinline__ int g2_col(int s, int l4) {
+    if constexpr (CA == 2) return 64 * (l4 & 1) + 32 * (l4 >> 1) + 8 * s;
+    else return 32 * s + 8 * l4;
+}
+
 // The wave-local backward with G1 (recompute of pre) and G2 (dM = dpre . Womega^T) on the bf16 matrix pipe
 // (exact 3-way split, fp32-class accuracy: see sem_attn_fwd_wave_b6_kernel); G3 (dWomega += M^T dpre, whose
 // reduction runs over the 16 rows of a tile -- half a K = 32 step) stays on the fp32 pipe.  Womega is split
-// twice into LDS at block start: transposed [a][k] for G1, as stored [f][a] for G2.
+// twice into LDS at block start: transposed [a][k] for G1, [f][a] for G2.
+//
+// Which feature a lane index stands for is chosen so that no operand is loaded twice: in G3's A operand and in
+// G2's output, index i of the 16 x 16 tile number ft is feature 4 i + ft -- the four features a lane already holds
+// of each of its rows (the float4 row loads of M and dZ) are then its G3 operands and the start values of its G2
+// accumulators, and a row of dM leaves as one 16-byte store per lane.  G2's reduction index (the attention
+// column) is ordered so that the 16-byte reads of the dpre tile and of the split Womega are bank-conflict free
+// (CA = 2: k-slot (l4, j) of step s is column 64 (l4 & 1) + 32 (l4 >> 1) + 8 s + j).
 template <int CA, int P>
 __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *__restrict__ M, const float *Wg,
                                                                 const float *bw, const float *uw,
@@ -867,7 +882,7 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
     constexpr int A = 64 * CA;
     constexpr int TA = A / 16;
     constexpr int WLD2 = A + 4;                 // dpre tile rows: 16-B aligned for the 8-float fragment reads
-    constexpr int W2LDB = A * 2 + 16;           // bytes per row of the split Womega [f][a] (G2's B operand)
+    constexpr int W2LDB = A * 2 + 32;           // bytes per row of the split Womega [f][a] (G2's B operand)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned char *Wt = reinterpret_cast<unsigned char *>(smem);        // G1 B operand: [3][A][144 B]   (transposed [a][k])
     unsigned char *W2s = Wt + 3 * A * SA_WLDB;                          // G2 B operand: [3][64 f][W2LDB] (as stored [f][a])
@@ -884,14 +899,16 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
         *reinterpret_cast<sa_i32x4 *>(dst + A * SA_WLDB) = fm;
         *reinterpret_cast<sa_i32x4 *>(dst + 2 * A * SA_WLDB) = fl;
     }
-    for (int it = threadIdx.x; it < 64 * (A / 8); it += 256) {          // (f, g): a-values 8g..8g+7 of row f
-        const int f = it / (A / 8), g = it % (A / 8);
+    for (int it = threadIdx.x; it < 64 * (A / 8); it += 256) {          // (row, g): the g-th 16-byte piece of an LDS row
+        const int lr = it / (A / 8), g = it % (A / 8);
+        const int f = 4 * (lr & 15) + (lr >> 4);                        // row 16 ft + i holds feature 4 i + ft
+        const int a0 = g2_col<CA>(g >> 2, g & 3);                       // piece g = step g / 4, lane group g % 4
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = Wg[f * A + 8 * g + j];
+        for (int j = 0; j < 8; ++j) v[j] = Wg[f * A + a0 + j];
         sa_i32x4 fh, fm, fl;
         sa_split8(v, fh, fm, fl);
-        unsigned char *dst = W2s + f * W2LDB + g * 16;
+        unsigned char *dst = W2s + lr * W2LDB + g * 16;
         *reinterpret_cast<sa_i32x4 *>(dst) = fh;
         *reinterpret_cast<sa_i32x4 *>(dst + 64 * W2LDB) = fm;
         *reinterpret_cast<sa_i32x4 *>(dst + 2 * 64 * W2LDB) = fl;
@@ -948,11 +965,14 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
         const int64_t g0 = r0 + 4 * l4;           // first row of this lane group
         // ---- d beta, d s inside the lane group (lane = features 4*l15 .. 4*l15+3)
         float ds[4], bt[4];
+        float4_t mvc[4], dzc[4];      // this tile's rows: features 4 l15 .. 4 l15 + 3 of rows g0 .. g0 + 3
         {
             float dbt[4];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const float4_t mv = mv_n[rr], dz = dz_n[rr];
+                mvc[rr] = mv;
+                dzc[rr] = dz;
                 float d = mv[0] * dz[0] + mv[1] * dz[1] + mv[2] * dz[2] + mv[3] * dz[3];
                 d = han_row16_sum(d);
                 dbt[rr] = d;
@@ -981,13 +1001,6 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
         f32x4 acc[TA];
 #pragma unroll
         for (int t = 0; t < TA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float dzt[4][4];      // dZ of this tile's rows in the accumulator layout (L2 hits, used by G2)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int64_t rg = g0 + reg < R ? g0 + reg : R - 1;
-#pragma unroll
-            for (int ft = 0; ft < 4; ++ft) dzt[reg][ft] = dZ[(rg / P) * 64 + 16 * ft + l15];
-        }
         {
             sa_i32x4 af[2][3];     // G1's A fragments: exact 3-way bf16 split of this tile's rows
 #pragma unroll
@@ -1004,14 +1017,7 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
                 araw[2] = *reinterpret_cast<const float4_t *>(mr + 32);
                 araw[3] = *reinterpret_cast<const float4_t *>(mr + 36);
             }
-            // G3's A operand: this tile's rows, feature-major per lane (L2 hits)
-            float g3a[4][4];
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int64_t rg = g0 + reg < R ? g0 + reg : R - 1;     // dpre of a padding row is 0
-#pragma unroll
-                for (int ft = 0; ft < 4; ++ft) g3a[reg][ft] = M[rg * 64 + l15 + 16 * ft];
-            }
+            // G3's A operand is mvc: index i of tile ft = feature 4 i + ft (dpre of a padding row is 0)
             // Column tile by column tile: G1(t) -> dpre(t) -> G3(t).  The VALU work of dpre(t)
             // (tanh, products, LDS store) has no dependence on the MFMAs of G1(t+1), so the
             // scheduler can run it in their shadow instead of after all of G1.
@@ -1047,27 +1053,26 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
                 for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
                     for (int ft = 0; ft < 4; ++ft)
-                        dW[ft][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(g3a[reg][ft], acc[t][reg], dW[ft][t], 0, 0, 0);
+                        dW[ft][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(mvc[reg][ft], acc[t][reg], dW[ft][t], 0, 0, 0);
             }
         }
         // ---- G2: dMx = dpre . Womega^T   (A operand from the wave's LDS tile)
-        // the accumulators start at beta * dZ (the direct term of dM); its loads were issued
-        // before G1, so the epilogue is stores only
+        // the accumulators start at beta * dZ (the direct term of dM), so the epilogue is stores only
         f32x4 acc2[4];
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) acc2[ft][reg] = bt[reg] * dzt[reg][ft];
+            for (int reg = 0; reg < 4; ++reg) acc2[ft][reg] = bt[reg] * dzc[reg][ft];
 #pragma unroll
         for (int s2 = 0; s2 < A / 32; ++s2) {       // K = 32 columns of the attention space per step
-            const float4_t d0 = *reinterpret_cast<const float4_t *>(mydp + l15 * WLD2 + 32 * s2 + 8 * l4);
-            const float4_t d1 = *reinterpret_cast<const float4_t *>(mydp + l15 * WLD2 + 32 * s2 + 8 * l4 + 4);
+            const float4_t d0 = *reinterpret_cast<const float4_t *>(mydp + l15 * WLD2 + g2_col<CA>(s2, l4));
+            const float4_t d1 = *reinterpret_cast<const float4_t *>(mydp + l15 * WLD2 + g2_col<CA>(s2, l4) + 4);
             const float v[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
             sa_i32x4 ah, am, al;
             sa_split8(v, ah, am, al);
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft) {
-                const unsigned char *wb = W2s + (16 * ft + l15) * W2LDB + (32 * s2 + 8 * l4) * 2;
+                const unsigned char *wb = W2s + (16 * ft + l15) * W2LDB + (4 * s2 + l4) * 16;
                 const sa_i32x4 bh = *reinterpret_cast<const sa_i32x4 *>(wb);
                 const sa_i32x4 bm = *reinterpret_cast<const sa_i32x4 *>(wb + 64 * W2LDB);
                 const sa_i32x4 bl = *reinterpret_cast<const sa_i32x4 *>(wb + 2 * 64 * W2LDB);
@@ -1085,10 +1090,9 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int64_t row = g0 + reg;
-            if (row < R) {
-#pragma unroll
-                for (int ft = 0; ft < 4; ++ft) dM[row * 64 + 16 * ft + l15] = acc2[ft][reg];
-            }
+            if (row < R)
+                *reinterpret_cast<float4_t *>(dM + row * 64 + 4 * l15) =
+                    (float4_t){acc2[0][reg], acc2[1][reg], acc2[2][reg], acc2[3][reg]};
         }
     }
     // ---- parameter gradients: lane groups -> waves (LDS) -> slab row
@@ -1110,7 +1114,7 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
                 for (int t = 0; t < TA; ++t)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const int idx = (16 * ft + 4 * l4 + reg) * A + 16 * t + l15;
+                        const int idx = (16 * l4 + 4 * reg + ft) * A + 16 * t + l15;     // feature 4 i + ft, i = 4 l4 + reg
                         red[idx] = (ww == 0 ? 0.f : red[idx]) + dW[ft][t][reg];
                     }
             if (l4 == 0) {
@@ -1721,7 +1725,7 @@ int launch_bwd(const float *M, const float *w, const float *b, const float *u, c
         const int grid = han_grid_for(N * P, 64, kSemBwdBlocks);
         *grid_out = grid;
         constexpr int A6 = 64 * CA;
-        const size_t blds = (size_t)3 * A6 * SA_WLDB + (size_t)3 * 64 * (A6 * 2 + 16) + (size_t)4 * 16 * (A6 + 4) * sizeof(float);
+        const size_t blds = (size_t)3 * A6 * SA_WLDB + (size_t)3 * 64 * (A6 * 2 + 32) + (size_t)4 * 16 * (A6 + 4) * sizeof(float);
         hipError_t e3 = hipSuccess;
 #define HAN_LAUNCH_BWD_B6(PV)                                                                            \
     e3 = hipFuncSetAttribute((const void *)sem_attn_bwd_wave_b6_kernel<CA, PV>,                          \
