@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void sem_attn_fwd_wave_kernel(const float *__r
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 sa_bf16x8 __attribute__((ext_vector_type(8)));
 typedef int sa_i32x4 __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
 constexpr int SA_WLDB = 160;     // bytes per LDS row of the transposed, split Womega: 64 bf16 + 32 B -- with rows of
                                  // 160 B a ds_read_b128 lane group (tools/lds_banks.py) lands on 64 different banks
 
@@ -864,8 +865,13 @@ __device__ __forceinline__ int g2_col(int s, int l4) {
 }
 
 // The wave-local backward with G1 (recompute of pre) and G2 (dM = dpre . Womega^T) on the bf16 matrix pipe
-// (exact 3-way split, fp32-class accuracy: see sem_attn_fwd_wave_b6_kernel); G3 (dWomega += M^T dpre, whose
-// reduction runs over the 16 rows of a tile -- half a K = 32 step) stays on the fp32 pipe.  Womega is split
+// (exact 3-way split, fp32-class accuracy: see sem_attn_fwd_wave_b6_kernel).  G3 (dWomega += M^T dpre) reduces over
+// ROWS, 16 per tile -- half a K = 32 step: the wave therefore works on two of its tiles per loop pass and runs G3
+// once for both, also on the bf16 pipe (G3B; k-slot (l4, j) = tile j / 4, row 4 l4 + j % 4 -- exactly the four dpre
+// values per tile a lane's G1 accumulators hold and the four rows per tile whose features it loaded).  One wave
+// issues an fp32 16x16x4 MFMA every ~51 cycles but a bf16 16x16x32 every ~27
+// (profiles/r04_ubench_mfma_valu_overlap.jsonl): 96 bf16 instead of 128 fp32 MFMAs per tile, for ~260 more vector
+// instructions of splitting.  G3B = false keeps G3 on the fp32 pipe (tile by tile; measurements).  Womega is split
 // twice into LDS at block start: transposed [a][k] for G1, [f][a] for G2.
 //
 // Which feature a lane index stands for is chosen so that no operand is loaded twice: in G3's A operand and in
@@ -874,7 +880,7 @@ __device__ __forceinline__ int g2_col(int s, int l4) {
 // accumulators, and a row of dM leaves as one 16-byte store per lane.  G2's reduction index (the attention
 // column) is ordered so that the 16-byte reads of the dpre tile and of the split Womega are bank-conflict free
 // (CA = 2: k-slot (l4, j) of step s is column 64 (l4 & 1) + 32 (l4 >> 1) + 8 s + j).
-template <int CA, int P>
+template <int CA, int P, bool G3B>
 __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *__restrict__ M, const float *Wg,
                                                                 const float *bw, const float *uw,
                                                                 const float *beta, const float *dZ, float *dM,
@@ -960,7 +966,15 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
         araw[2] = *reinterpret_cast<const float4_t *>(mr + 32);
         araw[3] = *reinterpret_cast<const float4_t *>(mr + 36);
     }
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += tstride) {
+    for (int64_t tile0 = (int64_t)blockIdx.x * 4 + w; tile0 < ntiles; tile0 += 2 * tstride) {
+      f32x4 dps[2][TA];         // dpre of the two tiles (G3B)
+      float4_t mvs[2][4];
+      // the second tile of the last pass may lie past the end: its rows are clamped, beta = 0 makes every one of
+      // its contributions zero and its stores are masked
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t tile = tile0 + u * tstride;
+        if (!G3B && tile >= ntiles) break;
         const int64_t r0 = tile * 16;
         const int64_t g0 = r0 + 4 * l4;           // first row of this lane group
         // ---- d beta, d s inside the lane group (lane = features 4*l15 .. 4*l15+3)
@@ -972,6 +986,7 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
             for (int rr = 0; rr < 4; ++rr) {
                 const float4_t mv = mv_n[rr], dz = dz_n[rr];
                 mvc[rr] = mv;
+                mvs[u][rr] = mv;
                 dzc[rr] = dz;
                 float d = mv[0] * dz[0] + mv[1] * dz[1] + mv[2] * dz[2] + mv[3] * dz[3];
                 d = han_row16_sum(d);
@@ -1049,11 +1064,15 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
                     acc[t][reg] = d;
                     mydp[(4 * l4 + reg) * WLD2 + 16 * t + l15] = d;
                 }
+                if constexpr (G3B) {
+                    dps[u][t] = acc[t];
+                } else {
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
+                    for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-                    for (int ft = 0; ft < 4; ++ft)
-                        dW[ft][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(mvc[reg][ft], acc[t][reg], dW[ft][t], 0, 0, 0);
+                        for (int ft = 0; ft < 4; ++ft)
+                            dW[ft][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(mvc[reg][ft], acc[t][reg], dW[ft][t], 0, 0, 0);
+                }
             }
         }
         // ---- G2: dMx = dpre . Womega^T   (A operand from the wave's LDS tile)
@@ -1094,6 +1113,35 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
                 *reinterpret_cast<float4_t *>(dM + row * 64 + 4 * l15) =
                     (float4_t){acc2[0][reg], acc2[1][reg], acc2[2][reg], acc2[3][reg]};
         }
+      }
+      if constexpr (G3B) {
+        // ---- G3 for both tiles: dWomega[4 i + ft][16 t + n] += sum over the 32 rows of M[row][4 i + ft] dpre[row][16 t + n]
+        sa_i32x4 mf[4][3];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const float v[8] = {mvs[0][0][ft], mvs[0][1][ft], mvs[0][2][ft], mvs[0][3][ft],
+                                mvs[1][0][ft], mvs[1][1][ft], mvs[1][2][ft], mvs[1][3][ft]};
+            sa_split8(v, mf[ft][0], mf[ft][1], mf[ft][2]);
+        }
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            const float v[8] = {dps[0][t][0], dps[0][t][1], dps[0][t][2], dps[0][t][3],
+                                dps[1][t][0], dps[1][t][1], dps[1][t][2], dps[1][t][3]};
+            sa_i32x4 dh, dm, dl;
+            sa_split8(v, dh, dm, dl);
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                f32x4 c = dW[ft][t];
+                c = sa_mfma(mf[ft][1], dm, c);
+                c = sa_mfma(mf[ft][2], dh, c);
+                c = sa_mfma(mf[ft][0], dl, c);
+                c = sa_mfma(mf[ft][1], dh, c);
+                c = sa_mfma(mf[ft][0], dm, c);
+                c = sa_mfma(mf[ft][0], dh, c);
+                dW[ft][t] = c;
+            }
+        }
+      }
     }
     // ---- parameter gradients: lane groups -> waves (LDS) -> slab row
 #pragma unroll
@@ -1130,6 +1178,259 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
     }
     float *out = slab + (int64_t)blockIdx.x * (64 * A + 2 * A);
     for (int i = threadIdx.x; i < 64 * A + 2 * A; i += 256) out[i] = red[i];
+}
+
+// The same backward at A = 128 with TWO waves per SIMD.  One wave cannot keep the matrix pipe busy (a wave issues
+// an fp32 16x16x4 MFMA every ~51 cycles and a bf16 16x16x32 every ~27 where the pipe takes 32 / 16:
+// profiles/r04_ubench_mfma_valu_overlap.jsonl), and the kernel above needs 390 registers -- 128 of them the dW
+// accumulators of a 64 x 128 matrix -- so it runs one wave per SIMD.  Here two waves SHARE a tile of 16 rows: wave h
+// of the pair owns attention columns 64 h .. 64 h + 63 for G1, dpre and G3 (64 dW accumulators) and output tiles
+// ft = 2 h, 2 h + 1 for G2, whose A operand is the pair's complete dpre tile in LDS.  Eight waves (four pairs) per
+// block share one split Womega; the two block barriers per tile are executed by every wave for the same number of
+// tiles (a pair whose tile lies past the end works on clamped rows with beta = 0: all its contributions are zero
+// and its stores are masked).  The row-local work (d beta, d s) and G1's A fragments are computed by both waves.
+template <int P>
+__global__ __launch_bounds__(512) void sem_attn_bwd_pair_b6_kernel(const float *__restrict__ M, const float *Wg,
+                                                                const float *bw, const float *uw,
+                                                                const float *beta, const float *dZ, float *dM,
+                                                                float *slab, int64_t N) {
+    constexpr int CA = 2;
+    constexpr int A = 128;
+    constexpr int TH = 4;                       // column tiles per wave
+    constexpr int WLD2 = A + 4;
+    constexpr int W2LDB = A * 2 + 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char *Wt = reinterpret_cast<unsigned char *>(smem);        // G1 B operand: [3][A][SA_WLDB]
+    unsigned char *W2s = Wt + 3 * A * SA_WLDB;                          // G2 B operand: [3][64][W2LDB]
+    float *dp = reinterpret_cast<float *>(W2s + 3 * 64 * W2LDB);        // [4 pairs][16][WLD2] fp32
+    for (int it = threadIdx.x; it < A * 8; it += 512) {
+        const int acol = it % A, g = it / A;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Wg[(8 * g + j) * A + acol];
+        sa_i32x4 fh, fm, fl;
+        sa_split8(v, fh, fm, fl);
+        unsigned char *dst = Wt + acol * SA_WLDB + g * 16;
+        *reinterpret_cast<sa_i32x4 *>(dst) = fh;
+        *reinterpret_cast<sa_i32x4 *>(dst + A * SA_WLDB) = fm;
+        *reinterpret_cast<sa_i32x4 *>(dst + 2 * A * SA_WLDB) = fl;
+    }
+    for (int it = threadIdx.x; it < 64 * (A / 8); it += 512) {
+        const int lr = it / (A / 8), g = it % (A / 8);
+        const int f = 4 * (lr & 15) + (lr >> 4);
+        const int a0 = g2_col<CA>(g >> 2, g & 3);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Wg[f * A + a0 + j];
+        sa_i32x4 fh, fm, fl;
+        sa_split8(v, fh, fm, fl);
+        unsigned char *dst = W2s + lr * W2LDB + g * 16;
+        *reinterpret_cast<sa_i32x4 *>(dst) = fh;
+        *reinterpret_cast<sa_i32x4 *>(dst + 64 * W2LDB) = fm;
+        *reinterpret_cast<sa_i32x4 *>(dst + 2 * 64 * W2LDB) = fl;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pair = w >> 1;
+    const int h = __builtin_amdgcn_readfirstlane(w & 1);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    float bcol[TH], ucol[TH], du[TH], db[TH];
+    f32x4 dW[4][TH];
+#pragma unroll
+    for (int t = 0; t < TH; ++t) {
+        bcol[t] = bw[64 * h + 16 * t + l15];
+        ucol[t] = uw[64 * h + 16 * t + l15];
+        du[t] = 0.f;
+        db[t] = 0.f;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) dW[ft][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float *mydp = dp + pair * 16 * WLD2;
+    __syncthreads();
+    const int64_t R = N * P;
+    const int64_t ntiles = (R + 15) / 16;
+    const int64_t tstride = (int64_t)gridDim.x * 4;
+    float4_t mv_n[4], dz_n[4];
+    float bt_n[4];
+    // the next tile's rows: dZ and beta are requested at the top of a tile, the M rows (which stay G3's A operand
+    // until G3 is done) after G3 -- by then G1's fragment loads of the same rows have pulled them into the caches
+    auto fetch_dz = [&](int64_t tile) {
+        const int64_t g0n = tile * 16 + 4 * l4;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t row = g0n + rr;
+            const bool ok = row < R;
+            const int64_t rc = ok ? row : R - 1;
+            dz_n[rr] = *reinterpret_cast<const float4_t *>(dZ + (rc / P) * 64 + 4 * l15);
+            bt_n[rr] = ok ? beta[rc] : 0.f;
+        }
+    };
+    auto fetch_mv = [&](int64_t tile) {
+        const int64_t g0n = tile * 16 + 4 * l4;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t rc = g0n + rr < R ? g0n + rr : R - 1;
+            mv_n[rr] = *reinterpret_cast<const float4_t *>(M + rc * 64 + 4 * l15);
+        }
+    };
+    float4_t araw[4];
+    auto fetch_a = [&](int64_t tile) {
+        const int64_t ra = tile * 16 + l15 < R ? tile * 16 + l15 : R - 1;
+        const float *mr = M + ra * 64 + 8 * l4;
+        araw[0] = *reinterpret_cast<const float4_t *>(mr);
+        araw[1] = *reinterpret_cast<const float4_t *>(mr + 4);
+        araw[2] = *reinterpret_cast<const float4_t *>(mr + 32);
+        araw[3] = *reinterpret_cast<const float4_t *>(mr + 36);
+    };
+    fetch_dz((int64_t)blockIdx.x * 4 + pair);
+    fetch_mv((int64_t)blockIdx.x * 4 + pair);
+    fetch_a((int64_t)blockIdx.x * 4 + pair);
+    // every wave of the block runs the same number of tiles: the barriers below are block-wide
+    for (int64_t base = (int64_t)blockIdx.x * 4; base < ntiles; base += tstride) {
+        const int64_t tile = base + pair;
+        const int64_t r0 = tile * 16;
+        const int64_t g0 = r0 + 4 * l4;
+        float ds[4], bt[4];
+        f32x4 acc2[2];            // G2's accumulators start at beta * dZ (the direct term of dM)
+        {
+            float dbt[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float4_t mv = mv_n[rr], dz = dz_n[rr];
+                bt[rr] = bt_n[rr];
+                acc2[0][rr] = bt[rr] * (h ? dz[2] : dz[0]);
+                acc2[1][rr] = bt[rr] * (h ? dz[3] : dz[1]);
+                float d = mv[0] * dz[0] + mv[1] * dz[1] + mv[2] * dz[2] + mv[3] * dz[3];
+                d = han_row16_sum(d);
+                dbt[rr] = d;
+            }
+            fetch_dz(tile + tstride);
+            if constexpr (P <= 4) {
+#pragma unroll
+                for (int k = 0; k < 4 / P; ++k) {
+                    float S = 0.f;
+#pragma unroll
+                    for (int p2 = 0; p2 < P; ++p2) S += bt[k * P + p2] * dbt[k * P + p2];
+#pragma unroll
+                    for (int p2 = 0; p2 < P; ++p2) ds[k * P + p2] = bt[k * P + p2] * (dbt[k * P + p2] - S);
+                }
+            } else {
+                float S = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) S += bt[rr] * dbt[rr];
+                S = node_xsum<P>(S);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) ds[rr] = bt[rr] * (dbt[rr] - S);
+            }
+        }
+        {
+            sa_i32x4 af[2][3];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float v[8] = {araw[2 * s2][0], araw[2 * s2][1], araw[2 * s2][2], araw[2 * s2][3],
+                                    araw[2 * s2 + 1][0], araw[2 * s2 + 1][1], araw[2 * s2 + 1][2], araw[2 * s2 + 1][3]};
+                sa_split8(v, af[s2][0], af[s2][1], af[s2][2]);
+            }
+            fetch_a(tile + tstride);
+#pragma unroll
+            for (int t = 0; t < TH; ++t) {
+                f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const unsigned char *wb = Wt + (64 * h + 16 * t + l15) * SA_WLDB + (32 * s2 + 8 * l4) * 2;
+                    const sa_i32x4 bh = *reinterpret_cast<const sa_i32x4 *>(wb);
+                    const sa_i32x4 bm = *reinterpret_cast<const sa_i32x4 *>(wb + A * SA_WLDB);
+                    const sa_i32x4 bl = *reinterpret_cast<const sa_i32x4 *>(wb + 2 * A * SA_WLDB);
+                    c = sa_mfma(af[s2][1], bm, c);
+                    c = sa_mfma(af[s2][2], bh, c);
+                    c = sa_mfma(af[s2][0], bl, c);
+                    c = sa_mfma(af[s2][1], bh, c);
+                    c = sa_mfma(af[s2][0], bm, c);
+                    c = sa_mfma(af[s2][0], bh, c);
+                }
+                if (t == 0) __syncthreads();      // the pair's previous tile has been read by both of its waves
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float v = fast_tanh(c[reg] + bcol[t]);
+                    const float d = ds[reg] * ucol[t] * (1.f - v * v);
+                    du[t] += ds[reg] * v;
+                    db[t] += d;
+                    c[reg] = d;
+                    mydp[(4 * l4 + reg) * WLD2 + 64 * h + 16 * t + l15] = d;
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                    for (int ft = 0; ft < 4; ++ft)
+                        dW[ft][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(mv_n[reg][ft], c[reg], dW[ft][t], 0, 0, 0);
+            }
+        }
+        fetch_mv(tile + tstride);
+        __syncthreads();                          // both halves of the pair's dpre tile are in LDS
+#pragma unroll
+        for (int s2 = 0; s2 < A / 32; ++s2) {
+            const float4_t d0 = *reinterpret_cast<const float4_t *>(mydp + l15 * WLD2 + g2_col<CA>(s2, l4));
+            const float4_t d1 = *reinterpret_cast<const float4_t *>(mydp + l15 * WLD2 + g2_col<CA>(s2, l4) + 4);
+            const float v[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+            sa_i32x4 ah, am, al;
+            sa_split8(v, ah, am, al);
+#pragma unroll
+            for (int f2 = 0; f2 < 2; ++f2) {
+                const unsigned char *wb = W2s + (16 * (2 * h + f2) + l15) * W2LDB + (4 * s2 + l4) * 16;
+                const sa_i32x4 bh = *reinterpret_cast<const sa_i32x4 *>(wb);
+                const sa_i32x4 bm = *reinterpret_cast<const sa_i32x4 *>(wb + 64 * W2LDB);
+                const sa_i32x4 bl = *reinterpret_cast<const sa_i32x4 *>(wb + 2 * 64 * W2LDB);
+                f32x4 c = acc2[f2];
+                c = sa_mfma(am, bm, c);
+                c = sa_mfma(al, bh, c);
+                c = sa_mfma(ah, bl, c);
+                c = sa_mfma(am, bh, c);
+                c = sa_mfma(ah, bm, c);
+                c = sa_mfma(ah, bh, c);
+                acc2[f2] = c;
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t row = g0 + reg;
+            if (row < R)
+                *reinterpret_cast<float2_t *>(dM + row * 64 + 4 * l15 + 2 * h) = (float2_t){acc2[0][reg], acc2[1][reg]};
+        }
+    }
+    // ---- parameter gradients: lane groups -> pairs (LDS) -> slab row
+#pragma unroll
+    for (int t = 0; t < TH; ++t) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            du[t] += __shfl_xor(du[t], o, 64);
+            db[t] += __shfl_xor(db[t], o, 64);
+        }
+    }
+    __syncthreads();
+    float *red = smem;   // [64*A] dW | [A] db | [A] du  (fits inside the split-Womega region)
+    for (int pp = 0; pp < 4; ++pp) {
+        if (pair == pp) {     // the two waves of a pair own different columns
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+                for (int t = 0; t < TH; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int idx = (16 * l4 + 4 * reg + ft) * A + 64 * h + 16 * t + l15;
+                        red[idx] = (pp == 0 ? 0.f : red[idx]) + dW[ft][t][reg];
+                    }
+            if (l4 == 0) {
+#pragma unroll
+                for (int t = 0; t < TH; ++t) {
+                    const int idx = 64 * A + 64 * h + 16 * t + l15;
+                    red[idx] = (pp == 0 ? 0.f : red[idx]) + db[t];
+                    red[idx + A] = (pp == 0 ? 0.f : red[idx + A]) + du[t];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *out = slab + (int64_t)blockIdx.x * (64 * A + 2 * A);
+    for (int i = threadIdx.x; i < 64 * A + 2 * A; i += 512) out[i] = red[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1727,11 +2028,17 @@ int launch_bwd(const float *M, const float *w, const float *b, const float *u, c
         constexpr int A6 = 64 * CA;
         const size_t blds = (size_t)3 * A6 * SA_WLDB + (size_t)3 * 64 * (A6 * 2 + 32) + (size_t)4 * 16 * (A6 + 4) * sizeof(float);
         hipError_t e3 = hipSuccess;
+#define HAN_LAUNCH_BWD_B6_AS(KERNEL, THREADS)                                                            \
+    e3 = hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds); \
+    if (e3 == hipSuccess) KERNEL<<<grid, THREADS, blds, st>>>(M, w, b, u, beta, dZ, dM, slab, N);
 #define HAN_LAUNCH_BWD_B6(PV)                                                                            \
-    e3 = hipFuncSetAttribute((const void *)sem_attn_bwd_wave_b6_kernel<CA, PV>,                          \
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);                     \
-    if (e3 == hipSuccess)                                                                                \
-        sem_attn_bwd_wave_b6_kernel<CA, PV><<<grid, 256, blds, st>>>(M, w, b, u, beta, dZ, dM, slab, N);
+    if (CA == 2 && (flags & HAN_FLAG_K3_PAIRS)) {                                                        \
+        HAN_LAUNCH_BWD_B6_AS((sem_attn_bwd_pair_b6_kernel<PV>), 512)                                     \
+    } else if (flags & HAN_FLAG_K3_G3_F32) {                                                             \
+        HAN_LAUNCH_BWD_B6_AS((sem_attn_bwd_wave_b6_kernel<CA, PV, false>), 256)                          \
+    } else {                                                                                             \
+        HAN_LAUNCH_BWD_B6_AS((sem_attn_bwd_wave_b6_kernel<CA, PV, true>), 256)                           \
+    }
         switch (P) {
             case 1: HAN_LAUNCH_BWD_B6(1) break;
             case 2: HAN_LAUNCH_BWD_B6(2) break;
@@ -1740,6 +2047,7 @@ int launch_bwd(const float *M, const float *w, const float *b, const float *u, c
             default: HAN_LAUNCH_BWD_B6(16) break;
         }
 #undef HAN_LAUNCH_BWD_B6
+#undef HAN_LAUNCH_BWD_B6_AS
         if (e3 != hipSuccess) return (int)e3;
         HAN_CHECK_LAUNCH();
         return 0;

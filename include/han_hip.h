@@ -73,6 +73,10 @@ extern "C" {
 #define HAN_FLAG_FTS_SLICE_OF(fl) (((fl) >> 8) & 0xFF)
 /* `flags` of han_sem_attn_fwd / han_sem_attn_bwd */
 #define HAN_FLAG_K3_EXACT_PIPE  8   /* fp32 MFMA kernels also for large inputs (default: bf16 x 6 from 65 536 rows) */
+#define HAN_FLAG_K3_PAIRS      16   /* measurements only: han_sem_attn_bwd at mp_att_size = 128 with two waves sharing a tile
+                                     * (two waves per SIMD, 64 attention columns each) -- not faster: DESIGN.md section 3 */
+#define HAN_FLAG_K3_G3_F32     32   /* measurements only: han_sem_attn_bwd's dW product on the fp32 matrix pipe, tile by tile
+                                     * (the round-3 form) instead of two tiles per step on the bf16 pipe                   */
 
 /* storage type of X and of the gather tables H / g ("bf16 feats" of the 10M-node
  * config): everything is accumulated in fp32; any head shape (8 x 8 is the tuned one) */

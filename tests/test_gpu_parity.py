@@ -661,6 +661,31 @@ def test_semantic_attention_fwd_bwd(dev, n, p, a, d):
     assert rel_err(du.cpu().numpy(), tu.grad.numpy()) < GTOL
 
 
+@pytest.mark.parametrize("n,p,a", [(20000, 4, 128), (9000, 8, 128), (70001, 1, 128), (16400, 4, 64)])
+@pytest.mark.parametrize("form", ["g3_f32", "pairs"])
+def test_semantic_attention_bwd_measurement_forms(dev, n, p, a, form):
+    """The two measurement-only forms of the large-input K3 backward (HAN_FLAG_K3_G3_F32: dW product on the fp32
+    pipe, tile by tile; HAN_FLAG_K3_PAIRS: two waves share a tile) against the default form (two tiles per pass,
+    dW product on the bf16 pipe) and the fp64 autograd of utils/layers.py:132-164 -- also with an odd number of
+    tiles per wave and a last tile of one row (70001 rows)."""
+    from han_amd import ops
+    rng = np.random.default_rng(n + p)
+    M = rng.standard_normal((n, p, 64))
+    w, b, u = rng.standard_normal((64, a)) * 0.2, rng.standard_normal(a) * 0.2, rng.standard_normal(a)
+    dZ = rng.standard_normal((n, 64))
+    gM, gw, gb, gu = _t(M, dev), _t(w, dev), _t(b, dev), _t(u, dev)
+    _, beta = ops.sem_attn_fwd(gM, gw, gb, gu)
+    flag = ops.FLAG_K3_G3_F32 if form == "g3_f32" else ops.FLAG_K3_PAIRS
+    ref = ops.sem_attn_bwd(gM, gw, gb, gu, beta, _t(dZ, dev))
+    got = ops.sem_attn_bwd(gM, gw, gb, gu, beta, _t(dZ, dev), flags=flag)
+    tM, tw, tb, tu = (torch.tensor(v, requires_grad=True) for v in (M, w, b, u))
+    Zt, _ = ht.semantic_attention(tM, tw, tb, tu)
+    (Zt * torch.tensor(dZ)).sum().backward()
+    for g, r, t64 in zip(got, ref, (tM.grad, tw.grad, tb.grad, tu.grad)):
+        assert rel_err(g.cpu().numpy(), t64.numpy()) < GTOL
+        assert rel_err(g.cpu().numpy(), r.cpu().numpy()) < GTOL
+
+
 def test_empty_inputs_are_noops(dev):
     """N == 0 / E == 0 through the C ABI: every entry point returns without launching
     (edge case of SURVEY.md section 4: empty inputs)."""

@@ -42,8 +42,12 @@ def main():
         t = timeit(lambda: ops.sem_attn_fwd(M, w, b, u))
         fl = 2.0 * n * p * 64 * 128
         print(json.dumps({"kernel": "sem_attn_fwd", "ms": round(t, 4), "TFLOPs": round(fl / t / 1e9, 1)}))
-        t = timeit(lambda: ops.sem_attn_bwd(M, w, b, u, beta, dZ))
-        print(json.dumps({"kernel": "sem_attn_bwd", "ms": round(t, 4), "TFLOPs": round(3 * fl / t / 1e9, 1)}))
+        # k3forms=1: also the measurement-only forms (HAN_FLAG_K3_G3_F32 = 32, HAN_FLAG_K3_PAIRS = 16), same process
+        forms = (("", 0), (" [G3 on the fp32 pipe]", 32), (" [two waves share a tile]", 16)) * 3 \
+            if kv.get("k3forms") == "1" else (("", 0),)
+        for tag, fl_ in forms:
+            t = timeit(lambda: ops.sem_attn_bwd(M, w, b, u, beta, dZ, flags=fl_))
+            print(json.dumps({"kernel": "sem_attn_bwd" + tag, "ms": round(t, 4), "TFLOPs": round(3 * fl / t / 1e9, 1)}))
         del M, dZ, Z, beta
     if "k2" in which:
         from han_amd import synth
