@@ -297,16 +297,20 @@ __device__ __forceinline__ f32x4 sa_mfma(const sa_i32x4 &a, const sa_i32x4 &b, c
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sa_bf16x8, a), __builtin_bit_cast(sa_bf16x8, b),
                                                    c, 0, 0, 0);
 }
-// 8 consecutive floats -> the three packed bf16x8 fragments
+// 8 consecutive floats -> the three packed bf16x8 fragments.  Two values at a time: the two subtractions of the
+// split are packed (v_pk_add_f32), 4.5 instead of 5.5 vector instructions per value.
 __device__ __forceinline__ void sa_split8(const float (&v)[8], sa_i32x4 &fh, sa_i32x4 &fm, sa_i32x4 &fl) {
-    uint32_t h[8], m[8], l[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) sa_split(v[j], h[j], m[j], l[j]);
+    typedef uint32_t sa_u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        fh[q] = (int)sa_pack(h[2 * q], h[2 * q + 1]);
-        fm[q] = (int)sa_pack(m[2 * q], m[2 * q + 1]);
-        fl[q] = (int)sa_pack(l[2 * q], l[2 * q + 1]);
+        const float2_t x = {v[2 * q], v[2 * q + 1]};
+        const sa_u32x2 hb = __builtin_bit_cast(sa_u32x2, x) & 0xFFFF0000u;
+        const float2_t r1 = x - __builtin_bit_cast(float2_t, hb);
+        const sa_u32x2 mb = __builtin_bit_cast(sa_u32x2, r1) & 0xFFFF0000u;
+        const sa_u32x2 lb = __builtin_bit_cast(sa_u32x2, r1 - __builtin_bit_cast(float2_t, mb));
+        fh[q] = (int)sa_pack(hb[0], hb[1]);
+        fm[q] = (int)sa_pack(mb[0], mb[1]);
+        fl[q] = (int)sa_pack(lb[0], lb[1]);
     }
 }
 
@@ -967,8 +971,9 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
         araw[3] = *reinterpret_cast<const float4_t *>(mr + 36);
     }
     for (int64_t tile0 = (int64_t)blockIdx.x * 4 + w; tile0 < ntiles; tile0 += 2 * tstride) {
-      f32x4 dps[2][TA];         // dpre of the two tiles (G3B)
-      float4_t mvs[2][4];
+      f32x4 dps[TA];            // G3B: dpre of the pass's first tile, kept until the second tile's column tile t is done
+      float4_t mvs[4];          // G3B: the first tile's rows
+      sa_i32x4 mf[4][3];        // G3B: G3's A fragments, M^T of both tiles (k-slot (l4, j) = tile j / 4, row 4 l4 + j % 4)
       // the second tile of the last pass may lie past the end: its rows are clamped, beta = 0 makes every one of
       // its contributions zero and its stores are masked
 #pragma unroll
@@ -986,7 +991,7 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
             for (int rr = 0; rr < 4; ++rr) {
                 const float4_t mv = mv_n[rr], dz = dz_n[rr];
                 mvc[rr] = mv;
-                mvs[u][rr] = mv;
+                if (G3B && u == 0) mvs[rr] = mv;
                 dzc[rr] = dz;
                 float d = mv[0] * dz[0] + mv[1] * dz[1] + mv[2] * dz[2] + mv[3] * dz[3];
                 d = han_row16_sum(d);
@@ -1010,6 +1015,14 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
                 S = node_xsum<P>(S);
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) ds[rr] = bt[rr] * (dbt[rr] - S);
+            }
+        }
+        if (G3B && u == 1) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const float v[8] = {mvs[0][ft], mvs[1][ft], mvs[2][ft], mvs[3][ft],
+                                    mvc[0][ft], mvc[1][ft], mvc[2][ft], mvc[3][ft]};
+                sa_split8(v, mf[ft][0], mf[ft][1], mf[ft][2]);
             }
         }
         // ---- G1: pre = M_tile . Womega
@@ -1065,7 +1078,27 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
                     mydp[(4 * l4 + reg) * WLD2 + 16 * t + l15] = d;
                 }
                 if constexpr (G3B) {
-                    dps[u][t] = acc[t];
+                    // G3 of both tiles' column tile t: dWomega[4 i + ft][16 t + n] += sum over the 32 rows of
+                    // M[row][4 i + ft] dpre[row][16 t + n]
+                    if (u == 0) {
+                        dps[t] = acc[t];
+                    } else {
+                        const float v[8] = {dps[t][0], dps[t][1], dps[t][2], dps[t][3],
+                                            acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+                        sa_i32x4 dh, dm, dl;
+                        sa_split8(v, dh, dm, dl);
+#pragma unroll
+                        for (int ft = 0; ft < 4; ++ft) {
+                            f32x4 c = dW[ft][t];
+                            c = sa_mfma(mf[ft][1], dm, c);
+                            c = sa_mfma(mf[ft][2], dh, c);
+                            c = sa_mfma(mf[ft][0], dl, c);
+                            c = sa_mfma(mf[ft][1], dh, c);
+                            c = sa_mfma(mf[ft][0], dm, c);
+                            c = sa_mfma(mf[ft][0], dh, c);
+                            dW[ft][t] = c;
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg)
@@ -1112,34 +1145,6 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
             if (row < R)
                 *reinterpret_cast<float4_t *>(dM + row * 64 + 4 * l15) =
                     (float4_t){acc2[0][reg], acc2[1][reg], acc2[2][reg], acc2[3][reg]};
-        }
-      }
-      if constexpr (G3B) {
-        // ---- G3 for both tiles: dWomega[4 i + ft][16 t + n] += sum over the 32 rows of M[row][4 i + ft] dpre[row][16 t + n]
-        sa_i32x4 mf[4][3];
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft) {
-            const float v[8] = {mvs[0][0][ft], mvs[0][1][ft], mvs[0][2][ft], mvs[0][3][ft],
-                                mvs[1][0][ft], mvs[1][1][ft], mvs[1][2][ft], mvs[1][3][ft]};
-            sa_split8(v, mf[ft][0], mf[ft][1], mf[ft][2]);
-        }
-#pragma unroll
-        for (int t = 0; t < TA; ++t) {
-            const float v[8] = {dps[0][t][0], dps[0][t][1], dps[0][t][2], dps[0][t][3],
-                                dps[1][t][0], dps[1][t][1], dps[1][t][2], dps[1][t][3]};
-            sa_i32x4 dh, dm, dl;
-            sa_split8(v, dh, dm, dl);
-#pragma unroll
-            for (int ft = 0; ft < 4; ++ft) {
-                f32x4 c = dW[ft][t];
-                c = sa_mfma(mf[ft][1], dm, c);
-                c = sa_mfma(mf[ft][2], dh, c);
-                c = sa_mfma(mf[ft][0], dl, c);
-                c = sa_mfma(mf[ft][1], dh, c);
-                c = sa_mfma(mf[ft][0], dm, c);
-                c = sa_mfma(mf[ft][0], dh, c);
-                dW[ft][t] = c;
-            }
         }
       }
     }
