@@ -538,6 +538,11 @@ def main():
     ap.add_argument("--reorder", choices=("none", "bfs"), default="none",
                     help="locality pass (han_amd.reorder): breadth-first relabelling of the nodes before training "
                          "(single GPU; the pass itself is timed separately and reported)")
+    ap.add_argument("--side-stream", action="store_true",
+                    help="HANTrainer(side_stream=True): the backward's dW of meta-path p on a second stream beside the "
+                         "gather of meta-path p + 1 (+1.3-2.5 %% epochs/s at SYN-1M; off by default because the gather's "
+                         "launch time -- the line's roofline -- then includes that company; the line carries "
+                         "roofline.alone beside it)")
     ap.add_argument("--no-dense", action="store_true",
                     help="keep small dense graphs on the lean CSR kernels (measurements: the matrix-pipe K2 form off)")
     ap.add_argument("--table-dtype", choices=("f32", "bf16"), default="f32",
@@ -635,7 +640,8 @@ def main():
     trainer = HANTrainer(model, [wl["x"]] * p, wl["graphs"], wl["labels"], wl["train_mask"],
                          wl["val_mask"], lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
                          part=part, use_graph=args.graph and part is None, graphs_local=part is not None,
-                         xs_full=[x_full] * p if x_full is not None else None, replicate=args.replicate)
+                         xs_full=[x_full] * p if x_full is not None else None, replicate=args.replicate,
+                         side_stream=bool(args.side_stream))
     exchange = None
     if part is not None:
         plans = model.halo_plans[0]
@@ -682,6 +688,18 @@ def main():
               "reserved GB %.1f allocated peak GB %.1f" % (ms1["reserved_bytes.all.current"] / 1e9,
                                                             ms1["allocated_bytes.all.peak"] / 1e9), file=sys.stderr)
     timing, ops.K2_TIMING = ops.K2_TIMING or [], None
+    # the training step runs dW of meta-path p on a second stream beside the backward gather of meta-path p + 1
+    # (HANTrainer(side_stream=...)): the gather's launch time in the timed region includes that company.  Two more
+    # epochs on one stream, outside the timed region, give the same kernels' launch times ALONE.
+    timing_alone = None
+    if model.side_stream is not None and not trainer.use_graph:
+        side, model.side_stream = model.side_stream, None
+        ops.K2_TIMING = []
+        for _ in range(2):
+            trainer.epoch()
+        torch.cuda.synchronize(dev)
+        timing_alone, ops.K2_TIMING = ops.K2_TIMING, None
+        model.side_stream = side
     comm_info = None
     if part is not None:
         part.comm = None
@@ -811,6 +829,17 @@ def main():
             # the K2 kernel with the largest total time in the timed region
             out["roofline"] = dict(roofs[dom], dominant_by="total time among the K2 kernels in the timed region")
             out["roofline_k2_all"] = roofs
+            if timing_alone:
+                alone = k2_rooflines(timing_alone, esz, regime, cache_served=cache_served)[0]
+                for key, r in roofs.items():
+                    if key in alone:
+                        r["alone"] = {k: alone[key][k] for k in ("avg_launch_ms", "achieved", "frac")}
+                out["roofline"]["alone"] = roofs[dom]["alone"]
+                out["roofline"]["co_scheduled"] = (
+                    "the training step runs K1's dW of meta-path p on a second stream beside the backward gather of "
+                    "meta-path p + 1 (3 of 4 launches): avg_launch_ms / achieved / frac are this kernel's launches in the "
+                    "timed region, WITH that company; `alone` = the same launches in two further epochs of this run "
+                    "on one stream (the default, without --side-stream, times the whole line that way)")
         else:
             out["roofline"] = None
             out["roofline_note"] = ("no per-kernel HIP events in this run (an epoch replayed from a hipGraph "

@@ -76,6 +76,38 @@ class _on_path:
             self.ctx.__exit__(*exc)
 
 
+class _on_side:
+    """Run the enclosed launches on the side stream (cfg["side_stream"]: single GPU, eager training step on large
+    graphs).  The backward's dW of meta-path p needs only dH_p, so it runs beside the transposed-graph gather of
+    meta-path p + 1: the gather is bound by the memory fabric and leaves vector / matrix issue slots that dW, bound by
+    exactly those, can use -- 2.70 + 0.52 ms one after the other, 2.95 ms side by side.  What was measured and is NOT
+    done: the forward's K1 of meta-path p + 1 beside K2 of meta-path p gains nothing (K2's blocks refill every slot
+    they free, K1's 8-wave blocks with 40 KB of LDS wait: 2.5 ms instead of 0.74, a higher stream priority changes
+    nothing, and CU masks only move the same CU time around: tools/cu_mask_probe.py); two K2 launches beside each
+    other evict each other's gather table from the Infinity Cache (four meta-path chains side by side: 40.7 ms per
+    epoch against 35.5).  Scratch buffers of the side stream are its own (ops.WS_SUFFIX)."""
+
+    def __init__(self, side):
+        self.s = side
+
+    def __enter__(self):
+        self.ctx = torch.cuda.stream(self.s)
+        self.ctx.__enter__()
+        self.prev, ops.WS_SUFFIX = ops.WS_SUFFIX, "@side"
+
+    def __exit__(self, *exc):
+        ops.WS_SUFFIX = self.prev
+        self.ctx.__exit__(*exc)
+
+
+def _used_on(stream, *tensors):
+    """Tensors allocated on one stream and read on another: tell the caching allocator, so that their memory is not
+    handed out again before that stream is done with it."""
+    for t in tensors:
+        if t is not None:
+            t.record_stream(stream)
+
+
 def _fork(streams):
     if streams is not None:
         cur = torch.cuda.current_stream()
@@ -155,6 +187,8 @@ class NodeLevelAttention(torch.autograd.Function):
         pj = [None] * P
         src = xs_full if all(replicated) else (xs if not any(replicated) else None)
         streams = cfg.get("streams") if (not multi and cfg.get("streams") is not None and len(cfg["streams"]) >= P) else None
+        # the backward runs dW beside the next meta-path's gather (_on_side); the forward stays one chain
+        side = cfg.get("side_stream") if (streams is None and not multi and train and P > 1 and W.is_cuda) else None
         _fork(streams)
         if streams is None and P > 1 and src is not None and _same_tensor(src) and W.is_contiguous() and src[0].stride(-1) == 1:
             full = all(replicated)
@@ -229,6 +263,7 @@ class NodeLevelAttention(torch.autograd.Function):
                 attend_path(p)
         _join(streams)
         del proj
+        ctx.side = side
         ctx.cfg, ctx.xs, ctx.graphs = cfg, xs, graphs
         ctx.xin_shape = tuple(Xin.shape) if Xin is not None else None
         ctx.saved_per_p = saved
@@ -284,6 +319,7 @@ class NodeLevelAttention(torch.autograd.Function):
         rows = [None] * P
         dres_in = []
         streams = ctx.streams       # the streams the forward ran (and allocated) on
+        side = ctx.side
         _fork(streams)
 
         def rows_path(p):      # row-local halves first; their tables go out while we continue
@@ -326,6 +362,13 @@ class NodeLevelAttention(torch.autograd.Function):
                                              seed_dev=seed_dev)
             rows[p] = None
             ops.score_param_bwd(H, df1, df2, K=K, FP=FP, out=(da1[p], da2[p], db1[p], db2[p]))
+            if side is not None and dXin is None:      # dW(p) beside the transposed-graph gather of meta-path p + 1
+                side.wait_stream(torch.cuda.current_stream())
+                with _on_side(side):
+                    ops.project_bwd(xs[p], dH, K, FP, in_drop=ctx.in_drop, seed=seed,
+                                    row_offset=row_offset, seed_dev=seed_dev, out=dW[p], keep=keep)
+                _used_on(side, dH)
+                return
             ops.project_bwd(xs[p], dH, K, FP, in_drop=ctx.in_drop, seed=seed,
                             row_offset=row_offset, seed_dev=seed_dev, out=dW[p], keep=keep)
             if dXin is not None:
@@ -341,6 +384,8 @@ class NodeLevelAttention(torch.autograd.Function):
             with _on_path(streams, p):
                 cols_path(p)
         _join(streams)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         ctx.saved_per_p = None
         if direct is not None:
             return (dXin,) + (None,) * 11

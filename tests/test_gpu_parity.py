@@ -1452,6 +1452,35 @@ def test_path_streams_do_not_change_the_numbers(dev, monkeypatch):
     assert torch.equal(flats[0], flats[1])
 
 
+@pytest.mark.parametrize("residual", [False, True])
+def test_side_stream_does_not_change_the_numbers(dev, residual):
+    """HANTrainer(side_stream=True): the backward's dW of meta-path p runs on a second stream beside the gather of
+    meta-path p + 1 (layers._on_side).  Same epochs on one stream: bit-equal losses and parameters -- the stream only
+    moves independent launches; dH is handed to it with record_stream, its scratch buffers are its own."""
+    from han_amd import rng as hrng
+    from han_amd.trainer import HANTrainer
+    prob = make_problem(54, 300, 40, 3, 3, [0.05, 0.3, 0.6], residual=residual)
+    x, graphs = gpu_inputs(prob, dev)
+    labels = _t(prob["labels"], dev, torch.int32)
+    tm = _t(prob["mask"].astype(np.uint8), dev, torch.uint8)
+    flats, hist = [], []
+    for flag in (True, False):
+        model, _ = build_model(prob, dev)
+        tr = HANTrainer(model, [x] * 3, graphs, labels, tm, attn_drop=0.6, ffd_drop=0.6, side_stream=flag)
+        assert (model.side_stream is not None) == flag
+        hrng.manual_seed(32)
+        hist.append([[float(v) for v in tr.epoch()] for _ in range(6)])
+        torch.cuda.synchronize()
+        flats.append(model.flat.detach().clone())
+    assert hist[0] == hist[1]
+    assert torch.equal(flats[0], flats[1])
+    # off by default; "auto" stays off at this size (on from 262 144 rows)
+    for kw in ({}, {"side_stream": "auto"}):
+        model, _ = build_model(prob, dev)
+        HANTrainer(model, [x] * 3, graphs, labels, tm, **kw)
+        assert model.side_stream is None
+
+
 def test_workspace_growth_between_graph_replays(dev):
     """The process-global scratch buffers are grow-only and a captured epoch replays with the raw
     pointers it saw: a LARGER request for the same buffers between two replays (another model, a
