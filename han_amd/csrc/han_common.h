@@ -147,6 +147,16 @@ __device__ __forceinline__ float han_row16_sum(float v) {
     return v;
 }
 
+// v of lane (i ^ O) inside an aligned group of 16 lanes, O = 1, 2, 4 or 8, as a DPP operand (no ds_bpermute, no LDS
+// round trip).  O = 4 is row_half_mirror (lane 7 - i of the 8-lane half): the same VALUE as lane i ^ 4 whenever the four
+// lanes of a quad hold equal values -- which they do after the O = 1 and O = 2 steps of a butterfly sum, the only use.
+template <int O>
+__device__ __forceinline__ float han_dpp_xor16(float v) {
+    static_assert(O == 1 || O == 2 || O == 4 || O == 8, "lane distance inside a row of 16");
+    constexpr int ctrl = O == 1 ? 0xB1 : O == 2 ? 0x4E : O == 4 ? 0x141 : 0x128;   // quad_perm x2, row_half_mirror, row_ror:8
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true));
+}
+
 __device__ __forceinline__ float han_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -68,11 +68,12 @@ __device__ __forceinline__ void tile_scores(const ProjFwdArgs &a, int64_t row, b
             s1 += vst[t] * a1c[t];
             s2 += vst[t] * a2c[t];
         }
-#pragma unroll
-        for (int o = 1; o < NL; o <<= 1) {
-            s1 += __shfl_xor(s1, o, 64);
-            s2 += __shfl_xor(s2, o, 64);
-        }
+        // butterfly over the head's NL lanes on DPP operands (bitwise the __shfl_xor butterfly, without its 3-4
+        // ds_bpermute round trips per sum: the fused eval kernel issued 1024 of them per wave)
+        if (NL > 1) { s1 += han_dpp_xor16<1>(s1); s2 += han_dpp_xor16<1>(s2); }
+        if (NL > 2) { s1 += han_dpp_xor16<2>(s1); s2 += han_dpp_xor16<2>(s2); }
+        if (NL > 4) { s1 += han_dpp_xor16<4>(s1); s2 += han_dpp_xor16<4>(s2); }
+        if (NL > 8) { s1 += han_dpp_xor16<8>(s1); s2 += han_dpp_xor16<8>(s2); }
         r1[u] = s1;
         r2[u] = s2;
     }
@@ -83,7 +84,7 @@ __device__ __forceinline__ void tile_scores(const ProjFwdArgs &a, int64_t row, b
         float4_t o1[2], o2[2];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float e1 = __shfl_xor(r1[u], 8, 64), e2 = __shfl_xor(r2[u], 8, 64);
+            const float e1 = han_dpp_xor16<8>(r1[u]), e2 = han_dpp_xor16<8>(r2[u]);
             o1[u >> 1][2 * (u & 1)] = r1[u] + a.b1[2 * u];
             o1[u >> 1][2 * (u & 1) + 1] = e1 + a.b1[2 * u + 1];
             o2[u >> 1][2 * (u & 1)] = r2[u] + a.b2[2 * u];
