@@ -897,6 +897,12 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
     unsigned char *Wt = reinterpret_cast<unsigned char *>(smem);        // G1 B operand: [3][A][144 B]   (transposed [a][k])
     unsigned char *W2s = Wt + 3 * A * SA_WLDB;                          // G2 B operand: [3][64 f][W2LDB] (as stored [f][a])
     float *dp = reinterpret_cast<float *>(W2s + 3 * 64 * W2LDB);        // [4 waves][16][WLD2] fp32
+    // b_omega | u_omega: held in registers up to P = 4; the P = 8 / 16 variants (node sums across lane groups) would
+    // spill five registers, and read the two values of a column tile from LDS instead (3 % slower at P = 4: measured)
+    constexpr bool BU_LDS = G3B && P >= 8;
+    float *bus = dp + 4 * 16 * WLD2;
+    if (BU_LDS)
+        for (int it = threadIdx.x; it < 2 * A; it += 256) bus[it] = it < A ? bw[it] : uw[it - A];
     for (int it = threadIdx.x; it < A * 8; it += 256) {                 // (a, g): k-values 8g..8g+7 of column a
         const int acol = it % A, g = it / A;
         float v[8];
@@ -925,12 +931,14 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    float bcol[TA], ucol[TA], du[TA], db[TA];
+    float bcol[BU_LDS ? 1 : TA], ucol[BU_LDS ? 1 : TA], du[TA], db[TA];
     f32x4 dW[4][TA];
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
-        bcol[t] = bw[16 * t + l15];
-        ucol[t] = uw[16 * t + l15];
+        if constexpr (!BU_LDS) {
+            bcol[t] = bw[16 * t + l15];
+            ucol[t] = uw[16 * t + l15];
+        }
         du[t] = 0.f;
         db[t] = 0.f;
 #pragma unroll
@@ -1068,10 +1076,18 @@ __global__ __launch_bounds__(256) void sem_attn_bwd_wave_b6_kernel(const float *
                     }
                     acc[t] = c;
                 }
+                float bcol_t, ucol_t;
+                if constexpr (BU_LDS) {
+                    bcol_t = bus[16 * t + l15];
+                    ucol_t = bus[A + 16 * t + l15];
+                } else {
+                    bcol_t = bcol[t];
+                    ucol_t = ucol[t];
+                }
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const float v = fast_tanh(acc[t][reg] + bcol[t]);
-                    const float d = ds[reg] * ucol[t] * (1.f - v * v);
+                    const float v = fast_tanh(acc[t][reg] + bcol_t);
+                    const float d = ds[reg] * ucol_t * (1.f - v * v);
                     du[t] += ds[reg] * v;
                     db[t] += d;
                     acc[t][reg] = d;
@@ -2031,7 +2047,7 @@ int launch_bwd(const float *M, const float *w, const float *b, const float *u, c
         const int grid = han_grid_for(N * P, 64, kSemBwdBlocks);
         *grid_out = grid;
         constexpr int A6 = 64 * CA;
-        const size_t blds = (size_t)3 * A6 * SA_WLDB + (size_t)3 * 64 * (A6 * 2 + 32) + (size_t)4 * 16 * (A6 + 4) * sizeof(float);
+        const size_t blds = (size_t)3 * A6 * SA_WLDB + (size_t)3 * 64 * (A6 * 2 + 32) + (size_t)(4 * 16 * (A6 + 4) + 2 * A6) * sizeof(float);
         hipError_t e3 = hipSuccess;
 #define HAN_LAUNCH_BWD_B6_AS(KERNEL, THREADS)                                                            \
     e3 = hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds); \
