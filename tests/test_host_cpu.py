@@ -837,3 +837,32 @@ def test_inplace_change_of_the_node_level_output_raises(cpu_ops):
     M[:, 0, :].mul_(2.0)
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         M.sum().backward()
+
+
+def test_lds_bank_model_on_the_k3_backward_layouts():
+    """tools/lds_banks.py restates the LDS banking rules of the MI355X guide (lane groups and bank width per
+    instruction).  The round-3 K3 backward measured 46 % bank-conflict cycles; the model must say so for its three
+    16-byte read patterns, and must find the round-4 layouts (sem_attn.hip: SA_WLDB = 160, rows of 288 B in G2's column
+    order, dpre tile pitch 132 words with g2_col's k-slots) conflict-free, with the tile's 4-byte writes unchanged."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from lds_banks import cycles
+    l15, l4 = (lambda l: l & 15), (lambda l: l >> 4)
+    # round 3: rows of 144 B / 272 B, dpre pieces at 32 s + 8 l4 floats
+    assert cycles(lambda l: l15(l) * 144 + 16 * l4(l), "read_b128")[0] == 8
+    assert cycles(lambda l: l15(l) * 272 + 16 * l4(l), "read_b128")[0] == 8
+    assert cycles(lambda l: (l15(l) * 132 + 8 * l4(l)) * 4, "read_b128")[0] == 8
+    # round 4
+    g2_col = lambda s, q: 64 * (q & 1) + 32 * (q >> 1) + 8 * s
+    for s2 in range(4):
+        assert cycles(lambda l: l15(l) * 160 + 64 * (s2 & 1) + 16 * l4(l), "read_b128")[0] == 4       # G1: Womega^T fragments
+        assert cycles(lambda l: l15(l) * 288 + (4 * s2 + l4(l)) * 16, "read_b128")[0] == 4            # G2: Womega fragments
+        for half in (0, 4):
+            assert cycles(lambda l: (l15(l) * 132 + g2_col(s2, l4(l)) + half) * 4, "read_b128")[0] == 4   # dpre tile
+    for t in range(8):
+        for reg in range(4):
+            assert cycles(lambda l: ((4 * l4(l) + reg) * 132 + 16 * t + l15(l)) * 4, "write_b32")[0] == 2
+    # a pitch that is a multiple of 256 B serialises a 16-lane group completely
+    assert cycles(lambda l: l15(l) * 256 + 16 * l4(l), "read_b128")[0] == 32
+
