@@ -84,6 +84,7 @@ struct FwdArgs {
     int64_t n_work;
     const int *only_if;      // lean kernels behind the dense path: run only when this device word is non-zero (null: always)
     int deep;                // HAN_FLAG_K2_DEEP (measurements)
+    int shared_hash;         // HAN_FLAG_K2_SHARED_HASH: the shared attention-dropout hash at any size
     float slope;
     uint32_t seed_lo, seed_hi, thr_coef;
     const uint64_t *seed_dev;
@@ -1732,11 +1733,15 @@ static void launch_fwd_rows(const FwdArgs &a, bool train, bool short_rows, hipSt
         // 13.6 ms -- what a CU keeps in flight is waves x steps, and registers spent on deeper unrolls cost more waves
         // than they add rows.)
         constexpr int UE = 4;
-        // (one attention-dropout hash per (edge, four heads) shared by ds_bpermute -- consume_edges<..., DD> -- is bitwise the
-        // same and was measured in one process, profiles/r04_k2_bf16_in_flight_sweep.jsonl: fp32 25.4 -> 24.0 ms at N = 10M
-        // but bf16 18.0 -> 18.9 ms, and 1.84 / 1.56 -> 1.85 / 1.61 ms at N = 1M: the two ds_bpermute per edge cost what
-        // the 11 vector instructions save; not instantiated)
-        if (train && fast) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, true, true><<<grid, 256, 0, st>>>(a);
+        // One attention-dropout hash per (edge, four heads) shared by ds_bpermute -- consume_edges<..., DD> -- is bitwise
+        // the same; measured in one process (profiles/r04_k2_bf16_in_flight_sweep.jsonl): fp32 25.4 -> 24.0 ms at N = 10M,
+        // but bf16 18.0 -> 18.9 ms, and 1.84 / 1.56 -> 1.85 / 1.61 ms at N = 1M -- the two ds_bpermute per edge cost what the
+        // 11 vector instructions save, except where the gather itself is slow: taken for fp32 tables beyond the Infinity
+        // Cache (more than 2M rows of 256 B), or when the caller asks (HAN_FLAG_K2_SHARED_HASH: tests, measurements).
+        constexpr bool DD_OK = FPC == 8 && !BF && !VAL;
+        if (DD_OK && train && fast && (a.shared_hash || a.N > (int64_t)2 * 1000 * 1000)) {
+            if constexpr (DD_OK) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, true, true, true><<<grid, 256, 0, st>>>(a);
+        } else if (train && fast) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, true, true><<<grid, 256, 0, st>>>(a);
         else if (train) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, false, true><<<grid, 256, 0, st>>>(a);
         else if (BF && a.deep) node_attn_fwd_kernel<FPC, false, 1, 8, BF, VAL, false, BF><<<grid, 256, 0, st>>>(a);      // HAN_FLAG_K2_DEEP
         else node_attn_fwd_kernel<FPC, false, 1, UE, BF, VAL, false, BF><<<grid, 256, 0, st>>>(a);
@@ -1882,7 +1887,7 @@ extern "C" int han_node_attn_fwd(const int64_t *rowptr, const int32_t *colidx, c
     FwdArgs a;
     a.rowptr = rowptr; a.colidx = colidx; a.edge_val = edge_val; a.H = H; a.gid = table_gid; a.lsb_mask = fts_drop > 0.f; a.f1 = f1; a.f2g = f2_src; a.a2 = a2; a.b2 = b2; a.c = c; a.res = res;
     a.out = out; a.out_stride = out_stride; a.pre = pre; a.lse = lse; a.aggp = aggp; a.tsum = tsum;
-    a.N = N; a.rows = nullptr; a.n_work = N; a.only_if = nullptr; a.deep = (flags & HAN_FLAG_K2_DEEP) ? 1 : 0; a.slope = slope;
+    a.N = N; a.rows = nullptr; a.n_work = N; a.only_if = nullptr; a.deep = (flags & HAN_FLAG_K2_DEEP) ? 1 : 0; a.shared_hash = (flags & HAN_FLAG_K2_SHARED_HASH) ? 1 : 0; a.slope = slope;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.seed_dev = seed_dev;
     a.thr_coef = coef_drop > 0.f ? han_keep_threshold(1.f - coef_drop) : HAN_KEEP_ALL;
     a.inv_keep_coef = 1.f / (1.f - coef_drop);

@@ -19,12 +19,14 @@ FLAG_XCD_ORDER = 1         # HAN_FLAG_XCD_ORDER: XCD-aware work order for graphs
 FLAG_LEAN = 256            # HAN_FLAG_LEAN: the lean K2 kernels of small graphs (scores read from the table, shared dropout hash, one lane per head at 8 x 8)
 FLAG_K2_DEEP = 512         # HAN_FLAG_K2_DEEP (measurements: bf16 eval forward with 8 steps in flight)
 K2_DEEP = False            # set by tools/k2_regimes.py --deep
+K2_SHARED_HASH = False     # tests / measurements: FLAG_K2_SHARED_HASH on every node_attn_fwd call
 FLAG_MASKED_EDGES = 64     # HAN_FLAG_MASKED_EDGES: negative entries of the transposed graph are skipped in place
 FLAG_K1_EXACT_PIPE = 2     # HAN_FLAG_K1_EXACT_PIPE / _MATRIX_PIPE: force one of the two K1 forward kernels (tests, measurements)
 FLAG_K1_MATRIX_PIPE = 4
 FLAG_K1_4WAVE = 16         # HAN_FLAG_K1_4WAVE (measurements: the two-waves-per-SIMD form of the bf16 x 6 kernel)
 FLAG_K1_PAIRS = 32         # HAN_FLAG_K1_PAIRS (measurements: project_fwd_multi fuses 2 meta-paths per block, not 4)
 FLAG_K3_EXACT_PIPE = 8     # HAN_FLAG_K3_EXACT_PIPE: fp32 MFMA K3 kernels also for large inputs
+FLAG_K2_SHARED_HASH = 1024 # HAN_FLAG_K2_SHARED_HASH: the shared attention-dropout hash of the fp32 training forward at any size
 FLAG_K3_PAIRS = 16         # HAN_FLAG_K3_PAIRS: measurements only (two waves share a tile in the K3 backward)
 FLAG_K3_G3_F32 = 32        # HAN_FLAG_K3_G3_F32: measurements only (dW product of the K3 backward on the fp32 pipe)
 
@@ -441,7 +443,8 @@ def node_attn_fwd(graph: CSRGraph, H_tab, f1, a2, b2, c, out=None, train=False, 
         out.data_ptr(), out.stride(0) if N > 1 else D,
         ptrs[0], ptrs[1], ptrs[2], ptrs[3], N, graph.nnz, K, FP, LEAKY_SLOPE, coef_drop, fts_drop,
         int(seed), _dev_word(seed_dev), int(row_offset), int(activation),
-        (FLAG_XCD_ORDER if graph.has_locality() else 0) | (FLAG_LEAN if lean else 0) | (FLAG_K2_DEEP if K2_DEEP else 0),
+        (FLAG_XCD_ORDER if graph.has_locality() else 0) | (FLAG_LEAN if lean else 0) | (FLAG_K2_DEEP if K2_DEEP else 0)
+        | (FLAG_K2_SHARED_HASH if K2_SHARED_HASH else 0),
         ctypes.byref(split) if split is not None else None,
         ctypes.byref(dense) if dense is not None else None, _stream()), "han_node_attn_fwd")
     if timing is not None:

@@ -686,6 +686,38 @@ def test_semantic_attention_bwd_measurement_forms(dev, n, p, a, form):
         assert rel_err(g.cpu().numpy(), r.cpu().numpy()) < GTOL
 
 
+def test_k2_shared_dropout_hash_is_bitwise_the_default(dev):
+    """HAN_FLAG_K2_SHARED_HASH (taken by the library itself for fp32 tables of more than 2M rows): one attention-dropout
+    hash per (edge, four heads) handed around by ds_bpermute.  Same draws, same arithmetic: the training forward's
+    output and saved state equal the default kernel's bit for bit -- rows of every length up to a few hundred, with the
+    degree bins on."""
+    from han_amd import ops
+    from han_amd.graph import CSRGraph
+    g = torch.Generator(device=dev).manual_seed(5)
+    n = 3000
+    deg = torch.randint(0, 140, (n,), device=dev, generator=g)
+    deg[:7] = torch.tensor([0, 1, 3, 4, 63, 64, 65], device=dev)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    col = torch.randint(0, n, (int(rowptr[-1]),), device=dev, generator=g).to(torch.int32)
+    graph = CSRGraph(rowptr, col, n)
+    rnd = lambda *s: torch.randn(s, device=dev, generator=g)
+    X, W = rnd(n, 24), rnd(24, 64) * 0.2
+    a1, a2, b1, b2, c = rnd(8, 8) * 0.3, rnd(8, 8) * 0.3, rnd(8) * 0.1, rnd(8) * 0.1, rnd(64) * 0.1
+    H, f1, f2 = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.6, fts_drop=0.6, seed=11)
+    res = []
+    for flag in (False, True):
+        ops.K2_SHARED_HASH = flag
+        try:
+            out, sv = ops.node_attn_fwd(graph, H, f1, a2, b2, c, train=True, coef_drop=0.6, fts_drop=0.6, seed=11)
+        finally:
+            ops.K2_SHARED_HASH = False
+        res.append([out.clone()] + [t.clone() for t in sv if t is not None])
+    assert len(res[0]) == len(res[1]) >= 4
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+
+
 def test_empty_inputs_are_noops(dev):
     """N == 0 / E == 0 through the C ABI: every entry point returns without launching
     (edge case of SURVEY.md section 4: empty inputs)."""
