@@ -1734,12 +1734,12 @@ static void launch_fwd_rows(const FwdArgs &a, bool train, bool short_rows, hipSt
         // than they add rows.)
         constexpr int UE = 4;
         // One attention-dropout hash per (edge, four heads) shared by ds_bpermute -- consume_edges<..., DD> -- is bitwise
-        // the same; measured in one process (profiles/r04_k2_bf16_in_flight_sweep.jsonl): fp32 25.4 -> 24.0 ms at N = 10M,
-        // but bf16 18.0 -> 18.9 ms, and 1.84 / 1.56 -> 1.85 / 1.61 ms at N = 1M -- the two ds_bpermute per edge cost what the
-        // 11 vector instructions save, except where the gather itself is slow: taken for fp32 tables beyond the Infinity
-        // Cache (more than 2M rows of 256 B), or when the caller asks (HAN_FLAG_K2_SHARED_HASH: tests, measurements).
+        // the same; measured in one process (profiles/r04_k2_bf16_in_flight_sweep.jsonl): fp32 25.4 -> 24.0 ms at N = 10M on
+        // one box, 25.5 -> 25.7 on another, bf16 18.0 -> 18.9 ms, and 1.84 / 1.56 -> 1.85 / 1.61 ms at N = 1M -- the two
+        // ds_bpermute per edge cost what the 11 vector instructions save.  Not a default anywhere; HAN_FLAG_K2_SHARED_HASH
+        // selects it (fp32 8 x 8 shape) for measurements, and its test pins that the draws are the same.
         constexpr bool DD_OK = FPC == 8 && !BF && !VAL;
-        if (DD_OK && train && fast && (a.shared_hash || a.N > (int64_t)2 * 1000 * 1000)) {
+        if (DD_OK && train && fast && a.shared_hash) {
             if constexpr (DD_OK) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, true, true, true><<<grid, 256, 0, st>>>(a);
         } else if (train && fast) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, true, true><<<grid, 256, 0, st>>>(a);
         else if (train) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, false, true><<<grid, 256, 0, st>>>(a);

@@ -26,7 +26,7 @@ FLAG_K1_MATRIX_PIPE = 4
 FLAG_K1_4WAVE = 16         # HAN_FLAG_K1_4WAVE (measurements: the two-waves-per-SIMD form of the bf16 x 6 kernel)
 FLAG_K1_PAIRS = 32         # HAN_FLAG_K1_PAIRS (measurements: project_fwd_multi fuses 2 meta-paths per block, not 4)
 FLAG_K3_EXACT_PIPE = 8     # HAN_FLAG_K3_EXACT_PIPE: fp32 MFMA K3 kernels also for large inputs
-FLAG_K2_SHARED_HASH = 1024 # HAN_FLAG_K2_SHARED_HASH: the shared attention-dropout hash of the fp32 training forward at any size
+FLAG_K2_SHARED_HASH = 1024 # HAN_FLAG_K2_SHARED_HASH: measurements only (one attention-dropout hash per edge and four heads)
 FLAG_K3_PAIRS = 16         # HAN_FLAG_K3_PAIRS: measurements only (two waves share a tile in the K3 backward)
 FLAG_K3_G3_F32 = 32        # HAN_FLAG_K3_G3_F32: measurements only (dW product of the K3 backward on the fp32 pipe)
 

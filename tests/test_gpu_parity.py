@@ -687,8 +687,8 @@ def test_semantic_attention_bwd_measurement_forms(dev, n, p, a, form):
 
 
 def test_k2_shared_dropout_hash_is_bitwise_the_default(dev):
-    """HAN_FLAG_K2_SHARED_HASH (taken by the library itself for fp32 tables of more than 2M rows): one attention-dropout
-    hash per (edge, four heads) handed around by ds_bpermute.  Same draws, same arithmetic: the training forward's
+    """HAN_FLAG_K2_SHARED_HASH (a measurement form, never a default): one attention-dropout hash per (edge, four heads)
+    handed around by ds_bpermute.  Same draws, same arithmetic: the training forward's
     output and saved state equal the default kernel's bit for bit -- rows of every length up to a few hundred, with the
     degree bins on."""
     from han_amd import ops
