@@ -538,6 +538,10 @@ def main():
     ap.add_argument("--reorder", choices=("none", "bfs"), default="none",
                     help="locality pass (han_amd.reorder): breadth-first relabelling of the nodes before training "
                          "(single GPU; the pass itself is timed separately and reported)")
+    ap.add_argument("--overlap-eval", nargs="?", const="branch", default=None, choices=("branch", "sections"),
+                    help="with --graph: the eval forward of epoch k - 1 as a second branch of the captured epoch beside "
+                         "the training step of epoch k (HANTrainer(overlap_eval=True); same numbers, the validation "
+                         "pair one call late)")
     ap.add_argument("--side-stream", action="store_true",
                     help="HANTrainer(side_stream=True): the backward's dW of meta-path p on a second stream beside the "
                          "gather of meta-path p + 1 (+1.3-2.5 %% epochs/s at SYN-1M; off by default because the gather's "
@@ -641,7 +645,8 @@ def main():
                          wl["val_mask"], lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
                          part=part, use_graph=args.graph and part is None, graphs_local=part is not None,
                          xs_full=[x_full] * p if x_full is not None else None, replicate=args.replicate,
-                         side_stream=bool(args.side_stream))
+                         side_stream=bool(args.side_stream),
+                         overlap_eval=(args.overlap_eval if (args.overlap_eval and args.graph and part is None) else False))
     exchange = None
     if part is not None:
         plans = model.halo_plans[0]
@@ -813,7 +818,11 @@ def main():
                        "(SURVEY.md section 8; (nnz - N)/2 distinct pairs i < j drawn without replacement, mirrored; "
                        "ids ascending per row)",
                        "parallelism": f"node-partition x{world}" if world > 1 else
-                       ("single GPU, epoch replayed from a hipGraph" if use_graph else "single GPU"),
+                       (("single GPU, epoch replayed from a hipGraph" +
+                         ("; eval forward of epoch k-1 runs as a branch beside the training step of epoch k "
+                          f"(overlap_eval = {trainer.overlap_form!r}: every epoch still holds one training step and one "
+                          "eval forward)"
+                          if trainer.overlap_eval else "")) if use_graph else "single GPU"),
                        **({"captured_epoch": {"c_abi_calls": getattr(trainer, "graph_abi_calls", None),
                                               "kernel_nodes_per_epoch": "profiles/r04_*_like_graph_kernel_stats.csv "
                                                                         "(calls / 53 epochs)"}} if use_graph else {}),
@@ -823,7 +832,8 @@ def main():
                        **({"reorder": reorder_info} if reorder_info is not None else {}),
                        "dropout": "0.6/0.6 (train step)", "optimizer": "TF-form Adam lr 0.005, L2 0.001"},
             "final": {"train_loss": round(tl, 5), "train_acc": round(ta, 5),
-                      "val_loss": round(vl, 5), "val_acc": round(va, 5)},
+                      "val_loss": round(vl, 5), "val_acc": round(va, 5),
+                      **({"val_of": "the parameters before the last step (overlap_eval)"} if trainer.overlap_eval else {})},
         }
         if dom is not None:
             # the K2 kernel with the largest total time in the timed region

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--epochs", type=int, default=200)
     ap.add_argument("--patience", type=int, default=100)
     ap.add_argument("--graph", action="store_true", help="replay the epoch from a hipGraph")
+    ap.add_argument("--overlap-eval", action="store_true",
+                    help="with --graph: validate the parameters of epoch k - 1 beside the training step of epoch k "
+                         "(HANTrainer(overlap_eval=True)); the early-stopping rule then sees each pair one call later")
     ap.add_argument("--planted", action="store_true",
                     help="without --mat: a synthetic task WITH structure (communities) instead of the ACM-shaped "
                          "random-label workload, to watch the model learn")
@@ -61,15 +64,21 @@ def main():
 
     model = HeteGAT_multi().build(len(graphs), ft, nb_classes, (8,), (8, 1), 128, device=dev)
     tr = HANTrainer(model, xs, graphs, labels, masks[0], masks[1], lr=0.005, l2_coef=0.001,
-                    attn_drop=0.6, ffd_drop=0.6, patience=args.patience, use_graph=args.graph)
+                    attn_drop=0.6, ffd_drop=0.6, patience=args.patience, use_graph=args.graph,
+                    overlap_eval=args.graph and args.overlap_eval)
     t0 = time.perf_counter()
     for epoch in range(args.epochs):
         tl, ta, vl, va = (float(v) for v in tr.epoch())
+        if tr.overlap_eval and epoch == 0:
+            continue                         # that pair belongs to the initial parameters (ex_acm3025.py has no such line)
         if epoch % 10 == 0:
             print(f"epoch {epoch:4d}  train loss {tl:.5f} acc {ta:.5f} | val loss {vl:.5f} acc {va:.5f}")
         if tr.early_stopping(vl, va):
             print(f"early stop at epoch {epoch}: min val loss {tr.vlss_mn:.5f}, max val acc {tr.vacc_mx:.5f}")
             break
+    else:
+        if tr.overlap_eval:                  # the validation pair of the last epoch
+            tr.early_stopping(*(float(v) for v in tr.flush_eval()))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"{epoch + 1} epochs in {dt:.2f} s ({(epoch + 1) / dt:.1f} epochs/s)")

@@ -68,7 +68,7 @@ class _on_path:
         if self.s is not None:
             self.ctx = torch.cuda.stream(self.s)
             self.ctx.__enter__()
-            self.prev, ops.WS_SUFFIX = ops.WS_SUFFIX, f"@p{self.p}"
+            self.prev, ops.WS_SUFFIX = ops.WS_SUFFIX, ops.WS_SUFFIX + f"@p{self.p}"
 
     def __exit__(self, *exc):
         if self.s is not None:
@@ -93,7 +93,7 @@ class _on_side:
     def __enter__(self):
         self.ctx = torch.cuda.stream(self.s)
         self.ctx.__enter__()
-        self.prev, ops.WS_SUFFIX = ops.WS_SUFFIX, "@side"
+        self.prev, ops.WS_SUFFIX = ops.WS_SUFFIX, ops.WS_SUFFIX + "@side"
 
     def __exit__(self, *exc):
         ops.WS_SUFFIX = self.prev
@@ -190,6 +190,10 @@ class NodeLevelAttention(torch.autograd.Function):
         # the backward runs dW beside the next meta-path's gather (_on_side); the forward stays one chain
         side = cfg.get("side_stream") if (streams is None and not multi and train and P > 1 and W.is_cuda) else None
         _fork(streams)
+        # HANTrainer(overlap_eval=True): the eval forward's K1 + K2 as one more branch of this fork / join section
+        overlap = cfg.get("overlap") if (train and cfg.get("group", 0) == 0) else None
+        if overlap is not None:
+            overlap.node_level()
         if streams is None and P > 1 and src is not None and _same_tensor(src) and W.is_contiguous() and src[0].stride(-1) == 1:
             full = all(replicated)
             Hs, f1s, f2s, keeps = ops.project_fwd_multi(src[0], W, a1, a2, b1, b2, in_drop=in_drop, fts_drop=in_drop,
@@ -262,6 +266,9 @@ class NodeLevelAttention(torch.autograd.Function):
             with _on_path(streams, p):
                 attend_path(p)
         _join(streams)
+        if overlap is not None:
+            overlap.join()
+        ctx.overlap = overlap
         del proj
         ctx.side = side
         ctx.cfg, ctx.xs, ctx.graphs = cfg, xs, graphs
@@ -321,6 +328,8 @@ class NodeLevelAttention(torch.autograd.Function):
         streams = ctx.streams       # the streams the forward ran (and allocated) on
         side = ctx.side
         _fork(streams)
+        if ctx.overlap is not None:      # the eval forward's K3 + classifier beside the per-meta-path backward chains
+            ctx.overlap.head()
 
         def rows_path(p):      # row-local halves first; their tables go out while we continue
             H, f1, f2, _, lse, aggp, tsum, R, _keep = ctx.saved_per_p[p]
@@ -384,6 +393,9 @@ class NodeLevelAttention(torch.autograd.Function):
             with _on_path(streams, p):
                 cols_path(p)
         _join(streams)
+        if ctx.overlap is not None:
+            ctx.overlap.join()
+            ctx.overlap = None
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         ctx.saved_per_p = None
@@ -591,9 +603,13 @@ class ClassifierLoss(torch.autograd.Function):
     Returns (loss, accuracy, logits (N,C)); only `loss` is differentiable."""
 
     @staticmethod
-    def forward(ctx, Z, Wc, bc, labels, mask, row_weight):
-        # (an eval forward under torch.no_grad() must not pay for the gradient half of the kernel)
-        need = any(ctx.needs_input_grad[:3])      # all False under torch.no_grad()
+    def forward(ctx, Z, Wc, bc, labels, mask, row_weight, *grad_mode):
+        # an eval forward under torch.no_grad() must neither pay for the gradient half of the kernel nor, in
+        # direct-gradient mode, WRITE Wc.grad / bc.grad.  needs_input_grad reports requires_grad whatever the grad
+        # mode and the grad mode is off inside every forward(), so the caller passes the one it was called under
+        # (classifier_loss_any); without it the inputs decide, as before
+        need = any(ctx.needs_input_grad[:3]) and (not grad_mode or bool(grad_mode[0]))
+        ctx.n_opt = len(grad_mode)
         ctx.set_materialize_grads(False)      # no zero-filled gradients for the accuracy / logits outputs
         # direct-gradient mode additionally assumes the loss is the root of backward()
         # (d loss = 1), which is how HANTrainer calls it
@@ -613,11 +629,12 @@ class ClassifierLoss(torch.autograd.Function):
     def backward(ctx, dloss, _dacc, _dlogits):
         dZ, dWc, dbc = ctx.grads
         ctx.grads = None
+        tail = (None,) * (3 + ctx.n_opt)
         if ctx.direct:
-            return dZ, None, None, None, None, None
+            return (dZ, None, None) + tail
         if dloss is None:
-            return None, None, None, None, None, None
-        return dZ * dloss, dWc * dloss, dbc * dloss, None, None, None
+            return (None, None, None) + tail
+        return (dZ * dloss, dWc * dloss, dbc * dloss) + tail
 
 
 class _ClassifierForward(torch.autograd.Function):
@@ -686,7 +703,7 @@ def classifier_loss_any(Z, Wc, bc, labels, mask, weight):
     dm = _pad_to(d)
     if dm != d:
         Z, Wc = torch.nn.functional.pad(Z, (0, dm - d)), torch.nn.functional.pad(Wc, (0, 0, 0, dm - d))
-    return ClassifierLoss.apply(Z, Wc, bc, labels, mask, weight)
+    return ClassifierLoss.apply(Z, Wc, bc, labels, mask, weight, torch.is_grad_enabled())
 
 
 # ---------------------------------------------------------------------------

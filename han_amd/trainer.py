@@ -22,12 +22,62 @@ from .gat import HeteGAT_multi
 from .graph import as_graph
 
 
+class _EvalBranch:
+    """HANTrainer(overlap_eval=True): the eval forward of the parameters an epoch starts with, cut in the two pieces
+    that fit the training step's fork / join sections: node_level() (K1 + K2 of every meta-path -> M) runs beside
+    the training forward's per-meta-path chains, head() (K3, classifier, loss; the copy of the parameters) beside
+    the backward's.  Each piece forks `stream` from the current stream, runs as one chain with scratch buffers of
+    its own (ops.WS_SUFFIX) and is joined by the section's own join (`join()`); with stream None the pieces run in
+    place."""
+
+    def __init__(self, trainer, stream):
+        self.tr, self.stream = trainer, stream
+        self.M = self.vl = self.va = None
+
+    def _run(self, fn):
+        m = self.tr.model
+        streams, m.path_streams = m.path_streams, None        # one chain: K1 of every meta-path in one launch
+        branch, m.overlap_branch = getattr(m, "overlap_branch", None), None
+        prev, ops.WS_SUFFIX = ops.WS_SUFFIX, ops.WS_SUFFIX + "@eval"
+        try:
+            with torch.no_grad():
+                if self.stream is None:
+                    fn()
+                else:
+                    self.stream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self.stream):
+                        fn()
+        finally:
+            m.path_streams, m.overlap_branch, ops.WS_SUFFIX = streams, branch, prev
+
+    def join(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+    def node_level(self):
+        tr = self.tr
+
+        def fn():
+            self.M = tr.model.node_level(tr.xs, tr.graphs, 0.0, 0.0, False, ops.ACT_ELU, graphs_t=tr.graphs_t)
+        self._run(fn)
+
+    def head(self):
+        tr = self.tr
+
+        def fn():
+            Z, _ = tr.model.semantic(self.M)
+            self.vl, self.va, _ = tr.model.classifier_loss(Z, tr.labels, tr.val_mask, tr.w_val)
+            tr._flat_prev.copy_(tr.model.flat)
+            self.M = None
+        self._run(fn)
+
+
 class HANTrainer:
     def __init__(self, model: HeteGAT_multi, xs, graphs, labels, train_mask, val_mask=None,
                  lr=0.005, l2_coef=0.001, attn_drop=0.6, ffd_drop=0.6,
                  part: NodePartition | None = None, patience=100, max_halo_fraction=0.6,
                  use_graph=False, graphs_local=False, xs_full=None, replicate="auto", masked_backward=False,
-                 side_stream=False):
+                 side_stream=False, overlap_eval=False):
         """xs: list of P (N_local,F) feature tensors (this rank's rows);
         graphs: list of P CSRGraph (or dense masks / CSR tuples).  Under a partition (`part`) either
         the GLOBAL graphs (graphs_local=False: each rank keeps its row block; small data sets) or --
@@ -44,6 +94,20 @@ class HANTrainer:
         graphs (ACM / DBLP sizes).  The per-step dropout seed and Adam's step count then live
         in a 2-word device state that the graph itself advances (han_hip.h "Seeds").
         Single-process only.
+        overlap_eval (with use_graph; False | True = "branch" | "sections"): the eval forward needs the parameters one training step produced and nothing
+        else of it, and the next step's forward and backward only READ those parameters -- so the captured epoch runs
+        the eval forward of the parameters it STARTS with as a second branch of the graph beside its own training
+        forward and backward, and only Adam waits for both.  Every number is the one the plain epoch computes, the
+        validation pair arrives one call later: call k returns (train loss / accuracy of step k, validation loss /
+        accuracy of the parameters BEFORE step k, i.e. of epoch k - 1; the first call evaluates the initial
+        parameters).  `flush_eval()` evaluates the current parameters (the validation pair of the last epoch), and
+        `early_stopping` snapshots the parameters the validation pair belongs to.  For the launch-bound small
+        graphs, where the eval chain (about a fifth of the epoch's dependent launches) then hides under the
+        training step; on graphs that fill the machine it buys nothing.  "branch": ONE branch from the epoch's first
+        node to Adam (ACM-like 0.398 -> 0.336 ms per epoch, DBLP-like 0.891 -> 0.896); "sections": the eval forward
+        in two pieces inside the training step's own fork / join sections -- K1 + K2 beside the training forward's
+        per-meta-path chains, K3 + classifier beside the backward's (ACM-like 0.384, DBLP-like 0.858: there the eval
+        gather then runs beside the training gathers of the other meta-paths only).
         xs_full: under a partition, optionally the features of ALL rows (P tensors (N,F), the same on
         every rank): the forward passes named by `replicate` ("auto" = dist.replication_policy,
         "all", "eval", "none") then project the whole table on every rank instead of exchanging it;
@@ -112,6 +176,15 @@ class HANTrainer:
         self.vlss_mn, self.vacc_mx, self.curr_step = float("inf"), 0.0, 0
         self.best_state = None
         self.use_graph = bool(use_graph)
+        if overlap_eval not in (False, True, "branch", "sections"):
+            raise ValueError(f"overlap_eval = {overlap_eval!r}: expected False, True, 'branch' or 'sections'")
+        self.overlap_eval = bool(overlap_eval)
+        self.overlap_form = "sections" if overlap_eval == "sections" else "branch"
+        if self.overlap_eval and not self.use_graph:
+            raise ValueError("overlap_eval reorders the captured epoch: it needs use_graph=True")
+        self._eval_stream = None
+        self._force_segments = False  # tests: run the two-piece flow of the captured epoch in place (any backend)
+        self._flat_prev = None        # overlap_eval: the parameters the returned validation pair was computed with
         self._capture = True          # tests switch this off to run the same device-state flow eagerly
         self._graph = None
         self._static_out = None
@@ -134,6 +207,10 @@ class HANTrainer:
             # microseconds on a few CUs (layers._on_path); HAN_PATH_STREAMS=0 keeps the single chain
             if dev.type == "cuda" and os.environ.get("HAN_PATH_STREAMS", "1") != "0" and len(self.graphs) > 1:
                 model.path_streams = [torch.cuda.Stream(device=dev) for _ in self.graphs]
+            if self.overlap_eval:
+                self._flat_prev = torch.empty_like(model.flat)
+                if dev.type == "cuda":
+                    self._eval_stream = torch.cuda.Stream(device=dev)
 
     def set_masked_backward(self, flag: bool):
         """Switch the opt-in masked backward on or off (plans are built on first use; collective under a partition)."""
@@ -254,9 +331,61 @@ class HANTrainer:
 
     def _epoch_body(self):
         self.step_state.add_(self._step_inc)
+        if self.overlap_eval:
+            return self._epoch_body_overlapped()
         tl, ta = self.train_step()
         vl, va = self.eval_step()
         return tl, ta, vl, va
+
+    def _eval_branch(self):
+        """The eval forward of the CURRENT parameters as ONE chain (launched eagerly: the warm-up epoch, the tests'
+        eager flow, the CPU stand-in backend), and the copy of those parameters that early_stopping checkpoints."""
+        br = _EvalBranch(self, None)
+        br.node_level()
+        br.head()
+        return br.vl, br.va
+
+    def _epoch_body_overlapped(self):
+        if not self._force_segments and (self._eval_stream is None or not torch.cuda.is_current_stream_capturing()):
+            # launched eagerly (the warm-up epoch, which also BUILDS the graphs' cached row lists and transposes on the
+            # stream it runs on): one chain, same order of values
+            vl, va = self._eval_branch()
+            tl, ta = self.train_step()
+            return tl, ta, vl, va
+        if self.overlap_form == "branch" and not self._force_segments:
+            # one branch from the epoch's first node to Adam, beside the whole training forward and backward
+            br = _EvalBranch(self, self._eval_stream)
+            br.node_level()
+            br.head()
+            self.model.zero_grad_flat()
+            loss, acc = self._forward(True, self.train_mask, self.w_train)
+            loss.backward()
+            br.join()                                         # Adam overwrites what the branch reads
+            self.opt.step()
+            return loss.detach(), acc, br.vl, br.va
+        # "sections": the eval forward rides in the training step's own fork / join sections (layers.NodeLevelAttention:
+        # K1 + K2 of all meta-paths beside the training forward's per-meta-path chains, K3 + classifier beside the
+        # backward's) -- a series-parallel graph like the plain epoch's
+        br = _EvalBranch(self, None if self._force_segments else self._eval_stream)
+        m = self.model
+        m.overlap_branch = br
+        try:
+            tl, ta = self.train_step()
+        finally:
+            m.overlap_branch = None
+        if br.vl is None:
+            raise NotImplementedError("overlap_eval: the first node-attention layer did not run through "
+                                      "layers.NodeLevelAttention (head shapes beyond 8 x 8 columns)")
+        return tl, ta, br.vl, br.va
+
+    def flush_eval(self):
+        """overlap_eval: the validation pair of the CURRENT parameters (the one the next epoch() would return),
+        launched eagerly; a no-op alias of eval_step() otherwise."""
+        if self.overlap_eval and self._flat_prev is not None:
+            vl, va = self.eval_step()
+            self._flat_prev.copy_(self.model.flat)
+            return vl, va
+        return self.eval_step()
 
     def _epoch_graph(self):
         self._graph_calls += 1
@@ -298,7 +427,9 @@ class HANTrainer:
         stop after `patience` epochs without either improving.  Returns True to stop."""
         if val_acc >= self.vacc_mx or val_loss <= self.vlss_mn:
             if val_acc >= self.vacc_mx and val_loss <= self.vlss_mn:
-                self.best_state = self.model.flat.detach().clone()
+                # overlap_eval: the pair belongs to the parameters before the step that ran beside it
+                src = self._flat_prev if self.overlap_eval else self.model.flat
+                self.best_state = src.detach().clone()
             self.vacc_mx = max(val_acc, self.vacc_mx)
             self.vlss_mn = min(val_loss, self.vlss_mn)
             self.curr_step = 0

@@ -1459,6 +1459,75 @@ def test_captured_epoch_replay_matches_eager_and_oracle(dev):
         assert np.abs(getattr(trainers[0].model, k).detach().cpu().numpy() - bpo[k].numpy()).max() < 2e-4, k
 
 
+def test_eval_forward_leaves_the_gradient_buffer_alone(dev):
+    """The classifier of an eval forward (torch.no_grad()) neither runs the gradient half of its kernel nor -- in the
+    trainer's direct-gradient mode -- writes Wc.grad / bc.grad: ctx.needs_input_grad reports requires_grad whatever
+    the grad mode, so layers.classifier_loss_any hands the grad mode to the Function.  (Until round 4 every eval
+    forward rewrote those two slices of the flat gradient buffer: harmless after Adam, a race beside a training step.)"""
+    from han_amd import layers
+    from han_amd.trainer import HANTrainer
+    prob = make_problem(61, 80, 12, 2, 3, [0.1, 0.4])
+    x, graphs = gpu_inputs(prob, dev)
+    model, _ = build_model(prob, dev)
+    tr = HANTrainer(model, [x, x], graphs, _t(prob["labels"], dev, torch.int32),
+                    _t(prob["mask"].astype(np.uint8), dev, torch.uint8), attn_drop=0.0, ffd_drop=0.0)
+    tr.train_step()
+    marker = torch.full_like(model.flat_grad, 7.0)
+    model.flat_grad.copy_(marker)
+    vl, va = tr.eval_step()
+    assert torch.equal(model.flat_grad, marker) and np.isfinite(float(vl))
+    Z = torch.randn(80, 64, device=dev)
+    with torch.no_grad():
+        l0 = layers.classifier_loss_any(Z, model.Wc, model.bc, tr.labels, tr.train_mask, tr.w_train)[0]
+    assert torch.equal(model.flat_grad, marker)
+    l1 = layers.classifier_loss_any(Z, model.Wc, model.bc, tr.labels, tr.train_mask, tr.w_train)[0]
+    assert float(l0) == float(l1) and not torch.equal(model.flat_grad, marker)     # with grad mode on it does write
+
+
+@pytest.mark.parametrize("form", ["branch", "sections"])
+@pytest.mark.parametrize("shape", ["small", "acm"])
+def test_overlap_eval_branch_of_the_captured_epoch(dev, shape, form):
+    """HANTrainer(use_graph=True, overlap_eval="branch" | "sections"): the eval forward of the parameters an epoch
+    starts with runs beside the training step inside the captured graph -- as one branch that only Adam waits for, or
+    in two pieces inside the training step's own fork / join sections.  Against the plain captured epoch: bit-equal training pairs and parameters in every replay (the eval branch has scratch buffers of its own and
+    never reads a half-updated parameter), the validation pair of epoch k - 1 in call k (the branch projects all
+    meta-paths in one fused K1 launch instead of one launch per path stream, hence a tolerance on that pair)."""
+    from han_amd import rng as hrng
+    from han_amd.trainer import HANTrainer
+    if shape == "small":
+        prob = make_problem(58, 90, 14, 3, 3, [0.05, 0.3, 0.6])
+    else:                       # the ACM-like shape class: split-F K1 (F = 1870) and the lean K2 kernels (24 % dense)
+        prob = make_problem(59, 3025, 1870, 2, 3, [0.003, 0.24])   # at size: the branches really run side by side
+    P = len(prob["biases"])
+    x, graphs = gpu_inputs(prob, dev)
+    labels = _t(prob["labels"], dev, torch.int32)
+    tm = _t(prob["mask"].astype(np.uint8), dev, torch.uint8)
+    vm = _t((~prob["mask"]).astype(np.uint8), dev, torch.uint8)
+    hist, trainers = [], []
+    for overlap in (False, True):
+        model, _ = build_model(prob, dev)
+        hrng.manual_seed(99)
+        tr = HANTrainer(model, [x] * P, graphs, labels, tm, vm, attn_drop=0.6, ffd_drop=0.6, use_graph=True,
+                        overlap_eval=form if overlap else False)
+        hist.append([[float(v) for v in tr.epoch()] for _ in range(7)])
+        for _ in range(120):             # replays issued back to back, no host sync in between (as bench.py does)
+            tr.epoch()
+        torch.cuda.synchronize()
+        trainers.append(tr)
+    plain, over = hist
+    assert trainers[1]._graph is not None and trainers[1]._eval_stream is not None
+    for k in range(7):
+        assert over[k][:2] == plain[k][:2], (k, over[k], plain[k])
+        if k:
+            assert abs(over[k][2] - plain[k - 1][2]) < 1e-5 * max(1.0, abs(plain[k - 1][2])), k
+            assert abs(over[k][3] - plain[k - 1][3]) < 1e-6, k
+    assert torch.equal(trainers[0].model.flat, trainers[1].model.flat)
+    vl, va = trainers[1].flush_eval()
+    vl0, va0 = trainers[0].eval_step()
+    assert abs(float(vl) - float(vl0)) < 1e-5 * max(1.0, abs(float(vl0))) and abs(float(va) - float(va0)) < 1e-6
+    assert torch.equal(trainers[1]._flat_prev, trainers[1].model.flat)
+
+
 def test_path_streams_do_not_change_the_numbers(dev, monkeypatch):
     """a captured epoch forks one stream per meta-path (HAN_PATH_STREAMS, default on).  The same epochs on
     the single chain (HAN_PATH_STREAMS=0) must give bit-equal parameters and losses: the streams only reorder

@@ -296,6 +296,70 @@ def test_device_step_state_mode_matches_oracle(cpu_ops):
         assert np.abs(getattr(model, k).detach().numpy() - bpo[k].numpy()).max() < 2e-5, k
 
 
+def test_eval_forward_does_not_write_gradients(cpu_ops):
+    """An eval forward (torch.no_grad()) leaves the flat gradient buffer alone: the fused classifier computes and, in
+    direct-gradient mode, WRITES dWc / dbc only when the caller's grad mode is on (layers.classifier_loss_any)."""
+    from han_amd import layers
+    from han_amd.trainer import HANTrainer
+    prob = make_problem(33, 40, 8, 2, 3, [0.1, 0.4])
+    model, _ = _cpu_model(prob)
+    x = torch.tensor(prob["x"][0], dtype=torch.float32)
+    tr = HANTrainer(model, [x, x], _cpu_graphs(prob), torch.tensor(prob["labels"], dtype=torch.int32),
+                    torch.tensor(prob["mask"].astype(np.uint8)), attn_drop=0.0, ffd_drop=0.0)
+    tr.train_step()
+    marker = torch.full_like(model.flat_grad, 7.0)
+    model.flat_grad.copy_(marker)
+    tr.eval_step()
+    assert torch.equal(model.flat_grad, marker)
+    Z = torch.randn(40, 64)
+    layers.classifier_loss_any(Z, model.Wc, model.bc, tr.labels, tr.train_mask, tr.w_train)
+    assert not torch.equal(model.flat_grad, marker)
+
+
+def test_overlap_eval_returns_the_plain_epoch_numbers_one_call_late(cpu_ops):
+    """HANTrainer(use_graph=True, overlap_eval=True): call k returns the training pair of step k and the validation
+    pair of the parameters BEFORE step k; flush_eval() gives the pair of the last epoch; early_stopping checkpoints
+    the parameters its pair belongs to.  On the CPU backend the reordered body runs eagerly."""
+    from han_amd import rng as hrng
+    from han_amd.trainer import HANTrainer
+    n, f, drop = 50, 8, 0.6
+    prob = make_problem(31, n, f, 2, 3, [0.1, 0.4])
+    x = torch.tensor(prob["x"][0], dtype=torch.float32)
+    hist, trainers = [], []
+    for overlap in (False, True, "segments"):
+        model, _ = _cpu_model(prob)
+        hrng.manual_seed(123)
+        tr = HANTrainer(model, [x, x], _cpu_graphs(prob), torch.tensor(prob["labels"], dtype=torch.int32),
+                        torch.tensor(prob["mask"].astype(np.uint8)), torch.tensor((~prob["mask"]).astype(np.uint8)),
+                        attn_drop=drop, ffd_drop=drop, use_graph=True, overlap_eval=bool(overlap))
+        # "segments": the flow of the CAPTURED epoch -- the eval forward in two pieces inside the training step's
+        # forward and backward (layers.NodeLevelAttention) -- run in place
+        tr._force_segments = overlap == "segments"
+        if overlap is True:
+            init = tr.model.flat.detach().clone()
+        hist.append([[float(v) for v in tr.epoch()] for _ in range(4)])
+        trainers.append(tr)
+    plain, over, seg = hist
+    for k in range(4):
+        assert over[k][:2] == plain[k][:2], k                     # the training step is untouched
+        assert seg[k] == over[k], (k, seg[k], over[k])
+        if k:
+            assert over[k][2:] == plain[k - 1][2:], k             # validation pair of the epoch before
+    assert torch.equal(trainers[2].model.flat, trainers[0].model.flat)
+    tr = trainers[1]
+    assert torch.equal(tr._flat_prev, trainers[0].model.flat) is False      # (it holds the parameters before step 4)
+    tr.early_stopping(over[3][2], over[3][3])
+    assert tr.best_state is not None and not torch.equal(tr.best_state, tr.model.flat)
+    assert [float(v) for v in tr.flush_eval()] == plain[3][2:]
+    assert torch.equal(tr._flat_prev, tr.model.flat) and torch.equal(tr.model.flat, trainers[0].model.flat)
+    # the first call evaluates the initial parameters
+    model0, _ = _cpu_model(prob)
+    assert torch.equal(model0.flat.detach(), init)
+    with pytest.raises(ValueError):
+        HANTrainer(model0, [x, x], _cpu_graphs(prob), torch.tensor(prob["labels"], dtype=torch.int32),
+                   torch.tensor(prob["mask"].astype(np.uint8)), overlap_eval=True)
+
+
 # -------------------------------------------------------------------- model surface
 def test_model_variables_and_initialisers():
     from han_amd.gat import HeteGAT_multi
