@@ -722,6 +722,7 @@ def main():
                                   "events on the compute stream around every wait for a collective (+ host time of "
                                   "host-staged gloo collectives), max over ranks"}
     use_graph = trainer.use_graph
+    overlap_form = trainer.overlap_form if trainer.overlap_eval else None      # (the trainer is released before the line is built)
     masked_info = None
     if args.masked_backward and not use_graph:
         # the extra, never the headline: same model state, same steps, the backward restricted to the live rows
@@ -820,9 +821,9 @@ def main():
                        "parallelism": f"node-partition x{world}" if world > 1 else
                        (("single GPU, epoch replayed from a hipGraph" +
                          ("; eval forward of epoch k-1 runs as a branch beside the training step of epoch k "
-                          f"(overlap_eval = {trainer.overlap_form!r}: every epoch still holds one training step and one "
+                          f"(overlap_eval = {overlap_form!r}: every epoch still holds one training step and one "
                           "eval forward)"
-                          if trainer.overlap_eval else "")) if use_graph else "single GPU"),
+                          if overlap_form else "")) if use_graph else "single GPU"),
                        **({"captured_epoch": {"c_abi_calls": getattr(trainer, "graph_abi_calls", None),
                                               "kernel_nodes_per_epoch": "profiles/r04_*_like_graph_kernel_stats.csv "
                                                                         "(calls / 53 epochs)"}} if use_graph else {}),
@@ -833,7 +834,7 @@ def main():
                        "dropout": "0.6/0.6 (train step)", "optimizer": "TF-form Adam lr 0.005, L2 0.001"},
             "final": {"train_loss": round(tl, 5), "train_acc": round(ta, 5),
                       "val_loss": round(vl, 5), "val_acc": round(va, 5),
-                      **({"val_of": "the parameters before the last step (overlap_eval)"} if trainer.overlap_eval else {})},
+                      **({"val_of": "the parameters before the last step (overlap_eval)"} if overlap_form else {})},
         }
         if dom is not None:
             # the K2 kernel with the largest total time in the timed region

@@ -91,6 +91,7 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
         self.halo_plans = (None, None)        # (forward, backward) per-meta-path HaloPlan lists
         self.masked_bwd = None                # per-meta-path MaskedBackwardPlan list (HANTrainer(masked_backward=True))
         self.path_streams = None              # one stream per meta-path (HANTrainer(use_graph=True)): layers._on_path
+        self.path_order = "index"             # "heavy": the per-meta-path chains of a captured epoch are issued largest graph first (layers._path_order)
         self.overlap_branch = None            # HANTrainer(overlap_eval=True): the eval forward riding in the captured training step (trainer._EvalBranch)
         self.side_stream = None               # second stream of the eager training step on large graphs (layers._on_side):
                                               # dW of meta-path p runs beside the backward gather of meta-path p + 1
@@ -281,7 +282,7 @@ class HeteGAT_multi(BaseGAttN, torch.nn.Module):
                     "table_dtype": self.table_dtype, "plans_f": self.halo_plans[0],
                     "plans_b": self.halo_plans[1], "xs_full": xs_full if layer == 0 else None,
                     "masked_bwd": self.masked_bwd if (layer == 0 and train) else None,
-                    "streams": self.path_streams, "side_stream": self.side_stream,
+                    "streams": self.path_streams, "side_stream": self.side_stream, "path_order": self.path_order,
                     "overlap": self.overlap_branch if (layer == 0 and train) else None, **kw}
 
         def layer_fwd(layer, Xin, xs_, K, FP, sink):

@@ -104,10 +104,11 @@ class HANTrainer:
         `early_stopping` snapshots the parameters the validation pair belongs to.  For the launch-bound small
         graphs, where the eval chain (about a fifth of the epoch's dependent launches) then hides under the
         training step; on graphs that fill the machine it buys nothing.  "branch": ONE branch from the epoch's first
-        node to Adam (ACM-like 0.398 -> 0.336 ms per epoch, DBLP-like 0.891 -> 0.896); "sections": the eval forward
-        in two pieces inside the training step's own fork / join sections -- K1 + K2 beside the training forward's
-        per-meta-path chains, K3 + classifier beside the backward's (ACM-like 0.384, DBLP-like 0.858: there the eval
-        gather then runs beside the training gathers of the other meta-paths only).
+        node to Adam (one box, 400 replays: ACM-like 0.394 -> 0.325 ms per epoch, DBLP-like 0.859 -> 0.828 with the
+        per-meta-path chains issued largest graph first, layers._path_order); "sections": the eval forward in two
+        pieces inside the training step's own fork / join sections -- K1 + K2 beside the training forward's
+        per-meta-path chains, K3 + classifier beside the backward's (ACM-like 0.384, DBLP-like 0.858 on another box
+        whose plain epochs took 0.398 / 0.891).
         xs_full: under a partition, optionally the features of ALL rows (P tensors (N,F), the same on
         every rank): the forward passes named by `replicate` ("auto" = dist.replication_policy,
         "all", "eval", "none") then project the whole table on every rank instead of exchanging it;
@@ -208,6 +209,7 @@ class HANTrainer:
             if dev.type == "cuda" and os.environ.get("HAN_PATH_STREAMS", "1") != "0" and len(self.graphs) > 1:
                 model.path_streams = [torch.cuda.Stream(device=dev) for _ in self.graphs]
             if self.overlap_eval:
+                model.path_order = "heavy"
                 self._flat_prev = torch.empty_like(model.flat)
                 if dev.type == "cuda":
                     self._eval_stream = torch.cuda.Stream(device=dev)

@@ -166,3 +166,25 @@ def test_bench_gpus_2_starts_two_ranks_by_itself(dev):
     assert d["exchange_bytes_received"] > 0 and d["comm_wait_ms"] >= 0 and d["grad_allreduce_bytes"] > 0
     assert "node-partition x2" in d["config"]["parallelism"]
     assert np.isfinite(d["final"]["train_loss"])
+
+
+def test_bench_default_path_prints_one_complete_line(dev):
+    """The line the driver records: `python bench.py` on one GPU, every leg of the default path switched on (live
+    K2 rooflines, the HBM-regime probe that releases the trainer first, the CPU baseline leg; the skew variant only
+    runs at the full size) at a small size -- one JSON line with the contract's keys, the roofline and cpu_baseline objects."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--nodes", "60000", "--steps", "2", "--warmup", "1",
+                        "--hbm-regime-nodes", "100000", "--cpu-sample", "2000", "--traffic", "static"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.5
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert "roofline_hbm_regime" in d
