@@ -185,6 +185,8 @@ def test_bench_default_path_prints_one_complete_line(dev):
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
-    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.5
+    # ("hbm", or the label of a table that the Infinity Cache / the L2s serve: the same 8 TB/s peak is the yardstick)
+    assert d["roofline"]["bound"] in ("hbm", "fabric / infinity cache", "l2 / infinity cache")
+    assert d["roofline"]["peak"] == 8000.0 and d["roofline"]["frac"] > 0
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
     assert "roofline_hbm_regime" in d
