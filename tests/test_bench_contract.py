@@ -207,6 +207,13 @@ def test_round4_lines_meet_what_they_claim():
     assert dblp["config"]["k2_dense_form"] == [False, False, True] and dblp_csr["config"]["k2_dense_form"] == [False] * 3
     assert dblp["ms_per_step"] <= 1.0 and dblp["value"] > 1.15 * dblp_csr["value"]
     assert acm["config"]["k2_dense_form"] == [False, False]
+    # overlap_eval: the same epochs (bit-equal training pair after 320 of them), faster than the plain epoch of the same box
+    for w in ("acm", "dblp"):
+        ov, pl = lines[f"r04_bench_{w}_like_graph_overlap_eval.json"], lines[f"r04_bench_{w}_like_graph_plain_same_box.json"]
+        assert "overlap_eval" in ov["config"]["parallelism"] and "overlap_eval" not in pl["config"]["parallelism"]
+        assert ov["config"]["workload"] == pl["config"]["workload"] and ov["steps"] == pl["steps"]
+        assert ov["final"]["train_loss"] == pl["final"]["train_loss"] and ov["final"]["train_acc"] == pl["final"]["train_acc"]
+        assert ov["value"] > (1.15 if w == "acm" else 1.03) * pl["value"]
     b16 = lines["r04_bench_syn10m_bf16_1gpu.json"]
     assert "syn-10m" in b16["config"]["workload"] and b16["dtype"].startswith("bf16") and b16["value"] > 1.5
     for name, dd in lines.items():
