@@ -171,21 +171,27 @@ __device__ __forceinline__ int han_bit_mask(int x) {
     return r;
 }
 
-// the 16-bit field `head & 3` of the hash words (hx, hy) that the lane at byte address `src_addr` computed (ds_bpermute)
-__device__ __forceinline__ uint32_t shared_field(const uint32_t hx, const uint32_t hy, const int src_addr, const int head) {
-    const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)hx);
-    const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)hy);
-    const uint32_t wsel = (head & 2) ? y : x;
-    return (head & 1) ? (wsel >> 16) : (wsel & 0xFFFFu);
+// the value lane `u` of this lane's DPP quad (4 consecutive lanes) holds: quad_perm [u, u, u, u], a full-rate move
+// without an LDS round trip
+__device__ __forceinline__ uint32_t quad_bcast(const uint32_t v, const int u) {
+    switch (u) {
+        case 0: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, true);
+        case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xF, 0xF, true);
+        case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA, 0xF, 0xF, true);
+        default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF, 0xF, 0xF, true);
+    }
 }
 
 // Gather U neighbour rows and fold them into the running softmax state.
 // FAST (training launches with both dropouts on and table index == global id): no uniform
 // branch is left inside the edge loop.  ALLV: all U slots hold real edges (full steps), so
 // the validity selects vanish; the tail of a row runs with U = 1.
-// DD (full 4-edge steps of the FAST training launch): the attention-dropout hash of an edge serves four heads, so ONE lane
-// of the 16-lane group computes it (lane q: edge q & 3, head quad (q >> 2) % KQ) and the others fetch their field with
-// ds_bpermute, instead of all 16 lanes hashing every edge.
+// DD (full 4-edge steps of the FAST training launch; HAN_FLAG_K2_SHARED_HASH, a measurement form): the attention-dropout
+// hash of an edge serves four heads and the four lanes of a DPP quad (q = 4m .. 4m+3) sit in ONE head quad, so lane q
+// hashes edge q & 3 of the step for that head quad -- one hash per lane and step instead of four -- and takes the other
+// three edges' words from its quad neighbours by quad_perm broadcasts (round 4 first handed them around with
+// ds_bpermute).  Same keys, same fields: bitwise the per-lane draws.  Neither form is faster than hashing per lane
+// (launch_fwd_rows): the hash is not what the training forward waits for.
 template <int FP, bool TRAIN, int U, bool BF, bool VAL, bool FAST, bool ALLV, bool DD = false>
 __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U], const float (&w)[U],
                                               const bool (&valid)[U], const float f1h, const uint32_t gi, const int q, const int head,
@@ -194,15 +200,13 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
     constexpr int KQ = (HAN_D / FP + 3) / 4;
     static_assert(!DD || (U == 4 && TRAIN && FAST && ALLV), "the shared hash is built for full 4-edge training steps");
     uint32_t dd_x = 0, dd_y = 0;
-    int dd_addr = 0;
     if (DD) {
         const int uu = q & 3;
         const int ju = uu == 0 ? j[0] : (uu == 1 ? j[1] : (uu == 2 ? j[2] : j[U - 1]));
         const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
-                                        (uint32_t)ju * (uint32_t)KQ + (uint32_t)((q >> 2) % KQ));
-        dd_x = rn.x;
-        dd_y = rn.y;
-        dd_addr = (int)(((__lane_id() & 48) + 4 * (head >> 2)) * 4);
+                                        (uint32_t)ju * (uint32_t)KQ + (uint32_t)(head >> 2));
+        if constexpr (FP >= 8) dd_x = (head & 2) ? rn.y : rn.x;      // the word the whole DPP quad reads (head & 2 is uniform in it)
+        else { dd_x = rn.x; dd_y = rn.y; }
     }
     float4_t hv[U];
 #pragma unroll
@@ -238,8 +242,15 @@ __device__ __forceinline__ void consume_edges(const FwdArgs &a, const int (&j)[U
         if (TRAIN) {
             // The 1/keep factors of both dropouts are applied once per row in write_row,
             // not per edge: here a dropped term is simply zeroed.
-            if (DD) {               // attention dropout from the group's shared hash
-                pd = shared_field(dd_x, dd_y, dd_addr + 4 * u, head) < a.thr_coef ? p : 0.f;
+            if (DD) {               // attention dropout from the quad's shared hashes
+                uint32_t wsel;
+                if constexpr (FP >= 8) wsel = quad_bcast(dd_x, u);
+                else {
+                    const uint32_t wx = quad_bcast(dd_x, u), wy = quad_bcast(dd_y, u);
+                    wsel = (head & 2) ? wy : wx;
+                }
+                const uint32_t fld = (head & 1) ? (wsel >> 16) : (wsel & 0xFFFFu);
+                pd = fld < a.thr_coef ? p : 0.f;
             } else if (FAST || drop_c) {   // attention dropout, layers.py:29-30
                 const uint32_t gj = (!FAST && a.gid) ? (uint32_t)a.gid[j[u]] : (uint32_t)j[u];
                 const HanRand64 rn = han_rand64(a.seed_lo, a.seed_hi, HAN_STREAM_COEF, gi,
@@ -1733,12 +1744,17 @@ static void launch_fwd_rows(const FwdArgs &a, bool train, bool short_rows, hipSt
         // 13.6 ms -- what a CU keeps in flight is waves x steps, and registers spent on deeper unrolls cost more waves
         // than they add rows.)
         constexpr int UE = 4;
-        // One attention-dropout hash per (edge, four heads) shared by ds_bpermute -- consume_edges<..., DD> -- is bitwise
-        // the same; measured in one process (profiles/r04_k2_bf16_in_flight_sweep.jsonl): fp32 25.4 -> 24.0 ms at N = 10M on
-        // one box, 25.5 -> 25.7 on another, bf16 18.0 -> 18.9 ms, and 1.84 / 1.56 -> 1.85 / 1.61 ms at N = 1M -- the two
-        // ds_bpermute per edge cost what the 11 vector instructions save.  Not a default anywhere; HAN_FLAG_K2_SHARED_HASH
-        // selects it (fp32 8 x 8 shape) for measurements, and its test pins that the draws are the same.
-        constexpr bool DD_OK = FPC == 8 && !BF && !VAL;
+        // One attention-dropout hash per lane and 4-edge step -- consume_edges<..., DD> -- is bitwise the same and no faster.
+        // With ds_bpermute (profiles/r04_k2_bf16_in_flight_sweep.jsonl): fp32 25.4 -> 24.0 ms at N = 10M on one box, 25.5 ->
+        // 25.7 on another, bf16 18.0 -> 18.9 ms, 1.84 / 1.56 -> 1.85 / 1.61 ms at N = 1M.  With DPP quad broadcasts
+        // (profiles/r04_k2_train_fwd_experiments.jsonl): fp32 24.78 -> 25.00 ms, bf16 18.35 -> 18.41 ms at N = 10M, 1.829 ->
+        // 1.842 / 1.553 -> 1.579 ms at N = 1M -- eleven vector instructions fewer per edge and nothing gained, so vector
+        // issue is not what this kernel waits for.  Nor is it the number of gathers in flight: requesting the rows of a
+        // full step one step ahead (two steps in flight per wave, same occupancy for fp32: 121 registers) moved the fp32
+        // kernels by < 0.5 % at either size and cost the bf16 training forward its fourth wave (138 registers: 18.7 -> 22.7
+        // ms); not in the tree.  HAN_FLAG_K2_SHARED_HASH selects the shared hash for measurements, and its test pins that
+        // the draws are the same.
+        constexpr bool DD_OK = FPC == 8 && !VAL;
         if (DD_OK && train && fast && a.shared_hash) {
             if constexpr (DD_OK) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, true, true, true><<<grid, 256, 0, st>>>(a);
         } else if (train && fast) node_attn_fwd_kernel<FPC, true, 1, 4, BF, VAL, true, true><<<grid, 256, 0, st>>>(a);

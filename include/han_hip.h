@@ -52,10 +52,9 @@ extern "C" {
                                   large tables: the score gather would cost a memory line per edge there.                      */
 #define HAN_FLAG_K2_DEEP 512    /* measurements only: the bf16 eval forward with 8 steps (32 rows) in flight per wave instead of 4
                                   (rounds 2-3's form: more registers, fewer waves; tools/k2_regimes.py --deep)               */
-#define HAN_FLAG_K2_SHARED_HASH 1024 /* measurements only: han_node_attn_fwd, training forward of the 8 x 8 fp32 shape with both dropouts
-                                  on, with ONE attention-dropout hash per (edge, four heads) handed to the other lanes by
-                                  ds_bpermute -- bitwise the same draws; faster on some boxes for tables beyond the Infinity Cache,
-                                  slower or equal everywhere else                                     */
+#define HAN_FLAG_K2_SHARED_HASH 1024 /* measurements only: han_node_attn_fwd, training forward of the 8 x 8 shape with both dropouts
+                                  on, with ONE attention-dropout hash per lane and 4-edge step, the other three edges' words taken
+                                  from the lane's DPP quad -- bitwise the same draws; no faster          */
 #define HAN_FLAG_MASKED_EDGES 64 /* han_node_attn_bwd_cols: entries of rowidx below 0 are skipped IN PLACE (their destination's
                                   g row is identically zero -- a destination outside the loss mask of a one-layer model);
                                   the remaining terms are summed in the positions and order of the full pass, so the

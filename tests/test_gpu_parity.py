@@ -687,8 +687,8 @@ def test_semantic_attention_bwd_measurement_forms(dev, n, p, a, form):
 
 
 def test_k2_shared_dropout_hash_is_bitwise_the_default(dev):
-    """HAN_FLAG_K2_SHARED_HASH (a measurement form, never a default): one attention-dropout hash per (edge, four heads)
-    handed around by ds_bpermute.  Same draws, same arithmetic: the training forward's
+    """HAN_FLAG_K2_SHARED_HASH: one attention-dropout hash per lane and 4-edge step (edge q & 3, the lane's head quad),
+    the other three edges' words taken from the DPP quad neighbours.  Same draws, same arithmetic: the training forward's
     output and saved state equal the default kernel's bit for bit -- rows of every length up to a few hundred, with the
     degree bins on."""
     from han_amd import ops
@@ -704,18 +704,19 @@ def test_k2_shared_dropout_hash_is_bitwise_the_default(dev):
     rnd = lambda *s: torch.randn(s, device=dev, generator=g)
     X, W = rnd(n, 24), rnd(24, 64) * 0.2
     a1, a2, b1, b2, c = rnd(8, 8) * 0.3, rnd(8, 8) * 0.3, rnd(8) * 0.1, rnd(8) * 0.1, rnd(64) * 0.1
-    H, f1, f2 = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.6, fts_drop=0.6, seed=11)
-    res = []
-    for flag in (False, True):
-        ops.K2_SHARED_HASH = flag
-        try:
-            out, sv = ops.node_attn_fwd(graph, H, f1, a2, b2, c, train=True, coef_drop=0.6, fts_drop=0.6, seed=11)
-        finally:
-            ops.K2_SHARED_HASH = False
-        res.append([out.clone()] + [t.clone() for t in sv if t is not None])
-    assert len(res[0]) == len(res[1]) >= 4
-    for x, y in zip(*res):
-        assert torch.equal(x, y)
+    for tdt in (torch.float32, torch.bfloat16):
+        H, f1, f2 = ops.project_fwd(X, W, a1, a2, b1, b2, in_drop=0.6, fts_drop=0.6, seed=11, table_dtype=tdt)
+        res = []
+        for flag in (False, True):
+            ops.K2_SHARED_HASH = flag
+            try:
+                out, sv = ops.node_attn_fwd(graph, H, f1, a2, b2, c, train=True, coef_drop=0.6, fts_drop=0.6, seed=11)
+            finally:
+                ops.K2_SHARED_HASH = False
+            res.append([out.clone()] + [t.clone() for t in sv if t is not None])
+        assert len(res[0]) == len(res[1]) >= 4
+        for x, y in zip(*res):
+            assert torch.equal(x, y), tdt
 
 
 def test_empty_inputs_are_noops(dev):

@@ -67,6 +67,14 @@ def main():
                 t = timeit(lambda: ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=cd,
                                                      fts_drop=fd, seed=3))
                 print(json.dumps({"kernel": f"k2 fwd train {tag} coef_drop={cd} fts_drop={fd}", "ms": round(t, 4)}))
+            if kv.get("shared") == "1":       # A/B in one process: HAN_FLAG_K2_SHARED_HASH off / on, three rounds
+                for rnd_ in range(3):
+                    for sh in (False, True):
+                        ops.K2_SHARED_HASH = sh
+                        t = timeit(lambda: ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=0.6,
+                                                             fts_drop=0.6, seed=3))
+                        print(json.dumps({"kernel": f"k2 fwd train {tag} shared_hash={int(sh)}", "n": n, "ms": round(t, 4)}))
+                ops.K2_SHARED_HASH = False
             _, sv = ops.node_attn_fwd(g, H, f1, a2, b2, c, out=out, train=True, coef_drop=0.6, fts_drop=0.6, seed=3)
             pre, lse, aggp, tsum = sv
             dOut = rnd(n, 64)
