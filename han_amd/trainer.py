@@ -94,8 +94,9 @@ class HANTrainer:
         graphs (ACM / DBLP sizes).  The per-step dropout seed and Adam's step count then live
         in a 2-word device state that the graph itself advances (han_hip.h "Seeds").
         Single-process only.
-        overlap_eval (with use_graph; False | True = "branch" | "sections"): the eval forward needs the parameters one training step produced and nothing
-        else of it, and the next step's forward and backward only READ those parameters -- so the captured epoch runs
+        overlap_eval (with use_graph; False | True = "branch" | "sections"): the eval forward needs the parameters one
+        training step produced and nothing else of it, and the next step's forward and backward only READ those
+        parameters -- so the captured epoch runs
         the eval forward of the parameters it STARTS with as a second branch of the graph beside its own training
         forward and backward, and only Adam waits for both.  Every number is the one the plain epoch computes, the
         validation pair arrives one call later: call k returns (train loss / accuracy of step k, validation loss /
