@@ -633,7 +633,7 @@ class ClassifierLoss(torch.autograd.Function):
                                                       row_weight, backward=need,
                                                       grad_out=(Wc.grad, bc.grad) if ctx.direct else None)
         ctx.grads = grads
-        if ctx.direct:      # views of the kernel's output pair: no clone launches
+        if ctx.direct or not need:      # views of the kernel's output pair: no clone launches (eval forward: nothing to differentiate)
             loss, acc = loss_acc[0:1].view(()), loss_acc[1:2].view(())
         else:
             loss, acc = loss_acc[0].clone(), loss_acc[1].clone()

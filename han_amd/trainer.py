@@ -173,6 +173,9 @@ class HANTrainer:
         self.w_train = 1.0 / max(self._global_count(self.train_mask), 1)
         self.w_val = 1.0 / max(self._global_count(self.val_mask), 1)
         self.opt = TFAdam(model.flat, model.flat_grad, lr=lr, l2_coef=l2_coef)
+        # d loss = 1 handed to backward() instead of the ones_like() autograd would launch per step: in a captured epoch
+        # of the small graphs that 1-element fill is a dependent 5-us launch between the loss and the K3 backward
+        self._one = torch.ones((), dtype=torch.float32, device=dev)
         self.attn_drop, self.ffd_drop = attn_drop, ffd_drop
         self.patience = patience
         self.vlss_mn, self.vacc_mx, self.curr_step = float("inf"), 0.0, 0
@@ -310,7 +313,7 @@ class HANTrainer:
         Returns device scalars (this rank's share of) loss and accuracy."""
         self.model.zero_grad_flat()
         loss, acc = self._forward(True, self.train_mask, self.w_train)
-        loss.backward()
+        loss.backward(self._one)
         if self.part is not None:
             self.part.all_reduce_sum_(self.model.flat_grad)
         self.opt.step()
@@ -362,7 +365,7 @@ class HANTrainer:
             br.head()
             self.model.zero_grad_flat()
             loss, acc = self._forward(True, self.train_mask, self.w_train)
-            loss.backward()
+            loss.backward(self._one)
             br.join()                                         # Adam overwrites what the branch reads
             self.opt.step()
             return loss.detach(), acc, br.vl, br.va
