@@ -471,6 +471,15 @@ constexpr float kLn2 = 0.6931471805599453f;
 __device__ __forceinline__ float han_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // the 16-bit field `head & 3` of the hash that lane (group base + u + 4 * (head >> 2)) computed
+// the same field from the hash words of lane `u` of this lane's DPP quad (quad_perm broadcasts: no LDS round trip).  For
+// the one-lane-per-head kernels: lanes 4c .. 4c+3 of an 8-lane group are the heads of head quad c, and lane 4c + u
+// (u = 0, 1) hashes edge u of the step for that quad.
+__device__ __forceinline__ uint32_t quad_field(const uint32_t hx, const uint32_t hy, const int u, const int head) {
+    const uint32_t x = quad_bcast(hx, u), y = quad_bcast(hy, u);
+    const uint32_t wsel = (head & 2) ? y : x;
+    return (head & 1) ? (wsel >> 16) : (wsel & 0xFFFFu);
+}
+
 __device__ __forceinline__ uint32_t lean_field(const uint32_t hx, const uint32_t hy, const int src_addr, const int head) {
     const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)hx);
     const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)hy);
@@ -652,10 +661,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_h8_kernel(const FwdArgs a_i
     const bool drop_c = TRAIN && a.thr_coef < HAN_KEEP_ALL;
     const bool drop_f = TRAIN && a.lsb_mask;
     const float *Hf = reinterpret_cast<const float *>(a.H);
-    const int pu = h & 1, pc = (h >> 1) & 1;       // this lane hashes for (edge pu of its group, head quad pc)
-    int baddr[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) baddr[u] = ((lane & 56) + 2 * (h >> 2) + u) * 4;
+    const int pu = h & 1, pc = h >> 2;             // this lane hashes for (edge pu of its group, its own head quad): quad_field
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
     for (int64_t row = wave0; row < a.N; row += nwaves) {
         int64_t cur = a.rowptr[row];
@@ -740,7 +746,7 @@ __global__ __launch_bounds__(256) void node_attn_fwd_h8_kernel(const FwdArgs a_i
                     const float p = valid[u] ? han_exp2(ev[u] - mc) : 0.f;
                     l += p;
                     float pd = p;
-                    if (drop_c) pd = lean_field(hx, hy, baddr[u], h) < a.thr_coef ? p : 0.f;
+                    if (drop_c) pd = quad_field(hx, hy, u, h) < a.thr_coef ? p : 0.f;
 #pragma unroll
                     for (int t = 0; t < 8; ++t) acc[t] += pd * hv[u][t];
                     if (TRAIN) {
@@ -1287,11 +1293,8 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_h8_kernel(const BwdCol
     const bool drop_c = a.thr_coef < HAN_KEEP_ALL;
     const float *Hf = reinterpret_cast<const float *>(a.H);
     const char *gsb = reinterpret_cast<const char *>(a.gs);
-    // the hash of (edge u, head quad c) is computed by lane 2c + u of the group (lanes 4..7 duplicate 0..3)
-    const int pu = h & 1, pc = (h >> 1) & 1;
-    int baddr[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) baddr[u] = ((lane & 56) + 2 * (h >> 2) + u) * 4;
+    // the hash of (edge u, head quad c) is computed by lane 4c + u of the group (lanes 4c + 2, 4c + 3 duplicate them)
+    const int pu = h & 1, pc = h >> 2;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
     for (int64_t src = wave0; src < a.NS; src += nwaves) {
         int64_t cur = a.colptr[src];
@@ -1365,7 +1368,7 @@ __global__ __launch_bounds__(256) void node_attn_bwd_cols_h8_kernel(const BwdCol
                     float alpha = __expf(han_lrelu(x, a.slope) - st[u][1]);
                     alpha = valid[u] ? alpha : 0.f;
                     float am = 1.f;
-                    if (drop_c) am = lean_field(hx, hy, baddr[u], h) < a.thr_coef ? a.inv_keep_coef : 0.f;
+                    if (drop_c) am = quad_field(hx, hy, u, h) < a.thr_coef ? a.inv_keep_coef : 0.f;
                     float dot = 0.f;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) dot += g0[u][t] * hd[t] + g1[u][t] * hd[4 + t];
